@@ -1,0 +1,152 @@
+/*
+ * rtvm.h - C ABI of librtvm.so, the MI355X (gfx950) stitching hot path.
+ *
+ * The reference (PROcessorI/Real-Time-Video-Mosaic) has no FFI of its own: the
+ * boundary of its hot path is the Python class VideMosaic (main.py:15-977),
+ * whose arithmetic is delegated to OpenCV calls.  Every entry point below
+ * replaces one of those calls (or the numpy statements around it); the
+ * file:line in each comment is the call site in the reference's main.py that
+ * a maintainer would re-point at this library (through ctypes.CDLL).
+ *
+ * Conventions
+ *   - return value 0 = RTVM_OK, negative = error code; no C++ exception
+ *     crosses this boundary; the message of the last failure on a context is
+ *     returned by rtvm_last_error().
+ *   - every array argument is caller-owned, C-contiguous, and sized as the
+ *     comment states.  Pointers are host pointers unless the entry point says
+ *     "device".  Nothing returned has to be freed by the caller.
+ *   - a context is single-threaded (one video stream, one HIP stream, one
+ *     device).  Distinct contexts may be used from distinct threads/processes.
+ *   - this library contains no CPU fallback: with no usable HIP device
+ *     rtvm_create() fails with RTVM_E_HIP.
+ */
+#ifndef RTVM_H
+#define RTVM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTVM_VERSION 100 /* 0.1.0 */
+
+enum {
+    RTVM_OK = 0,
+    RTVM_E_ARG = -1,        /* bad argument (null pointer, size out of range) */
+    RTVM_E_HIP = -2,        /* HIP runtime error, or no device */
+    RTVM_E_NOMEM = -3,      /* device or host allocation failed */
+    RTVM_E_DEGENERATE = -4, /* geometry is degenerate (singular H, ...) */
+    RTVM_E_STATE = -5       /* call order violated (e.g. warp before canvas_init) */
+};
+
+/* rtvm_create: detector */
+enum { RTVM_DET_ORB = 0, RTVM_DET_SIFT_MATCH_ONLY = 1 };
+
+/* rtvm_create: flags */
+enum {
+    RTVM_FLAG_WARP_FIXED = 1 << 0, /* warpPerspective arithmetic of OpenCV <= 4.10
+                                      (1/32-pixel fixed point); default is the
+                                      fp32 arithmetic of OpenCV >= 4.11 */
+    RTVM_FLAG_MATCH_LEGACY = 1 << 1 /* reserved: one-sided cross-check of OpenCV < 4.2 */
+};
+
+/* per-frame status bits reported by rtvm_process_frame / rtvm_frame_status */
+enum {
+    RTVM_FRAME_OK = 0,
+    RTVM_FRAME_FEW_MATCHES = 1, /* < 4 matches: frame skipped, state not advanced (main.py:722-724) */
+    RTVM_FRAME_NO_HOMOGRAPHY = 2, /* RANSAC found no model: skipped (main.py:729-731) */
+    RTVM_FRAME_INVALID_H = 4    /* validate_homography() failed: identity used (main.py:734-737) */
+};
+
+typedef struct rtvm_ctx rtvm_ctx;
+
+/* ---- life cycle ------------------------------------------------------- */
+
+int rtvm_version(void);
+
+/* Replaces VideMosaic.__init__'s detector/matcher/canvas set-up (main.py:29-37, 80-81).
+ * frame_h/frame_w: size of every frame of the stream; canvas_h/canvas_w: mosaic
+ * canvas (main.py:80-81 computes int(oh*H) x int(ow*W)); nfeatures: ORB_create(n)
+ * (main.py:36).  All device memory the context will ever use is allocated here. */
+int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w, int canvas_h, int canvas_w,
+                int detector, int nfeatures, int flags);
+void rtvm_destroy(rtvm_ctx* ctx);
+const char* rtvm_last_error(const rtvm_ctx* ctx);
+/* Waits for all work queued on the context's stream. */
+int rtvm_sync(rtvm_ctx* ctx);
+/* Upper bound of keypoints rtvm_orb can return (nfeatures plus room for ties at the
+ * retainBest cut); size the output arrays of rtvm_orb with it. */
+int rtvm_max_keypoints(const rtvm_ctx* ctx);
+
+/* ---- stage entry points (host buffers in, host buffers out) ----------- */
+
+/* cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY)  main.py:111,717.
+ * bgr: frame_h*frame_w*3 u8; gray: frame_h*frame_w u8. */
+int rtvm_gray(rtvm_ctx* ctx, const uint8_t* bgr, uint8_t* gray);
+
+/* cv2.cvtColor + cv2.ORB_create(n).detectAndCompute(gray, None)  main.py:36,111-112,717-718.
+ * Outputs (capacity rtvm_max_keypoints()): xy n*2 f32 (level-0 pixel coordinates),
+ * size, angle_deg, response n f32, octave n i32, desc n*32 u8.  Keypoints are
+ * ordered by pyramid level, then row-major inside a level. */
+int rtvm_orb(rtvm_ctx* ctx, const uint8_t* bgr, int* n_out, float* xy, float* size,
+             float* angle_deg, float* response, int32_t* octave, uint8_t* desc);
+
+/* cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(q, t)  main.py:37,695.
+ * q: nq*32 u8, t: nt*32 u8; outputs have capacity nq; matches are emitted in
+ * ascending query index.  nq, nt <= 65535. */
+int rtvm_match_hamming_xcheck(rtvm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                              int32_t* qidx, int32_t* tidx, int32_t* dist, int* m_out);
+/* Same, followed by the stable sort by distance of main.py:698. */
+int rtvm_match_hamming_xcheck_sorted(rtvm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t,
+                                     int nt, int32_t* qidx, int32_t* tidx, int32_t* dist,
+                                     int* m_out);
+
+/* cv2.BFMatcher().knnMatch(q, t, k=2)  main.py:34,688.
+ * q: nq*dim f32, t: nt*dim f32 (nt >= 2); idx: nq*2 i32, dist: nq*2 f32 (ascending). */
+int rtvm_match_l2_knn2(rtvm_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim,
+                       int32_t* idx, float* dist);
+
+/* cv2.findHomography(src, dst, cv2.RANSAC, ransacReprojThreshold=thresh)  main.py:856-857.
+ * src_xy/dst_xy: m*2 f32.  *found = 0 means OpenCV would have returned None.
+ * inlier_mask (m u8) may be NULL. */
+int rtvm_find_homography_ransac(rtvm_ctx* ctx, const float* src_xy, const float* dst_xy, int m,
+                                double thresh, int max_iters, double confidence, double H[9],
+                                uint8_t* inlier_mask, int* found);
+
+/* Canvas zero-fill and paste of the first frame at (row_off, col_off)  main.py:80-90. */
+int rtvm_canvas_init(rtvm_ctx* ctx, const uint8_t* first_bgr, int row_off, int col_off);
+
+/* cv2.warpPerspective(frame, H, (canvas_w, canvas_h), flags=cv2.INTER_LINEAR)  main.py:871.
+ * out: canvas_h*canvas_w*3 u8.  Stage parity only; rtvm_warp_blend does not call it. */
+int rtvm_warp_perspective(rtvm_ctx* ctx, const uint8_t* bgr, const double H[9], uint8_t* out);
+
+/* cv2.distanceTransform(mask, cv2.DIST_L2, 3)  main.py:888-889.
+ * mask: h*w u8 (non-zero = inside), dist: h*w f32.  h*w <= canvas_h*canvas_w. */
+int rtvm_distance_transform(rtvm_ctx* ctx, const uint8_t* mask, int h, int w, float* dist);
+
+/* The whole of VideMosaic.warp(): warp, masks, distance transforms, weights,
+ * 31x31 blur, blend and commit into the canvas  main.py:871-927. */
+int rtvm_warp_blend(rtvm_ctx* ctx, const uint8_t* bgr, const double H[9]);
+
+/* output_img readers  main.py:1632,1649: canvas_h*canvas_w*3 u8 (the reference's
+ * float64 canvas only ever holds these integers).  Syncs the stream. */
+int rtvm_canvas_read(rtvm_ctx* ctx, uint8_t* out);
+
+/* ---- device-resident stream path -------------------------------------- */
+
+/* process_first_frame + canvas set-up (main.py:78-94, 104-112) with a frame that is
+ * already in device memory (frame_h*frame_w*3 u8).  Asynchronous. */
+int rtvm_stream_begin(rtvm_ctx* ctx, const uint8_t* bgr_dev, int row_off, int col_off);
+/* VideMosaic.process_frame (main.py:710-759) for one device-resident frame: ORB,
+ * match, RANSAC, validate, smooth, chain, warp+blend, state advance, all queued on
+ * the context's stream without a host round trip.  Asynchronous. */
+int rtvm_process_frame(rtvm_ctx* ctx, const uint8_t* bgr_dev);
+/* Status bits, match count and the absolute homography of the most recent
+ * rtvm_process_frame (any may be NULL).  Syncs the stream. */
+int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_matches, double H_abs[9]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTVM_H */

@@ -1,0 +1,69 @@
+/*
+ * oracle.h - CPU restatement of the reference's stitching hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load liboracle_rtvm.so.  The product library (librtvm.so) never links,
+ * loads or calls it.
+ *
+ * PARITY UNPINNED.  The arithmetic of the reference's hot path lives in
+ * OpenCV (opencv-python, version not pinned by the reference's
+ * requirements.txt:1-2), which is neither vendored in the reference nor
+ * installed in the build image, and the reference ships no tests, fixtures or
+ * golden vectors.  Each function below restates the published OpenCV 4.x
+ * algorithm behind one call site of the reference's main.py (cited per
+ * function) as plain sequential C++; the numpy statements of main.py itself
+ * (masks, weights, blend, validate, smooth) are restated literally.
+ *
+ * Every function mirrors the signature of the librtvm.so entry point it
+ * checks (include/rtvm.h) minus the context argument.
+ */
+#ifndef RTVM_ORACLE_H
+#define RTVM_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* main.py:111,717  cv2.cvtColor(BGR2GRAY) */
+void rtvm_oracle_gray(const uint8_t* bgr, int h, int w, uint8_t* gray);
+
+/* ORB parameters that are not fixed by the reference call site are OpenCV's defaults. */
+int rtvm_oracle_max_keypoints(int nfeatures);
+/* main.py:36,112,718  cv2.ORB_create(n).detectAndCompute on a BGR frame */
+int rtvm_oracle_orb(const uint8_t* bgr, int h, int w, int nfeatures, int* n_out, float* xy,
+                    float* size, float* angle_deg, float* response, int32_t* octave,
+                    uint8_t* desc);
+/* intermediate products of rtvm_oracle_orb for stage-level checks: level geometry and
+ * the pyramid / blurred pyramid pixels, levels concatenated without borders */
+int rtvm_oracle_orb_pyramid(const uint8_t* gray, int h, int w, int* level_h, int* level_w,
+                            uint8_t* pyr, uint8_t* pyr_blur);
+
+/* main.py:37,695 (+698 when sorted != 0) */
+int rtvm_oracle_match_hamming_xcheck(const uint8_t* q, int nq, const uint8_t* t, int nt,
+                                     int32_t* qidx, int32_t* tidx, int32_t* dist, int* m_out,
+                                     int sorted);
+/* main.py:34,688 */
+int rtvm_oracle_match_l2_knn2(const float* q, int nq, const float* t, int nt, int dim,
+                              int32_t* idx, float* dist);
+
+/* main.py:856-857 */
+int rtvm_oracle_find_homography_ransac(const float* src_xy, const float* dst_xy, int m,
+                                       double thresh, int max_iters, double confidence,
+                                       double H[9], uint8_t* inlier_mask, int* found);
+
+/* main.py:871; fixed != 0 selects the 1/32-pixel fixed-point arithmetic */
+int rtvm_oracle_warp_perspective(const uint8_t* bgr, int fh, int fw, const double H[9], int ch,
+                                 int cw, int fixed, uint8_t* out);
+/* main.py:888-889 */
+void rtvm_oracle_distance_transform(const uint8_t* mask, int h, int w, float* dist);
+/* main.py:897-898  cv2.GaussianBlur(f32, (31,31), 0) */
+void rtvm_oracle_gaussian_blur31(const float* src, int h, int w, float* dst);
+/* main.py:871-927 on a u8 canvas (the reference's float64 canvas holds only these integers) */
+int rtvm_oracle_warp_blend(uint8_t* canvas, int ch, int cw, const uint8_t* bgr, int fh, int fw,
+                           const double H[9], int fixed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,8 @@
+"""MI355X-native stitching hot path behind the reference's VideMosaic API.
+
+The directory name is not a Python identifier; import it with
+``importlib.import_module("real-time-video-mosaic_amd")`` (tests and bench.py
+alias it as ``rtvm``).
+"""
+from . import _ffi  # noqa: F401
+from ._ffi import Context, RtvmError  # noqa: F401

@@ -1,0 +1,220 @@
+"""ctypes binding of librtvm.so (C ABI declared in include/rtvm.h).
+
+There is no CPU fallback: if the library is missing, or no HIP device can be
+opened, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librtvm.so")
+
+OK = 0
+E_ARG, E_HIP, E_NOMEM, E_DEGENERATE, E_STATE = -1, -2, -3, -4, -5
+DET_ORB, DET_SIFT_MATCH_ONLY = 0, 1
+FLAG_WARP_FIXED = 1
+FRAME_FEW_MATCHES, FRAME_NO_HOMOGRAPHY, FRAME_INVALID_H = 1, 2, 4
+
+# name -> (restype, argtypes); also the list the symbol-export test walks
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_intp = C.POINTER(C.c_int)
+_vp = C.c_void_p
+SIGNATURES = {
+    "rtvm_version": (C.c_int, []),
+    "rtvm_create": (C.c_int, [C.POINTER(_vp)] + [C.c_int] * 8),
+    "rtvm_destroy": (None, [_vp]),
+    "rtvm_last_error": (C.c_char_p, [_vp]),
+    "rtvm_sync": (C.c_int, [_vp]),
+    "rtvm_max_keypoints": (C.c_int, [_vp]),
+    "rtvm_gray": (C.c_int, [_vp, _vp, _vp]),
+    "rtvm_orb": (C.c_int, [_vp, _vp, _intp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rtvm_match_hamming_xcheck": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _intp]),
+    "rtvm_match_hamming_xcheck_sorted": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _intp]),
+    "rtvm_match_l2_knn2": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rtvm_find_homography_ransac": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, C.c_double, _vp, _vp, _intp]),
+    "rtvm_canvas_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "rtvm_warp_perspective": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "rtvm_distance_transform": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
+    "rtvm_warp_blend": (C.c_int, [_vp, _vp, _vp]),
+    "rtvm_canvas_read": (C.c_int, [_vp, _vp]),
+    "rtvm_stream_begin": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "rtvm_process_frame": (C.c_int, [_vp, _vp]),
+    "rtvm_frame_status": (C.c_int, [_vp, _intp, _intp, _intp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load librtvm.so once; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "librtvm.so not found at %s: build it with `make lib` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class RtvmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rtvm error %d: %s" % (code, msg))
+        self.code = code
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """Owns one rtvm_ctx (one video stream on one GPU)."""
+
+    def __init__(self, frame_h=0, frame_w=0, canvas_h=0, canvas_w=0, detector=DET_ORB,
+                 nfeatures=700, flags=0, device=0):
+        self._h = C.c_void_p()
+        L = lib()
+        rc = L.rtvm_create(C.byref(self._h), device, frame_h, frame_w, canvas_h, canvas_w,
+                           detector, nfeatures, flags)
+        if rc != OK:
+            self._h = None
+            raise RtvmError(rc, "rtvm_create failed (no HIP device, bad size or out of memory)")
+        self.frame_h, self.frame_w = frame_h, frame_w
+        self.canvas_h, self.canvas_w = canvas_h, canvas_w
+        self.nfeatures = nfeatures
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rtvm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise RtvmError(rc, lib().rtvm_last_error(self._h).decode("utf-8", "replace"))
+
+    # ---- stages ---------------------------------------------------------
+    def max_keypoints(self):
+        return lib().rtvm_max_keypoints(self._h)
+
+    def gray(self, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        out = np.empty(bgr.shape[:2], np.uint8)
+        self._check(lib().rtvm_gray(self._h, ptr(bgr), ptr(out)))
+        return out
+
+    def orb(self, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        assert bgr.shape == (self.frame_h, self.frame_w, 3)
+        cap = self.max_keypoints()
+        n = C.c_int(0)
+        xy = np.empty((cap, 2), np.float32)
+        size = np.empty(cap, np.float32)
+        angle = np.empty(cap, np.float32)
+        resp = np.empty(cap, np.float32)
+        octave = np.empty(cap, np.int32)
+        desc = np.empty((cap, 32), np.uint8)
+        self._check(lib().rtvm_orb(self._h, ptr(bgr), C.byref(n), ptr(xy), ptr(size), ptr(angle),
+                                   ptr(resp), ptr(octave), ptr(desc)))
+        k = n.value
+        return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=angle[:k].copy(),
+                    response=resp[:k].copy(), octave=octave[:k].copy(), desc=desc[:k].copy())
+
+    def match_hamming(self, q, t, sorted_by_distance=False):
+        q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, dtype=np.uint8).reshape(-1, 32)
+        nq, nt = len(q), len(t)
+        qi = np.empty(max(nq, 1), np.int32)
+        ti = np.empty(max(nq, 1), np.int32)
+        di = np.empty(max(nq, 1), np.int32)
+        m = C.c_int(0)
+        fn = lib().rtvm_match_hamming_xcheck_sorted if sorted_by_distance else lib().rtvm_match_hamming_xcheck
+        self._check(fn(self._h, ptr(q), nq, ptr(t), nt, ptr(qi), ptr(ti), ptr(di), C.byref(m)))
+        k = m.value
+        return qi[:k].copy(), ti[:k].copy(), di[:k].copy()
+
+    def match_l2_knn2(self, q, t):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        t = np.ascontiguousarray(t, dtype=np.float32)
+        nq, dim = q.shape
+        nt = t.shape[0]
+        idx = np.empty((nq, 2), np.int32)
+        dist = np.empty((nq, 2), np.float32)
+        self._check(lib().rtvm_match_l2_knn2(self._h, ptr(q), nq, ptr(t), nt, dim, ptr(idx), ptr(dist)))
+        return idx, dist
+
+    def find_homography(self, src_xy, dst_xy, thresh=2.0, max_iters=2000, confidence=0.995):
+        src = np.ascontiguousarray(src_xy, dtype=np.float32).reshape(-1, 2)
+        dst = np.ascontiguousarray(dst_xy, dtype=np.float32).reshape(-1, 2)
+        m = len(src)
+        H = np.zeros(9, np.float64)
+        mask = np.zeros(max(m, 1), np.uint8)
+        found = C.c_int(0)
+        self._check(lib().rtvm_find_homography_ransac(self._h, ptr(src), ptr(dst), m, thresh, max_iters,
+                                                      confidence, ptr(H), ptr(mask), C.byref(found)))
+        if not found.value:
+            return None, mask[:m]
+        return H.reshape(3, 3), mask[:m]
+
+    def canvas_init(self, first_bgr, row_off, col_off):
+        first_bgr = np.ascontiguousarray(first_bgr, dtype=np.uint8)
+        self._check(lib().rtvm_canvas_init(self._h, ptr(first_bgr), int(row_off), int(col_off)))
+
+    def warp_perspective(self, bgr, H):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
+        out = np.empty((self.canvas_h, self.canvas_w, 3), np.uint8)
+        self._check(lib().rtvm_warp_perspective(self._h, ptr(bgr), ptr(H), ptr(out)))
+        return out
+
+    def distance_transform(self, mask):
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        h, w = mask.shape
+        out = np.empty((h, w), np.float32)
+        self._check(lib().rtvm_distance_transform(self._h, ptr(mask), h, w, ptr(out)))
+        return out
+
+    def warp_blend(self, bgr, H):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
+        self._check(lib().rtvm_warp_blend(self._h, ptr(bgr), ptr(H)))
+
+    def canvas_read(self):
+        out = np.empty((self.canvas_h, self.canvas_w, 3), np.uint8)
+        self._check(lib().rtvm_canvas_read(self._h, ptr(out)))
+        return out
+
+    def sync(self):
+        self._check(lib().rtvm_sync(self._h))
+
+    # ---- device-resident stream path -------------------------------------
+    def stream_begin(self, bgr_dev_ptr, row_off, col_off):
+        self._check(lib().rtvm_stream_begin(self._h, C.c_void_p(bgr_dev_ptr), int(row_off), int(col_off)))
+
+    def process_frame(self, bgr_dev_ptr):
+        self._check(lib().rtvm_process_frame(self._h, C.c_void_p(bgr_dev_ptr)))
+
+    def frame_status(self):
+        st, nk, nm = C.c_int(0), C.c_int(0), C.c_int(0)
+        H = np.zeros(9, np.float64)
+        self._check(lib().rtvm_frame_status(self._h, C.byref(st), C.byref(nk), C.byref(nm), ptr(H)))
+        return st.value, nk.value, nm.value, H.reshape(3, 3)

@@ -1,0 +1,163 @@
+// C ABI of librtvm.so (declared in include/rtvm.h): context life cycle and the
+// host-buffer stage entry points.  Each entry point copies its inputs to the
+// context's device buffers, queues the stage's kernels on the context's stream,
+// copies the results back and waits.
+#include "common.h"
+
+#include <new>
+
+namespace {
+
+template <typename T>
+int dev_alloc(rtvm_ctx* c, T** p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e != hipSuccess) RTVM_FAIL(c, RTVM_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    return RTVM_OK;
+}
+
+#define ALLOC(c, field, n)                                    \
+    do {                                                      \
+        int r_ = dev_alloc((c), &(c)->field, (size_t)(n));    \
+        if (r_ != RTVM_OK) return r_;                         \
+    } while (0)
+
+int alloc_all(rtvm_ctx* c) {
+    // matcher
+    const int mk = RTVM_MAX_MATCH;
+    ALLOC(c, d_mq, (size_t)mk * 32);
+    ALLOC(c, d_mt, (size_t)mk * 32);
+    ALLOC(c, d_mcount, 4);
+    ALLOC(c, d_qkey, mk);
+    ALLOC(c, d_tkey, mk);
+    ALLOC(c, d_m_qidx, mk);
+    ALLOC(c, d_m_tidx, mk);
+    ALLOC(c, d_m_dist, mk);
+    ALLOC(c, d_m_count, 4);
+    HIP_TRY(c, hipHostMalloc(&c->h_pinned, 1 << 16, hipHostMallocDefault));
+    return RTVM_OK;
+}
+
+void free_all(rtvm_ctx* c) {
+    void* ptrs[] = {c->d_mq, c->d_mt, c->d_mcount, c->d_qkey, c->d_tkey, c->d_m_qidx, c->d_m_tidx,
+                    c->d_m_dist, c->d_m_count};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+}
+
+}  // namespace
+
+extern "C" int rtvm_version(void) { return RTVM_VERSION; }
+
+extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w, int canvas_h,
+                           int canvas_w, int detector, int nfeatures, int flags) {
+    if (!out) return RTVM_E_ARG;
+    *out = nullptr;
+    if (frame_h < 0 || frame_w < 0 || canvas_h < 0 || canvas_w < 0 || nfeatures < 0) return RTVM_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return RTVM_E_HIP;
+    rtvm_ctx* c = new (std::nothrow) rtvm_ctx;
+    if (!c) return RTVM_E_NOMEM;
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->fh = frame_h;
+    c->fw = frame_w;
+    c->ch = canvas_h;
+    c->cw = canvas_w;
+    c->detector = detector;
+    c->nfeatures = nfeatures;
+    c->flags = flags;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return RTVM_E_HIP;
+    }
+    int r = alloc_all(c);
+    if (r != RTVM_OK) {
+        fprintf(stderr, "rtvm_create: %s\n", c->err);
+        free_all(c);
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return r;
+    }
+    *out = c;
+    return RTVM_OK;
+}
+
+extern "C" void rtvm_destroy(rtvm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_all(c);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* rtvm_last_error(const rtvm_ctx* c) { return c ? c->err : "null context"; }
+
+extern "C" int rtvm_sync(rtvm_ctx* c) {
+    if (!c) return RTVM_E_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTVM_OK;
+}
+
+static int match_hamming_host(rtvm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                              int32_t* qidx, int32_t* tidx, int32_t* dist, int* m_out, int sorted) {
+    if (!c) return RTVM_E_ARG;
+    if (!m_out || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t))
+        RTVM_FAIL(c, RTVM_E_ARG, "match_hamming: bad argument");
+    if (nq > RTVM_MAX_MATCH || nt > RTVM_MAX_MATCH)
+        RTVM_FAIL(c, RTVM_E_ARG, "match_hamming: at most %d descriptors per side", RTVM_MAX_MATCH);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int* hc = (int*)c->h_pinned;
+    hc[0] = nq;
+    hc[1] = nt;
+    HIP_TRY(c, hipMemcpyAsync(c->d_mcount, hc, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (nq) HIP_TRY(c, hipMemcpyAsync(c->d_mq, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    if (nt) HIP_TRY(c, hipMemcpyAsync(c->d_mt, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    int r = rtvm_launch_hamming(c, c->d_mq, c->d_mt, c->d_mcount, c->d_mcount + 1, nq, nt, sorted);
+    if (r != RTVM_OK) return r;
+    HIP_TRY(c, hipMemcpyAsync(hc + 2, c->d_m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int m = hc[2];
+    if (m < 0 || m > nq) RTVM_FAIL(c, RTVM_E_HIP, "match_hamming: device returned count %d", m);
+    if (m) {
+        if (!qidx || !tidx || !dist) RTVM_FAIL(c, RTVM_E_ARG, "match_hamming: null output");
+        HIP_TRY(c, hipMemcpyAsync(qidx, c->d_m_qidx, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(tidx, c->d_m_tidx, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(dist, c->d_m_dist, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    *m_out = m;
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_match_hamming_xcheck(rtvm_ctx* c, const uint8_t* q, int nq, const uint8_t* t,
+                                         int nt, int32_t* qidx, int32_t* tidx, int32_t* dist,
+                                         int* m_out) {
+    return match_hamming_host(c, q, nq, t, nt, qidx, tidx, dist, m_out, 0);
+}
+
+extern "C" int rtvm_match_hamming_xcheck_sorted(rtvm_ctx* c, const uint8_t* q, int nq,
+                                                const uint8_t* t, int nt, int32_t* qidx,
+                                                int32_t* tidx, int32_t* dist, int* m_out) {
+    return match_hamming_host(c, q, nq, t, nt, qidx, tidx, dist, m_out, 1);
+}
+
+// ---- not yet implemented (stubs keep the ABI complete while stages land) ----
+#define RTVM_STUB(ctx) RTVM_FAIL(ctx, RTVM_E_STATE, "%s: not implemented yet", __func__)
+extern "C" int rtvm_max_keypoints(const rtvm_ctx* c) { return c ? c->plan.max_kp : 0; }
+extern "C" int rtvm_gray(rtvm_ctx* c, const uint8_t*, uint8_t*) { RTVM_STUB(c); }
+extern "C" int rtvm_orb(rtvm_ctx* c, const uint8_t*, int*, float*, float*, float*, float*, int32_t*, uint8_t*) { RTVM_STUB(c); }
+extern "C" int rtvm_match_l2_knn2(rtvm_ctx* c, const float*, int, const float*, int, int, int32_t*, float*) { RTVM_STUB(c); }
+extern "C" int rtvm_find_homography_ransac(rtvm_ctx* c, const float*, const float*, int, double, int, double, double*, uint8_t*, int*) { RTVM_STUB(c); }
+extern "C" int rtvm_canvas_init(rtvm_ctx* c, const uint8_t*, int, int) { RTVM_STUB(c); }
+extern "C" int rtvm_warp_perspective(rtvm_ctx* c, const uint8_t*, const double*, uint8_t*) { RTVM_STUB(c); }
+extern "C" int rtvm_distance_transform(rtvm_ctx* c, const uint8_t*, int, int, float*) { RTVM_STUB(c); }
+extern "C" int rtvm_warp_blend(rtvm_ctx* c, const uint8_t*, const double*) { RTVM_STUB(c); }
+extern "C" int rtvm_canvas_read(rtvm_ctx* c, uint8_t*) { RTVM_STUB(c); }
+extern "C" int rtvm_stream_begin(rtvm_ctx* c, const uint8_t*, int, int) { RTVM_STUB(c); }
+extern "C" int rtvm_process_frame(rtvm_ctx* c, const uint8_t*) { RTVM_STUB(c); }
+extern "C" int rtvm_frame_status(rtvm_ctx* c, int*, int*, int*, double*) { RTVM_STUB(c); }

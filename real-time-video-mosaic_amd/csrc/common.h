@@ -1,0 +1,151 @@
+// Internal declarations shared by the translation units of librtvm.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/rtvm.h"
+
+#define RTVM_NLEVELS 8
+#define RTVM_MAX_MATCH 16384   // keypoints per side the Hamming matcher (sorted form) accepts
+#define RTVM_RANSAC_MAX_ITERS 2000
+
+// ---------------------------------------------------------------------------
+// ORB geometry (host side plan, mirrored in device constant tables)
+struct OrbLevel {
+    int w, h;          // level size
+    int pitch;         // row pitch in bytes of the level plane (multiple of 64)
+    size_t off;        // byte offset of the level plane inside a pyramid buffer
+    float scale;       // layerScale[level] = (float)pow(1.2f, level)
+    int quota;         // nfeaturesPerLevel
+    int cand_off;      // first slot of this level in the candidate arrays
+    int cand_cap;      // candidate capacity of this level
+    int sel_off;       // first slot of this level in the per-level selected arrays
+    int sel_cap;       // capacity of the per-level selected arrays
+    int xtab_off;      // offset into the resize x tables
+    int ytab_off;      // offset into the resize y tables
+};
+
+struct OrbPlan {
+    OrbLevel lv[RTVM_NLEVELS];
+    size_t pyr_bytes;  // bytes of one pyramid buffer (all levels)
+    int cand_total;
+    int sel_total;
+    int max_kp;        // capacity of the final keypoint arrays
+    int xtab_total, ytab_total;
+};
+
+// Feature set of one frame, device resident.
+struct FeatSet {
+    float* xy;         // max_kp*2
+    float* size;       // max_kp
+    float* angle;      // max_kp
+    float* response;   // max_kp
+    int32_t* octave;   // max_kp
+    int32_t* lxy;      // max_kp*2 level-pixel coordinates (x,y)
+    uint8_t* desc;     // max_kp*32
+    int* count;        // 1
+};
+
+// Device-side stream state (what VideMosaic keeps between frames).
+struct StreamState {
+    double H_old[9];
+    double H_abs[9];
+    double last_valid_H[9];
+    double hist[5][9];
+    int hist_len;
+    int status;        // RTVM_FRAME_* of the last frame
+    int n_matches;
+    int n_kp;
+    int prev_slot;     // which FeatSet holds the previous frame
+    int frame_index;
+};
+
+struct rtvm_ctx {
+    int device;
+    hipStream_t stream;
+    int fh, fw, ch, cw;
+    int detector, nfeatures, flags;
+    char err[512];
+
+    // --- ORB ---
+    OrbPlan plan;
+    uint8_t* d_bgr;        // staging frame fh*fw*3
+    uint8_t* d_pyr;        // pyramid (un-blurred)
+    uint8_t* d_pyr_blur;   // pyramid after the 7x7 blur
+    uint8_t* d_score;      // FAST score planes, same layout as d_pyr
+    uint16_t* d_xofs;      // resize tables
+    uint16_t* d_xw;
+    uint16_t* d_yofs;
+    uint16_t* d_yw;
+    uint32_t* d_cand;      // candidates: packed (score<<24 | y<<12 | x)?? see orb.hip
+    int* d_cand_count;     // RTVM_NLEVELS counters + RTVM_NLEVELS*256 histogram
+    int* d_sel_count;      // per-level selected counts
+    int32_t* d_sel_lxy;    // per-level selected (x,y)
+    float* d_sel_resp;     // per-level selected harris response
+    FeatSet feat[2];
+
+    // --- matcher ---
+    uint8_t* d_mq;         // staging descriptors for the stage API
+    uint8_t* d_mt;
+    int* d_mcount;         // [nq, nt]
+    uint32_t* d_qkey;      // packed (dist<<16 | idx) per query
+    uint32_t* d_tkey;      // per train
+    int32_t* d_m_qidx;     // matches
+    int32_t* d_m_tidx;
+    int32_t* d_m_dist;
+    int* d_m_count;
+    // L2 matcher
+    float* d_lq;
+    float* d_lt;
+    int32_t* d_l_idx;
+    float* d_l_dist;
+    size_t l_cap_q, l_cap_t;
+
+    // --- RANSAC ---
+    float* d_rs_src;       // m*2
+    float* d_rs_dst;
+    int* d_rs_count;
+    void* d_rs_work;       // workspace, see ransac.hip
+    double* d_rs_H;        // 9 doubles + found flag area
+    uint8_t* d_rs_mask;
+
+    // --- canvas / warp / blend ---
+    uint8_t* d_canvas;     // ch*cw*3
+    uint8_t* d_warped;     // ch*cw*3
+    uint8_t* d_mask_new;   // ch*cw
+    uint8_t* d_mask_old;   // ch*cw
+    uint16_t* d_dt_s;      // diagonal step planes: [2 masks][2 orientations][ch*cw]
+    uint32_t* d_dt_r;      // row-pass planes [2][ch*cw]
+    uint32_t* d_dt_c;      // column forward pass planes [2][ch*cw]
+    float* d_dist;         // [2][ch*cw]
+    float* d_rb;           // row-blurred weights [2][ch*cw]
+    double* d_H;           // 9 doubles (warp input) + 9 (inverse)
+    int* d_roi;            // x0,y0,x1,y1 of the clipped warped quad
+    int canvas_ready;
+
+    StreamState* d_state;
+    void* h_pinned;        // small pinned host buffer for read-backs
+};
+
+#define RTVM_FAIL(ctx, code, ...)                         \
+    do {                                                  \
+        snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); \
+        return (code);                                    \
+    } while (0)
+
+#define HIP_TRY(ctx, expr)                                                            \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            RTVM_FAIL(ctx, RTVM_E_HIP, "%s failed: %s (%s:%d)", #expr,                \
+                      hipGetErrorString(e_), __FILE__, __LINE__);                     \
+    } while (0)
+
+// ---- launchers implemented by the stage files (all asynchronous on ctx->stream) ----
+// match.hip
+int rtvm_launch_hamming(rtvm_ctx* c, const uint8_t* dq, const uint8_t* dt, const int* d_nq,
+                        const int* d_nt, int cap_q, int cap_t, int sorted);
+int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim,
+                        int32_t* d_idx, float* d_dist);

@@ -1,0 +1,168 @@
+// Brute-force descriptor matchers for gfx950.
+//
+// Hamming (ORB): all-pairs distance between 256-bit descriptors, nearest
+// neighbour in both directions, mutual-nearest-neighbour filter, optional
+// stable sort by distance.  Replaces cv2.BFMatcher(NORM_HAMMING,
+// crossCheck=True).match and the sorted() that follows it (reference
+// main.py:37,695,698).
+#include "common.h"
+
+namespace {
+
+// One wave per (64 rows of A) x (64 rows of B).  Lane l keeps row l of the A
+// tile in registers and row l of the B chunk; the B rows are then broadcast one
+// at a time through v_readlane (scalar operands), so the inner loop is 8 xor +
+// 8 popcount-accumulate per pair and touches no memory.  The per-row minimum
+// is merged across B chunks with one atomicMin on a packed (dist << 16 | index)
+// key, whose integer order is exactly "smaller distance first, then lower
+// index", i.e. OpenCV's first-minimum rule.
+// blockIdx.z = 0: A = query, B = train; 1: A = train, B = query.
+__global__ __launch_bounds__(64) void k_hamming_argmin(const uint8_t* __restrict__ q,
+                                                       const uint8_t* __restrict__ t,
+                                                       const int* __restrict__ nq_p,
+                                                       const int* __restrict__ nt_p,
+                                                       uint32_t* __restrict__ qkey,
+                                                       uint32_t* __restrict__ tkey) {
+    const int dir = blockIdx.z;
+    const uint8_t* A = dir ? t : q;
+    const uint8_t* B = dir ? q : t;
+    const int nA = dir ? *nt_p : *nq_p;
+    const int nB = dir ? *nq_p : *nt_p;
+    uint32_t* key = dir ? tkey : qkey;
+    const int a0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    if (a0 >= nA || b0 >= nB) return;
+    const int lane = threadIdx.x;
+    const int ia = min(a0 + lane, nA - 1), ib = min(b0 + lane, nB - 1);
+    const uint4* pa = reinterpret_cast<const uint4*>(A + (size_t)ia * 32);
+    const uint4* pb = reinterpret_cast<const uint4*>(B + (size_t)ib * 32);
+    const uint4 a_lo = pa[0], a_hi = pa[1];
+    const uint4 b_lo = pb[0], b_hi = pb[1];
+    const int nb = min(64, nB - b0);
+    uint32_t best = 0xFFFFFFFFu;
+#pragma unroll 8
+    for (int k = 0; k < 64; k++) {
+        uint32_t d;
+        d = __popc(a_lo.x ^ (uint32_t)__builtin_amdgcn_readlane((int)b_lo.x, k));
+        d += __popc(a_lo.y ^ (uint32_t)__builtin_amdgcn_readlane((int)b_lo.y, k));
+        d += __popc(a_lo.z ^ (uint32_t)__builtin_amdgcn_readlane((int)b_lo.z, k));
+        d += __popc(a_lo.w ^ (uint32_t)__builtin_amdgcn_readlane((int)b_lo.w, k));
+        d += __popc(a_hi.x ^ (uint32_t)__builtin_amdgcn_readlane((int)b_hi.x, k));
+        d += __popc(a_hi.y ^ (uint32_t)__builtin_amdgcn_readlane((int)b_hi.y, k));
+        d += __popc(a_hi.z ^ (uint32_t)__builtin_amdgcn_readlane((int)b_hi.z, k));
+        d += __popc(a_hi.w ^ (uint32_t)__builtin_amdgcn_readlane((int)b_hi.w, k));
+        // rows past the end of B were loaded clamped; keep them out of the minimum
+        best = min(best, k < nb ? ((d << 16) | (uint32_t)(b0 + k)) : 0xFFFFFFFFu);
+    }
+    if (a0 + lane < nA) atomicMin(&key[a0 + lane], best);
+}
+
+__global__ void k_fill_u32(uint32_t* p, uint32_t v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// Single workgroup: mutual-NN filter, order-preserving compaction (ascending
+// query index) and, when sorted != 0, a bitonic sort of (dist << 16 | position)
+// keys, which is the stable sort by distance of main.py:698.
+__global__ __launch_bounds__(1024) void k_xcheck_compact(const uint32_t* __restrict__ qkey,
+                                                         const uint32_t* __restrict__ tkey,
+                                                         const int* __restrict__ nq_p,
+                                                         const int* __restrict__ nt_p,
+                                                         int32_t* __restrict__ m_qidx,
+                                                         int32_t* __restrict__ m_tidx,
+                                                         int32_t* __restrict__ m_dist,
+                                                         int* __restrict__ m_count, int sorted) {
+    __shared__ uint32_t s_key[RTVM_MAX_MATCH];  // (dist << 16 | position)
+    __shared__ uint16_t s_q[RTVM_MAX_MATCH];
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = *nq_p, nt = *nt_p;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nq; i0 += 1024) {
+        const int i = i0 + tid;
+        bool ok = false;
+        uint32_t kq = 0;
+        if (i < nq && nt > 0) {
+            kq = qkey[i];
+            const uint32_t j = kq & 0xFFFFu;
+            ok = (tkey[j] & 0xFFFFu) == (uint32_t)i;
+        }
+        const unsigned long long bal = __ballot(ok);
+        const int wrank = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += s_wave[w];
+        const int base = s_base;
+        if (ok) {
+            const int pos = base + woff + wrank;
+            s_key[pos] = (kq & 0xFFFF0000u) | (uint32_t)pos;
+            s_q[pos] = (uint16_t)i;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += s_wave[w];
+            s_base = base + tot;
+        }
+        __syncthreads();
+    }
+    const int m = s_base;
+    if (sorted && m > 1) {
+        int n2 = 1;
+        while (n2 < m) n2 <<= 1;
+        for (int i = m + tid; i < n2; i += 1024) s_key[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < n2; i += 1024) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const uint32_t a = s_key[i], b = s_key[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) {
+                            s_key[i] = b;
+                            s_key[ixj] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    for (int p = tid; p < m; p += 1024) {
+        const uint32_t key = s_key[p];
+        const int src = (int)(key & 0xFFFFu);  // position before sorting
+        const int qi = s_q[src];
+        m_qidx[p] = qi;
+        m_tidx[p] = (int)(qkey[qi] & 0xFFFFu);
+        m_dist[p] = (int)(key >> 16);
+    }
+    if (tid == 0) *m_count = m;
+}
+
+}  // namespace
+
+// dq/dt: device descriptors; d_nq/d_nt: device counts; cap_q/cap_t: upper bounds
+// of the counts (grid sizing).  Results land in c->d_m_* / c->d_m_count.
+int rtvm_launch_hamming(rtvm_ctx* c, const uint8_t* dq, const uint8_t* dt, const int* d_nq,
+                        const int* d_nt, int cap_q, int cap_t, int sorted) {
+    if (cap_q > RTVM_MAX_MATCH || cap_t > RTVM_MAX_MATCH)
+        RTVM_FAIL(c, RTVM_E_ARG, "hamming matcher: at most %d descriptors per side", RTVM_MAX_MATCH);
+    const int nfill = cap_q > cap_t ? cap_q : cap_t;
+    if (nfill > 0) {
+        hipLaunchKernelGGL(k_fill_u32, dim3((nfill + 255) / 256), dim3(256), 0, c->stream, c->d_qkey,
+                           0xFFFFFFFFu, cap_q);
+        hipLaunchKernelGGL(k_fill_u32, dim3((nfill + 255) / 256), dim3(256), 0, c->stream, c->d_tkey,
+                           0xFFFFFFFFu, cap_t);
+        const int tiles = (nfill + 63) / 64;
+        hipLaunchKernelGGL(k_hamming_argmin, dim3(tiles, tiles, 2), dim3(64), 0, c->stream, dq, dt, d_nq,
+                           d_nt, c->d_qkey, c->d_tkey);
+    }
+    hipLaunchKernelGGL(k_xcheck_compact, dim3(1), dim3(1024), 0, c->stream, c->d_qkey, c->d_tkey, d_nq,
+                       d_nt, c->d_m_qidx, c->d_m_tidx, c->d_m_dist, c->d_m_count, sorted);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}

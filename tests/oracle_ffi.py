@@ -1,0 +1,48 @@
+"""ctypes binding of oracle/liboracle_rtvm.so (the CPU restatement).  Tests only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "oracle", "liboracle_rtvm.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("oracle library missing: run `make oracle`")
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def match_hamming(q, t, sorted_by_distance=False):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    nq, nt = len(q), len(t)
+    qi = np.empty(max(nq, 1), np.int32)
+    ti = np.empty(max(nq, 1), np.int32)
+    di = np.empty(max(nq, 1), np.int32)
+    m = C.c_int(0)
+    rc = lib().rtvm_oracle_match_hamming_xcheck(_p(q), nq, _p(t), nt, _p(qi), _p(ti), _p(di),
+                                                C.byref(m), int(sorted_by_distance))
+    assert rc == 0
+    k = m.value
+    return qi[:k].copy(), ti[:k].copy(), di[:k].copy()
+
+
+def match_l2_knn2(q, t):
+    q = np.ascontiguousarray(q, np.float32)
+    t = np.ascontiguousarray(t, np.float32)
+    nq, dim = q.shape
+    idx = np.empty((nq, 2), np.int32)
+    dist = np.empty((nq, 2), np.float32)
+    rc = lib().rtvm_oracle_match_l2_knn2(_p(q), nq, _p(t), len(t), dim, _p(idx), _p(dist))
+    assert rc == 0
+    return idx, dist

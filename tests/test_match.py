@@ -1,0 +1,118 @@
+"""Matcher: oracle vs numpy twin vs golden fixtures (CPU), HIP vs oracle (GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_ffi as orc
+sys.path.insert(0, os.path.join(orc.ROOT, "oracle"))
+import np_twin  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def make_desc(seed, nq, nt, planted=0.6, noise_bits=20, ties=True):
+    """Random 256-bit descriptors with planted correspondences and exact duplicates."""
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    k = int(min(nq, nt) * planted)
+    src = rng.permutation(nt)[:k]
+    dst = rng.permutation(nq)[:k]
+    q[dst] = t[src]
+    for i in dst:  # flip a few bits
+        nb = rng.integers(0, noise_bits + 1)
+        bits = rng.integers(0, 256, nb)
+        for b in bits:
+            q[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    if ties and nt >= 8 and nq >= 8:
+        t[3] = t[1]          # duplicate train rows: first index must win
+        t[7] = t[1]
+        q[5] = q[2]          # duplicate query rows
+        q[0] = t[1]
+    return q, t
+
+
+CASES = [(0, 0), (0, 5), (5, 0), (1, 1), (3, 70), (70, 3), (64, 64), (65, 63), (700, 700), (1000, 900)]
+
+
+@pytest.mark.parametrize("nq,nt", CASES)
+@pytest.mark.parametrize("srt", [False, True])
+def test_oracle_matches_numpy_twin(nq, nt, srt):
+    q, t = make_desc(nq * 131 + nt, nq, nt)
+    a = orc.match_hamming(q, t, srt)
+    b = np_twin.match_hamming_xcheck(q, t, srt)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_oracle_golden_fixture():
+    g = np.load(os.path.join(GOLD, "match_hamming.npz"))
+    for tag in ("a", "b"):
+        got = orc.match_hamming(g["q_" + tag], g["t_" + tag], True)
+        assert np.array_equal(got[0], g["qi_" + tag])
+        assert np.array_equal(got[1], g["ti_" + tag])
+        assert np.array_equal(got[2], g["di_" + tag])
+
+
+def test_mutual_nn_property():
+    q, t = make_desc(7, 300, 280)
+    qi, ti, di = orc.match_hamming(q, t)
+    D = np_twin.hamming_matrix(q, t)
+    assert np.all(np.diff(qi) > 0)
+    for i, j, d in zip(qi, ti, di):
+        assert D[i, j] == d == D[i].min() == D[:, j].min()
+    assert len(set(ti.tolist())) == len(ti)
+
+
+def test_l2_oracle_matches_numpy_twin():
+    rng = np.random.default_rng(3)
+    t = rng.integers(0, 256, (150, 128)).astype(np.float32)
+    q = rng.integers(0, 256, (120, 128)).astype(np.float32)
+    q[:60] = t[:60] + rng.integers(-3, 4, (60, 128))
+    t[9] = t[4]
+    q[1] = t[4]
+    a = orc.match_l2_knn2(q, t)
+    b = np_twin.match_l2_knn2(q, t)
+    assert np.array_equal(a[0], b[0])
+    assert np.array_equal(a[1], b[1])
+
+
+# ---------------------------------------------------------------- GPU parity
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nt", CASES + [(4000, 4000), (4097, 3999)])
+@pytest.mark.parametrize("srt", [False, True])
+def test_hip_hamming_bit_exact(ctx_small, nq, nt, srt):
+    q, t = make_desc(nq * 17 + nt + 1, nq, nt)
+    got = ctx_small.match_hamming(q, t, srt)
+    ref = orc.match_hamming(q, t, srt)
+    for x, y in zip(got, ref):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_hip_hamming_golden(ctx_small):
+    g = np.load(os.path.join(GOLD, "match_hamming.npz"))
+    for tag in ("a", "b"):
+        got = ctx_small.match_hamming(g["q_" + tag], g["t_" + tag], True)
+        assert np.array_equal(got[0], g["qi_" + tag])
+        assert np.array_equal(got[1], g["ti_" + tag])
+        assert np.array_equal(got[2], g["di_" + tag])
+
+
+@pytest.mark.gpu
+def test_hip_hamming_all_identical(ctx_small):
+    """Every distance ties at 0: lowest index wins in both directions -> one match (0,0)."""
+    q = np.zeros((100, 32), np.uint8)
+    t = np.zeros((90, 32), np.uint8)
+    qi, ti, di = ctx_small.match_hamming(q, t, True)
+    assert qi.tolist() == [0] and ti.tolist() == [0] and di.tolist() == [0]
+
+
+@pytest.mark.gpu
+def test_hip_hamming_rejects_oversize(ctx_small):
+    import rtvm
+    q = np.zeros((16385, 32), np.uint8)
+    with pytest.raises(rtvm.RtvmError):
+        ctx_small.match_hamming(q, q[:10])
