@@ -36,12 +36,35 @@ int alloc_all(rtvm_ctx* c) {
     ALLOC(c, d_m_dist, mk);
     ALLOC(c, d_m_count, 4);
     HIP_TRY(c, hipHostMalloc(&c->h_pinned, 1 << 16, hipHostMallocDefault));
+    // frame staging
+    const size_t f_px = (size_t)c->fh * c->fw;
+    ALLOC(c, d_bgr, f_px * 3);
+    // canvas / warp / blend
+    const size_t n_px = (size_t)c->ch * c->cw;
+    ALLOC(c, d_canvas, n_px * 3);
+    ALLOC(c, d_warped, n_px * 3);
+    ALLOC(c, d_mask_new, n_px);
+    ALLOC(c, d_mask_old, n_px);
+    ALLOC(c, d_dt_s, n_px * 4);
+    ALLOC(c, d_dt_r, n_px * 2);
+    ALLOC(c, d_dt_f, n_px * 2);
+    ALLOC(c, d_dist, n_px * 2);
+    ALLOC(c, d_wgt, n_px * 2);
+    ALLOC(c, d_rb, n_px * 2);
+    ALLOC(c, d_gk, 32);
+    ALLOC(c, d_H, 16);
+    ALLOC(c, d_wp, 1);
+    ALLOC(c, d_jobs, 3);
+    int r = rtvm_warp_setup(c);
+    if (r != RTVM_OK) return r;
     return RTVM_OK;
 }
 
 void free_all(rtvm_ctx* c) {
     void* ptrs[] = {c->d_mq, c->d_mt, c->d_mcount, c->d_qkey, c->d_tkey, c->d_m_qidx, c->d_m_tidx,
-                    c->d_m_dist, c->d_m_count};
+                    c->d_m_dist, c->d_m_count, c->d_bgr, c->d_canvas, c->d_warped, c->d_mask_new, c->d_mask_old,
+                    c->d_dt_s, c->d_dt_r, c->d_dt_f, c->d_dist, c->d_wgt, c->d_rb, c->d_gk, c->d_H, c->d_wp,
+                    c->d_jobs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -146,6 +169,100 @@ extern "C" int rtvm_match_hamming_xcheck_sorted(rtvm_ctx* c, const uint8_t* q, i
     return match_hamming_host(c, q, nq, t, nt, qidx, tidx, dist, m_out, 1);
 }
 
+// ---- canvas / warp / blend ------------------------------------------------
+static int need_canvas(rtvm_ctx* c, const char* who) {
+    if (c->ch <= 0 || c->cw <= 0 || c->fh <= 0 || c->fw <= 0)
+        RTVM_FAIL(c, RTVM_E_STATE, "%s: context was created without frame/canvas size", who);
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_canvas_init(rtvm_ctx* c, const uint8_t* first_bgr, int row_off, int col_off) {
+    if (!c) return RTVM_E_ARG;
+    if (!first_bgr) RTVM_FAIL(c, RTVM_E_ARG, "canvas_init: null frame");
+    int r = need_canvas(c, "canvas_init");
+    if (r) return r;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bgr, first_bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
+    r = rtvm_launch_canvas_init(c, c->d_bgr, row_off, col_off);
+    if (r) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTVM_OK;
+}
+
+static int upload_H(rtvm_ctx* c, const double H[9]) {
+    double* hp = (double*)c->h_pinned + 16;
+    memcpy(hp, H, 9 * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(c->d_H, hp, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_warp_perspective(rtvm_ctx* c, const uint8_t* bgr, const double H[9], uint8_t* out) {
+    if (!c) return RTVM_E_ARG;
+    if (!bgr || !H || !out) RTVM_FAIL(c, RTVM_E_ARG, "warp_perspective: null argument");
+    int r = need_canvas(c, "warp_perspective");
+    if (r) return r;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
+    if ((r = upload_H(c, H))) return r;
+    if ((r = rtvm_launch_warp_only(c, c->d_bgr, c->d_H, c->d_warped))) return r;
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_warped, (size_t)c->ch * c->cw * 3, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_distance_transform(rtvm_ctx* c, const uint8_t* mask, int h, int w, float* dist) {
+    if (!c) return RTVM_E_ARG;
+    if (!mask || !dist || h <= 0 || w <= 0) RTVM_FAIL(c, RTVM_E_ARG, "distance_transform: bad argument");
+    if ((size_t)h * w > (size_t)c->ch * c->cw)
+        RTVM_FAIL(c, RTVM_E_ARG, "distance_transform: %dx%d exceeds the context's canvas", h, w);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n_px = (size_t)c->ch * c->cw;
+    DtJob* jb = (DtJob*)((char*)c->h_pinned + 1024);
+    jb->mask = c->d_mask_new;
+    jb->pitch = w;
+    jb->x0 = jb->y0 = 0;
+    jb->x1 = w;
+    jb->y1 = h;
+    jb->sA = c->d_dt_s;
+    jb->sB = c->d_dt_s + n_px;
+    jb->R = c->d_dt_r;
+    jb->F = c->d_dt_f;
+    jb->dist = c->d_dist;
+    HIP_TRY(c, hipMemcpyAsync(c->d_jobs + 2, jb, sizeof(DtJob), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mask_new, mask, (size_t)h * w, hipMemcpyHostToDevice, c->stream));
+    int r = rtvm_launch_dt(c, c->d_jobs + 2, 1, w, h);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpyAsync(dist, c->d_dist, (size_t)h * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_warp_blend(rtvm_ctx* c, const uint8_t* bgr, const double H[9]) {
+    if (!c) return RTVM_E_ARG;
+    if (!bgr || !H) RTVM_FAIL(c, RTVM_E_ARG, "warp_blend: null argument");
+    int r = need_canvas(c, "warp_blend");
+    if (r) return r;
+    if (!c->canvas_ready) RTVM_FAIL(c, RTVM_E_STATE, "warp_blend: call rtvm_canvas_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
+    if ((r = upload_H(c, H))) return r;
+    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H))) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_canvas_read(rtvm_ctx* c, uint8_t* out) {
+    if (!c) return RTVM_E_ARG;
+    if (!out) RTVM_FAIL(c, RTVM_E_ARG, "canvas_read: null output");
+    int r = need_canvas(c, "canvas_read");
+    if (r) return r;
+    if (!c->canvas_ready) RTVM_FAIL(c, RTVM_E_STATE, "canvas_read: call rtvm_canvas_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_canvas, (size_t)c->ch * c->cw * 3, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTVM_OK;
+}
+
 // ---- not yet implemented (stubs keep the ABI complete while stages land) ----
 #define RTVM_STUB(ctx) RTVM_FAIL(ctx, RTVM_E_STATE, "%s: not implemented yet", __func__)
 extern "C" int rtvm_max_keypoints(const rtvm_ctx* c) { return c ? c->plan.max_kp : 0; }
@@ -153,11 +270,6 @@ extern "C" int rtvm_gray(rtvm_ctx* c, const uint8_t*, uint8_t*) { RTVM_STUB(c); 
 extern "C" int rtvm_orb(rtvm_ctx* c, const uint8_t*, int*, float*, float*, float*, float*, int32_t*, uint8_t*) { RTVM_STUB(c); }
 extern "C" int rtvm_match_l2_knn2(rtvm_ctx* c, const float*, int, const float*, int, int, int32_t*, float*) { RTVM_STUB(c); }
 extern "C" int rtvm_find_homography_ransac(rtvm_ctx* c, const float*, const float*, int, double, int, double, double*, uint8_t*, int*) { RTVM_STUB(c); }
-extern "C" int rtvm_canvas_init(rtvm_ctx* c, const uint8_t*, int, int) { RTVM_STUB(c); }
-extern "C" int rtvm_warp_perspective(rtvm_ctx* c, const uint8_t*, const double*, uint8_t*) { RTVM_STUB(c); }
-extern "C" int rtvm_distance_transform(rtvm_ctx* c, const uint8_t*, int, int, float*) { RTVM_STUB(c); }
-extern "C" int rtvm_warp_blend(rtvm_ctx* c, const uint8_t*, const double*) { RTVM_STUB(c); }
-extern "C" int rtvm_canvas_read(rtvm_ctx* c, uint8_t*) { RTVM_STUB(c); }
 extern "C" int rtvm_stream_begin(rtvm_ctx* c, const uint8_t*, int, int) { RTVM_STUB(c); }
 extern "C" int rtvm_process_frame(rtvm_ctx* c, const uint8_t*) { RTVM_STUB(c); }
 extern "C" int rtvm_frame_status(rtvm_ctx* c, int*, int*, int*, double*) { RTVM_STUB(c); }

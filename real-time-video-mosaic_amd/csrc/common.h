@@ -48,6 +48,29 @@ struct FeatSet {
     int* count;        // 1
 };
 
+// One distance-transform job: a rectangle of a mask plane and the planes the
+// scans write (all indexed y*pitch + x like the mask).
+struct DtJob {
+    const uint8_t* mask;
+    int pitch;
+    int x0, y0, x1, y1;
+    uint16_t* sA;      // steps to the nearest zero along x - y = const
+    uint16_t* sB;      // steps to the nearest zero along x + y = const
+    uint32_t* R;       // row scan result
+    uint32_t* F;       // downward column scan
+    float* dist;
+};
+
+// Per-frame warp parameters, written on the device by k_warp_prep.
+struct WarpParams {
+    double M[9];       // H^-1
+    float Mf[9];       // (float)M
+    int rx0, ry0, rx1, ry1;   // region outside which the warped frame is zero
+    int wx0, wy0, wx1, wy1;   // region where the blend weights are needed (ROI + 15, clipped)
+    int bw0;           // block width of the fixed-point coordinate evaluation
+    int pad;
+};
+
 // Device-side stream state (what VideMosaic keeps between frames).
 struct StreamState {
     double H_old[9];
@@ -116,13 +139,16 @@ struct rtvm_ctx {
     uint8_t* d_warped;     // ch*cw*3
     uint8_t* d_mask_new;   // ch*cw
     uint8_t* d_mask_old;   // ch*cw
-    uint16_t* d_dt_s;      // diagonal step planes: [2 masks][2 orientations][ch*cw]
+    uint16_t* d_dt_s;      // diagonal step planes: [2 jobs][2 orientations][ch*cw]
     uint32_t* d_dt_r;      // row-pass planes [2][ch*cw]
-    uint32_t* d_dt_c;      // column forward pass planes [2][ch*cw]
-    float* d_dist;         // [2][ch*cw]
+    uint32_t* d_dt_f;      // downward column pass planes [2][ch*cw]
+    float* d_dist;         // [2][ch*cw]: 0 = new, 1 = old
+    float* d_wgt;          // blend weights [2][ch*cw]
     float* d_rb;           // row-blurred weights [2][ch*cw]
-    double* d_H;           // 9 doubles (warp input) + 9 (inverse)
-    int* d_roi;            // x0,y0,x1,y1 of the clipped warped quad
+    float* d_gk;           // 31 Gaussian taps
+    double* d_H;           // 9 doubles: homography handed to the warp
+    WarpParams* d_wp;
+    DtJob* d_jobs;         // [0] = new mask on the ROI, [1] = old mask on the canvas, [2] = stage API
     int canvas_ready;
 
     StreamState* d_state;
@@ -147,5 +173,12 @@ struct rtvm_ctx {
 // match.hip
 int rtvm_launch_hamming(rtvm_ctx* c, const uint8_t* dq, const uint8_t* dt, const int* d_nq,
                         const int* d_nt, int cap_q, int cap_t, int sorted);
+// dt.hip
+int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h);
+// warp.hip
+int rtvm_warp_setup(rtvm_ctx* c);  // uploads constant tables (after allocation)
+int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_off);
+int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out);
+int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H);
 int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim,
                         int32_t* d_idx, float* d_dist);

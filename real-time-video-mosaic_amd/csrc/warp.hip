@@ -1,0 +1,372 @@
+// VideMosaic.warp() for gfx950 (reference main.py:861-936): perspective warp of
+// the frame into canvas coordinates, masks, chamfer distance transforms (dt.hip),
+// blend weights, separable 31x31 Gaussian, blend and commit into the canvas.
+//
+// Data layout in HBM: the canvas is u8 HxWx3 (the reference's float64 canvas
+// only ever holds the integers 0..255); every auxiliary plane (warped frame,
+// masks, distances, weights) has the canvas' width as pitch and is only touched
+// inside the region of interest of the frame being stitched.  mask_old
+// (canvas pixel has a non-zero channel) is kept up to date by the commit
+// kernel instead of being recomputed from the canvas every frame.
+#include "common.h"
+
+#include <cmath>
+
+namespace {
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+// One thread: M = H^-1 (cv::invert's 3x3 closed form), the region of the canvas
+// the frame can touch, and the two distance-transform jobs of the frame.
+__global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restrict__ wp,
+                            DtJob* __restrict__ jobs, int fh, int fw, int ch, int cw, int force_full) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double S[9];
+    for (int i = 0; i < 9; i++) S[i] = Hp[i];
+    double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) +
+               S[2] * (S[3] * S[7] - S[4] * S[6]);
+    double t[9];
+    bool full = force_full != 0;
+    if (d == 0.) {
+        for (int i = 0; i < 9; i++) t[i] = 0.;
+        full = true;
+    } else {
+        d = 1. / d;
+        t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+        t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+        t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+        t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+        t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+        t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+        t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+        t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+        t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+    }
+    for (int i = 0; i < 9; i++) {
+        wp->M[i] = t[i];
+        wp->Mf[i] = (float)t[i];
+    }
+    // Canvas pixels whose source coordinate can fall inside (-1, fw) x (-1, fh):
+    // the image under H of that rectangle grown by half a pixel, plus two pixels.
+    int x0 = 0, y0 = 0, x1 = cw, y1 = ch;
+    if (!full) {
+        const double cx[4] = {-1.5, fw + 0.5, fw + 0.5, -1.5};
+        const double cy[4] = {-1.5, -1.5, fh + 0.5, fh + 0.5};
+        double mnx = 1e300, mny = 1e300, mxx = -1e300, mxy = -1e300;
+        bool ok = true;
+        for (int k = 0; k < 4; k++) {
+            const double w = S[6] * cx[k] + S[7] * cy[k] + S[8];
+            const double X = (S[0] * cx[k] + S[1] * cy[k] + S[2]) / w;
+            const double Y = (S[3] * cx[k] + S[4] * cy[k] + S[5]) / w;
+            if (!(w > 1e-9) || !(fabs(X) < 1e9) || !(fabs(Y) < 1e9)) ok = false;
+            mnx = fmin(mnx, X);
+            mxx = fmax(mxx, X);
+            mny = fmin(mny, Y);
+            mxy = fmax(mxy, Y);
+        }
+        if (ok) {
+            x0 = max(0, (int)floor(mnx) - 2);
+            y0 = max(0, (int)floor(mny) - 2);
+            x1 = min(cw, (int)ceil(mxx) + 3);
+            y1 = min(ch, (int)ceil(mxy) + 3);
+            if (x1 <= x0 || y1 <= y0) x0 = y0 = x1 = y1 = 0;
+        }
+    }
+    wp->rx0 = x0;
+    wp->ry0 = y0;
+    wp->rx1 = x1;
+    wp->ry1 = y1;
+    const bool empty = x1 <= x0;
+    wp->wx0 = empty ? 0 : max(0, x0 - 15);
+    wp->wy0 = empty ? 0 : max(0, y0 - 15);
+    wp->wx1 = empty ? 0 : min(cw, x1 + 15);
+    wp->wy1 = empty ? 0 : min(ch, y1 + 15);
+    const int bh0 = ch < 16 ? ch : 16;
+    wp->bw0 = (1024 / bh0) < cw ? (1024 / bh0) : cw;
+    if (jobs) {
+        jobs[0].x0 = x0;
+        jobs[0].y0 = y0;
+        jobs[0].x1 = x1;
+        jobs[0].y1 = y1;
+        // the old-canvas distances are needed only when the frame touches the canvas
+        jobs[1].x0 = 0;
+        jobs[1].y0 = 0;
+        jobs[1].x1 = empty ? 0 : cw;
+        jobs[1].y1 = empty ? 0 : ch;
+    }
+}
+
+__device__ __forceinline__ int tap(const uint8_t* __restrict__ src, int fh, int fw, int y, int x, int c) {
+    return ((unsigned)x < (unsigned)fw && (unsigned)y < (unsigned)fh) ? src[((size_t)y * fw + x) * 3 + c] : 0;
+}
+
+// cv2.warpPerspective(frame, H, (cw, ch), INTER_LINEAR), BORDER_CONSTANT 0, for the
+// pixels of the region of interest.  FIXED: 1/32-pixel fixed point (OpenCV <= 4.10),
+// else float32 (OpenCV >= 4.11).  Also writes mask_new = any channel > 0.
+template <bool FIXED>
+__global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, const WarpParams* __restrict__ wp,
+                                              uint8_t* __restrict__ out, uint8_t* __restrict__ mask_new, int fh,
+                                              int fw, int ch, int cw) {
+    const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
+    if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 4 <= ry0) return;
+    const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
+    if (x < rx0 || x >= rx1 || y < ry0 || y >= ry1) return;
+    int v[3] = {0, 0, 0};
+    if (FIXED) {
+        const double* M = wp->M;
+        const int bw0 = wp->bw0;
+        const int xb = (x / bw0) * bw0, x1 = x - xb;
+        const double X0 = M[0] * xb + M[1] * y + M[2];
+        const double Y0 = M[3] * xb + M[4] * y + M[5];
+        const double W0 = M[6] * xb + M[7] * y + M[8];
+        double W = W0 + M[6] * x1;
+        W = W ? 32. / W : 0;
+        const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + M[0] * x1) * W));
+        const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + M[3] * x1) * W));
+        const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
+        int sx = X >> 5, sy = Y >> 5;
+        sx = sx < -32768 ? -32768 : sx > 32767 ? 32767 : sx;
+        sy = sy < -32768 ? -32768 : sy > 32767 ? 32767 : sy;
+        const int ax = X & 31, ay = Y & 31;
+        const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32;
+        const int w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+        if (sx >= -1 && sx < fw && sy >= -1 && sy < fh) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int s = w00 * tap(src, fh, fw, sy, sx, c) + w01 * tap(src, fh, fw, sy, sx + 1, c) +
+                              w10 * tap(src, fh, fw, sy + 1, sx, c) + w11 * tap(src, fh, fw, sy + 1, sx + 1, c);
+                v[c] = (s + 16384) >> 15;
+            }
+        }
+    } else {
+        const float* Mf = wp->Mf;
+        const float fx = (float)x, fy = (float)y;
+        const float w = (Mf[6] * fx + Mf[7] * fy) + Mf[8];
+        const float sx = ((Mf[0] * fx + Mf[1] * fy) + Mf[2]) / w;
+        const float sy = ((Mf[3] * fx + Mf[4] * fy) + Mf[5]) / w;
+        if (sx > -1.f && sx < (float)fw && sy > -1.f && sy < (float)fh) {
+            const float flx = floorf(sx), fly = floorf(sy);
+            const int ix = (int)flx, iy = (int)fly;
+            const float a = sx - flx, b = sy - fly;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float p00 = (float)tap(src, fh, fw, iy, ix, c), p01 = (float)tap(src, fh, fw, iy, ix + 1, c);
+                const float p10 = (float)tap(src, fh, fw, iy + 1, ix, c), p11 = (float)tap(src, fh, fw, iy + 1, ix + 1, c);
+                const float v0 = p00 + (p01 - p00) * a;
+                const float v1 = p10 + (p11 - p10) * a;
+                const float r = v0 + (v1 - v0) * b;
+                const int q = __float2int_rn(r);
+                v[c] = q < 0 ? 0 : q > 255 ? 255 : q;
+            }
+        }
+    }
+    const size_t p = (size_t)y * cw + x;
+    out[3 * p] = (uint8_t)v[0];
+    out[3 * p + 1] = (uint8_t)v[1];
+    out[3 * p + 2] = (uint8_t)v[2];
+    if (mask_new) mask_new[p] = (v[0] | v[1] | v[2]) ? 255 : 0;
+}
+
+// weight_new = dn / (dn + do + 1e-6), weight_old = do / (...)  (main.py:892-894)
+// on the ROI grown by the blur radius.  dn is zero outside the ROI.
+__global__ __launch_bounds__(256) void k_weights(const WarpParams* __restrict__ wp, const float* __restrict__ dn,
+                                                 const float* __restrict__ dold, float* __restrict__ wn,
+                                                 float* __restrict__ wo, int cw) {
+    const int wx0 = wp->wx0, wy0 = wp->wy0, wx1 = wp->wx1, wy1 = wp->wy1;
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
+    if (bx >= wx1 || bx + 64 <= wx0 || by >= wy1 || by + 4 <= wy0) return;
+    const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
+    if (x < wx0 || x >= wx1 || y < wy0 || y >= wy1) return;
+    const size_t p = (size_t)y * cw + x;
+    const bool in_roi = x >= wp->rx0 && x < wp->rx1 && y >= wp->ry0 && y < wp->ry1;
+    const float a = in_roi ? dn[p] : 0.f;
+    const float b = dold[p];
+    const float sum = (a + b) + 1e-6f;
+    wn[p] = a / sum;
+    wo[p] = b / sum;
+}
+
+// Row pass of cv2.GaussianBlur(w, (31,31), 0) (main.py:897-898) for both weight
+// planes: 31 taps added left to right in float32, BORDER_REFLECT_101 at the canvas
+// edge.  One workgroup = 256 consecutive pixels of one row, staged through LDS.
+__global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
+                                                   const float* __restrict__ wn, const float* __restrict__ wo,
+                                                   float* __restrict__ rbn, float* __restrict__ rbo, int cw) {
+    const int rx0 = wp->rx0, rx1 = wp->rx1, wy0 = wp->wy0, wy1 = wp->wy1;
+    const int bx = blockIdx.x * 256, y = blockIdx.y;
+    if (y < wy0 || y >= wy1 || bx >= rx1 || bx + 256 <= rx0) return;
+    __shared__ float s_n[256 + 30], s_o[256 + 30];
+    __shared__ float s_k[31];
+    const size_t row = (size_t)y * cw;
+    for (int i = threadIdx.x; i < 256 + 30; i += 256) {
+        const int xs = reflect101(bx - 15 + i, cw);
+        // weights exist on [wx0, wx1); columns this row pass never needs may lie outside
+        const bool ok = xs >= wp->wx0 && xs < wp->wx1;
+        s_n[i] = ok ? wn[row + xs] : 0.f;
+        s_o[i] = ok ? wo[row + xs] : 0.f;
+    }
+    if (threadIdx.x < 31) s_k[threadIdx.x] = gk[threadIdx.x];
+    __syncthreads();
+    const int x = bx + threadIdx.x;
+    if (x < rx0 || x >= rx1) return;
+    float a = s_k[0] * s_n[threadIdx.x], b = s_k[0] * s_o[threadIdx.x];
+#pragma unroll
+    for (int i = 1; i < 31; i++) {
+        a += s_k[i] * s_n[threadIdx.x + i];
+        b += s_k[i] * s_o[threadIdx.x + i];
+    }
+    rbn[row + x] = a;
+    rbo[row + x] = b;
+}
+
+// Column pass of the blur (centre tap, then symmetric pairs outwards), blend
+// and commit (main.py:905-927), per pixel of the ROI:
+//   new & old : canvas = trunc_u8(canvas * w_old + warped * w_new)
+//   new only  : canvas = warped
+__global__ __launch_bounds__(256) void k_blur_cols_commit(const WarpParams* __restrict__ wp,
+                                                          const float* __restrict__ gk,
+                                                          const float* __restrict__ rbn,
+                                                          const float* __restrict__ rbo,
+                                                          const uint8_t* __restrict__ warped,
+                                                          const uint8_t* __restrict__ mask_new,
+                                                          uint8_t* __restrict__ mask_old,
+                                                          uint8_t* __restrict__ canvas, int ch, int cw) {
+    const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
+    if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 4 <= ry0) return;
+    const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
+    if (x < rx0 || x >= rx1 || y < ry0 || y >= ry1) return;
+    const size_t p = (size_t)y * cw + x;
+    if (!mask_new[p]) return;
+    if (!mask_old[p]) {
+        canvas[3 * p] = warped[3 * p];
+        canvas[3 * p + 1] = warped[3 * p + 1];
+        canvas[3 * p + 2] = warped[3 * p + 2];
+        mask_old[p] = 255;
+        return;
+    }
+    float a = gk[15] * rbn[p], b = gk[15] * rbo[p];
+#pragma unroll
+    for (int i = 1; i <= 15; i++) {
+        const size_t pu = (size_t)reflect101(y + i, ch) * cw + x;
+        const size_t pd = (size_t)reflect101(y - i, ch) * cw + x;
+        a += gk[15 + i] * (rbn[pu] + rbn[pd]);
+        b += gk[15 + i] * (rbo[pu] + rbo[pd]);
+    }
+    int any = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float v = (float)canvas[3 * p + c] * b + (float)warped[3 * p + c] * a;
+        const int q = (int)v;  // astype(uint8) truncates
+        canvas[3 * p + c] = (uint8_t)q;
+        any |= q & 255;
+    }
+    mask_old[p] = any ? 255 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_canvas_paste(const uint8_t* __restrict__ src, uint8_t* __restrict__ canvas,
+                                                      uint8_t* __restrict__ mask_old, int fh, int fw, int ch, int cw,
+                                                      int row_off, int col_off) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= fw || y >= fh) return;
+    const int cy = y + row_off, cx = x + col_off;
+    if (cy < 0 || cy >= ch || cx < 0 || cx >= cw) return;
+    const size_t s = ((size_t)y * fw + x) * 3, p = (size_t)cy * cw + cx;
+    const uint8_t b = src[s], g = src[s + 1], r = src[s + 2];
+    canvas[3 * p] = b;
+    canvas[3 * p + 1] = g;
+    canvas[3 * p + 2] = r;
+    mask_old[p] = (b | g | r) ? 255 : 0;
+}
+
+}  // namespace
+
+// cv::getGaussianKernel(31, 0, CV_32F): sigma = 0.3*((31-1)*0.5 - 1) + 0.8
+int rtvm_warp_setup(rtvm_ctx* c) {
+    const int n = 31;
+    const double sigma = ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2 = -0.5 / (sigma * sigma);
+    double t[31], sum = 0;
+    for (int i = 0; i < n; i++) {
+        const double x = i - (n - 1) * 0.5;
+        t[i] = std::exp(scale2 * x * x);
+        sum += t[i];
+    }
+    sum = 1. / sum;
+    float k[31];
+    for (int i = 0; i < n; i++) k[i] = (float)(t[i] * sum);
+    HIP_TRY(c, hipMemcpy(c->d_gk, k, sizeof(k), hipMemcpyHostToDevice));
+    const size_t n_px = (size_t)c->ch * c->cw;
+    DtJob jobs[3];
+    for (int j = 0; j < 2; j++) {
+        jobs[j].mask = j == 0 ? c->d_mask_new : c->d_mask_old;
+        jobs[j].pitch = c->cw;
+        jobs[j].x0 = jobs[j].y0 = jobs[j].x1 = jobs[j].y1 = 0;
+        jobs[j].sA = c->d_dt_s + (size_t)(2 * j) * n_px;
+        jobs[j].sB = c->d_dt_s + (size_t)(2 * j + 1) * n_px;
+        jobs[j].R = c->d_dt_r + (size_t)j * n_px;
+        jobs[j].F = c->d_dt_f + (size_t)j * n_px;
+        jobs[j].dist = c->d_dist + (size_t)j * n_px;
+    }
+    jobs[2] = jobs[0];
+    HIP_TRY(c, hipMemcpy(c->d_jobs, jobs, sizeof(jobs), hipMemcpyHostToDevice));
+    return RTVM_OK;
+}
+
+int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_off) {
+    const size_t n_px = (size_t)c->ch * c->cw;
+    HIP_TRY(c, hipMemsetAsync(c->d_canvas, 0, n_px * 3, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_mask_old, 0, n_px, c->stream));
+    hipLaunchKernelGGL(k_canvas_paste, dim3((c->fw + 63) / 64, (c->fh + 3) / 4), dim3(256), 0, c->stream, d_bgr,
+                       c->d_canvas, c->d_mask_old, c->fh, c->fw, c->ch, c->cw, row_off, col_off);
+    HIP_TRY(c, hipGetLastError());
+    c->canvas_ready = 1;
+    return RTVM_OK;
+}
+
+// Full-canvas warp into d_out (stage parity of cv2.warpPerspective alone).
+int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out) {
+    hipLaunchKernelGGL(k_warp_prep, dim3(1), dim3(64), 0, c->stream, d_H, c->d_wp, (DtJob*)nullptr, c->fh, c->fw,
+                       c->ch, c->cw, 1);
+    const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
+    if (c->flags & RTVM_FLAG_WARP_FIXED)
+        hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, c->stream, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
+                           c->fh, c->fw, c->ch, c->cw);
+    else
+        hipLaunchKernelGGL(k_warp<false>, grid, dim3(256), 0, c->stream, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
+                           c->fh, c->fw, c->ch, c->cw);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}
+
+// The whole of VideMosaic.warp() for one frame, H read from device memory.
+int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H) {
+    const size_t n_px = (size_t)c->ch * c->cw;
+    hipLaunchKernelGGL(k_warp_prep, dim3(1), dim3(64), 0, c->stream, d_H, c->d_wp, c->d_jobs, c->fh, c->fw, c->ch,
+                       c->cw, 0);
+    const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
+    if (c->flags & RTVM_FLAG_WARP_FIXED)
+        hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, c->stream, d_bgr, c->d_wp, c->d_warped, c->d_mask_new,
+                           c->fh, c->fw, c->ch, c->cw);
+    else
+        hipLaunchKernelGGL(k_warp<false>, grid, dim3(256), 0, c->stream, d_bgr, c->d_wp, c->d_warped, c->d_mask_new,
+                           c->fh, c->fw, c->ch, c->cw);
+    int r = rtvm_launch_dt(c, c->d_jobs, 2, c->cw, c->ch);
+    if (r != RTVM_OK) return r;
+    float* wn = c->d_wgt;
+    float* wo = c->d_wgt + n_px;
+    float* rbn = c->d_rb;
+    float* rbo = c->d_rb + n_px;
+    hipLaunchKernelGGL(k_weights, grid, dim3(256), 0, c->stream, c->d_wp, c->d_dist, c->d_dist + n_px, wn, wo, c->cw);
+    hipLaunchKernelGGL(k_blur_rows, dim3((c->cw + 255) / 256, c->ch), dim3(256), 0, c->stream, c->d_wp, c->d_gk, wn,
+                       wo, rbn, rbo, c->cw);
+    hipLaunchKernelGGL(k_blur_cols_commit, grid, dim3(256), 0, c->stream, c->d_wp, c->d_gk, rbn, rbo, c->d_warped,
+                       c->d_mask_new, c->d_mask_old, c->d_canvas, c->ch, c->cw);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}

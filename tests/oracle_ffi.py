@@ -46,3 +46,37 @@ def match_l2_knn2(q, t):
     rc = lib().rtvm_oracle_match_l2_knn2(_p(q), nq, _p(t), len(t), dim, _p(idx), _p(dist))
     assert rc == 0
     return idx, dist
+
+
+def warp_perspective(bgr, H, ch, cw, fixed):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    out = np.empty((ch, cw, 3), np.uint8)
+    rc = lib().rtvm_oracle_warp_perspective(_p(bgr), bgr.shape[0], bgr.shape[1], _p(H), ch, cw, int(fixed), _p(out))
+    assert rc == 0
+    return out
+
+
+def distance_transform(mask):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    out = np.empty(mask.shape, np.float32)
+    lib().rtvm_oracle_distance_transform(_p(mask), mask.shape[0], mask.shape[1], _p(out))
+    return out
+
+
+def gaussian_blur31(src):
+    src = np.ascontiguousarray(src, np.float32)
+    out = np.empty(src.shape, np.float32)
+    lib().rtvm_oracle_gaussian_blur31(_p(src), src.shape[0], src.shape[1], _p(out))
+    return out
+
+
+def warp_blend(canvas, bgr, H, fixed):
+    """Returns the new canvas (u8); the input is not modified."""
+    canvas = np.ascontiguousarray(canvas, np.uint8).copy()
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    rc = lib().rtvm_oracle_warp_blend(_p(canvas), canvas.shape[0], canvas.shape[1], _p(bgr), bgr.shape[0],
+                                      bgr.shape[1], _p(H), int(fixed))
+    assert rc == 0
+    return canvas
