@@ -57,6 +57,29 @@ int alloc_all(rtvm_ctx* c) {
     ALLOC(c, d_jobs, 3);
     int r = rtvm_warp_setup(c);
     if (r != RTVM_OK) return r;
+    // RANSAC
+    ALLOC(c, d_rs_src, (size_t)mk * 2);
+    ALLOC(c, d_rs_dst, (size_t)mk * 2);
+    ALLOC(c, d_rs_count, 4);
+    HIP_TRY(c, hipMalloc(&c->d_rs_state, rtvm_ransac_state_bytes()));
+    c->rs_raw_n = 32768;
+    ALLOC(c, d_rs_raw, c->rs_raw_n);
+    ALLOC(c, d_rs_idx, RTVM_RANSAC_MAX_ITERS * 4);
+    ALLOC(c, d_rs_good, RTVM_RANSAC_MAX_ITERS);
+    ALLOC(c, d_rs_hypH, RTVM_RANSAC_MAX_ITERS * 9);
+    ALLOC(c, d_rs_csrc, (size_t)mk * 2);
+    ALLOC(c, d_rs_cdst, (size_t)mk * 2);
+    ALLOC(c, d_rs_H, 16);
+    ALLOC(c, d_rs_mask, mk);
+    ALLOC(c, d_rs_found, 4);
+    {
+        uint32_t* raw = new (std::nothrow) uint32_t[c->rs_raw_n];
+        if (!raw) RTVM_FAIL(c, RTVM_E_NOMEM, "host allocation failed");
+        rtvm_ransac_raw_table(raw, c->rs_raw_n);
+        hipError_t e = hipMemcpy(c->d_rs_raw, raw, c->rs_raw_n * sizeof(uint32_t), hipMemcpyHostToDevice);
+        delete[] raw;
+        HIP_TRY(c, e);
+    }
     return RTVM_OK;
 }
 
@@ -64,7 +87,8 @@ void free_all(rtvm_ctx* c) {
     void* ptrs[] = {c->d_mq, c->d_mt, c->d_mcount, c->d_qkey, c->d_tkey, c->d_m_qidx, c->d_m_tidx,
                     c->d_m_dist, c->d_m_count, c->d_bgr, c->d_canvas, c->d_warped, c->d_mask_new, c->d_mask_old,
                     c->d_dt_s, c->d_dt_r, c->d_dt_f, c->d_dist, c->d_wgt, c->d_rb, c->d_gk, c->d_H, c->d_wp,
-                    c->d_jobs};
+                    c->d_jobs, c->d_rs_src, c->d_rs_dst, c->d_rs_count, c->d_rs_state, c->d_rs_raw, c->d_rs_idx,
+                    c->d_rs_good, c->d_rs_hypH, c->d_rs_csrc, c->d_rs_cdst, c->d_rs_H, c->d_rs_mask, c->d_rs_found};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -169,6 +193,36 @@ extern "C" int rtvm_match_hamming_xcheck_sorted(rtvm_ctx* c, const uint8_t* q, i
     return match_hamming_host(c, q, nq, t, nt, qidx, tidx, dist, m_out, 1);
 }
 
+// ---- RANSAC homography ------------------------------------------------------
+extern "C" int rtvm_find_homography_ransac(rtvm_ctx* c, const float* src_xy, const float* dst_xy, int m,
+                                           double thresh, int max_iters, double confidence, double H[9],
+                                           uint8_t* inlier_mask, int* found) {
+    if (!c) return RTVM_E_ARG;
+    if (!found || !H || m < 0 || (m > 0 && (!src_xy || !dst_xy)))
+        RTVM_FAIL(c, RTVM_E_ARG, "find_homography: bad argument");
+    if (m > RTVM_MAX_MATCH) RTVM_FAIL(c, RTVM_E_ARG, "find_homography: at most %d point pairs", RTVM_MAX_MATCH);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int* hc = (int*)c->h_pinned;
+    hc[0] = m;
+    HIP_TRY(c, hipMemcpyAsync(c->d_rs_count, hc, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (m) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_rs_src, src_xy, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_rs_dst, dst_xy, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    int r = rtvm_launch_ransac(c, c->d_rs_src, c->d_rs_dst, c->d_rs_count, thresh, max_iters, confidence,
+                               c->d_rs_H, c->d_rs_mask, c->d_rs_found);
+    if (r) return r;
+    double* hH = (double*)c->h_pinned + 8;
+    HIP_TRY(c, hipMemcpyAsync(hH, c->d_rs_H, 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hc + 1, c->d_rs_found, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (inlier_mask && m) HIP_TRY(c, hipMemcpyAsync(inlier_mask, c->d_rs_mask, (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *found = hc[1];
+    memcpy(H, hH, 9 * sizeof(double));
+    if (!*found && inlier_mask && m) memset(inlier_mask, 0, (size_t)m);
+    return RTVM_OK;
+}
+
 // ---- canvas / warp / blend ------------------------------------------------
 static int need_canvas(rtvm_ctx* c, const char* who) {
     if (c->ch <= 0 || c->cw <= 0 || c->fh <= 0 || c->fw <= 0)
@@ -269,7 +323,6 @@ extern "C" int rtvm_max_keypoints(const rtvm_ctx* c) { return c ? c->plan.max_kp
 extern "C" int rtvm_gray(rtvm_ctx* c, const uint8_t*, uint8_t*) { RTVM_STUB(c); }
 extern "C" int rtvm_orb(rtvm_ctx* c, const uint8_t*, int*, float*, float*, float*, float*, int32_t*, uint8_t*) { RTVM_STUB(c); }
 extern "C" int rtvm_match_l2_knn2(rtvm_ctx* c, const float*, int, const float*, int, int, int32_t*, float*) { RTVM_STUB(c); }
-extern "C" int rtvm_find_homography_ransac(rtvm_ctx* c, const float*, const float*, int, double, int, double, double*, uint8_t*, int*) { RTVM_STUB(c); }
 extern "C" int rtvm_stream_begin(rtvm_ctx* c, const uint8_t*, int, int) { RTVM_STUB(c); }
 extern "C" int rtvm_process_frame(rtvm_ctx* c, const uint8_t*) { RTVM_STUB(c); }
 extern "C" int rtvm_frame_status(rtvm_ctx* c, int*, int*, int*, double*) { RTVM_STUB(c); }

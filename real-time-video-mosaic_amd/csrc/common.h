@@ -127,12 +127,20 @@ struct rtvm_ctx {
     size_t l_cap_q, l_cap_t;
 
     // --- RANSAC ---
-    float* d_rs_src;       // m*2
-    float* d_rs_dst;
+    float* d_rs_src;       // m*2 matched points (cur)
+    float* d_rs_dst;       // m*2 matched points (prev)
     int* d_rs_count;
-    void* d_rs_work;       // workspace, see ransac.hip
-    double* d_rs_H;        // 9 doubles + found flag area
+    void* d_rs_state;      // RsState (ransac.hip)
+    uint32_t* d_rs_raw;    // raw outputs of the fixed-seed RNG
+    int rs_raw_n;
+    int* d_rs_idx;         // 4 indices per iteration
+    int* d_rs_good;        // inlier count per iteration
+    double* d_rs_hypH;     // 9 doubles per iteration
+    float* d_rs_csrc;      // compacted inliers
+    float* d_rs_cdst;
+    double* d_rs_H;        // 9 doubles
     uint8_t* d_rs_mask;
+    int* d_rs_found;
 
     // --- canvas / warp / blend ---
     uint8_t* d_canvas;     // ch*cw*3
@@ -180,5 +188,10 @@ int rtvm_warp_setup(rtvm_ctx* c);  // uploads constant tables (after allocation)
 int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_off);
 int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out);
 int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H);
+// ransac.hip
+size_t rtvm_ransac_state_bytes();
+void rtvm_ransac_raw_table(uint32_t* raw, int n);
+int rtvm_launch_ransac(rtvm_ctx* c, const float* d_src, const float* d_dst, const int* d_count, double thresh,
+                       int max_iters, double confidence, double* d_H, uint8_t* d_mask, int* d_found);
 int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim,
                         int32_t* d_idx, float* d_dist);

@@ -1,0 +1,773 @@
+// cv2.findHomography(src, dst, cv2.RANSAC, thresh) for gfx950 (reference
+// main.py:856-857).
+//
+// OpenCV's loop is sequential (draw a 4-point subset, solve, score, maybe shrink
+// the iteration budget), but three facts make it data-parallel without changing
+// its result:
+//   * the subset sequence depends only on the points and on the fixed-seed RNG
+//     stream, never on the scores, so the subsets of many iterations can be
+//     generated up front (k_rs_subsets; the raw RNG outputs are a constant table);
+//   * solving and scoring a hypothesis is independent of every other hypothesis
+//     (k_rs_hyp: one wave per hypothesis, 9x9 Jacobi eigen-solve in LDS, inlier
+//     count by ballot + popcount);
+//   * the keep/stop rule only needs the inlier counts in iteration order
+//     (k_rs_replay, one lane).
+// Iterations 0..63 are evaluated first; with a usable inlier ratio the budget has
+// dropped below 64 by then and the second batch (64..max_iters-1) exits at once.
+// k_rs_refine then recomputes the winner's inlier mask, re-solves on all inliers
+// and runs the 10-iteration Levenberg-Marquardt polish, one wave per problem.
+//
+// Sums over all inlier points use the order "lane l adds points l, l+64, ... in
+// turn, then a butterfly over lane masks 32,16,8,4,2,1", which the CPU
+// restatement mirrors; everything else follows OpenCV's operation order in
+// IEEE double/float without contraction.
+#include "common.h"
+
+#include <cfloat>
+#include <cmath>
+
+namespace {
+
+constexpr int RS_BATCH0 = 64;  // iterations evaluated in the first batch
+
+struct RsState {
+    int niters, max_good, best, done, found, fail_at, next_pos, next_iter;
+};
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ double cv_hypot(double a, double b) {
+    a = fabs(a);
+    b = fabs(b);
+    if (a > b) {
+        b /= a;
+        return a * sqrt(1 + b * b);
+    }
+    if (b > 0) {
+        a /= b;
+        return b * sqrt(1 + a * a);
+    }
+    return 0;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+}
+
+// cv::JacobiImpl_<double> executed by one full wave on LDS-resident matrices
+// (A: n x n, only the upper triangle is used and it is destroyed; V: rows are the
+// eigenvectors; W: eigenvalues, descending).  The pivot choice, the rotation
+// formulas and the bookkeeping of the per-row / per-column maxima follow the
+// sequential algorithm exactly; lanes only share out independent element updates.
+__device__ void jacobi_wave(double* A, double* W, double* V, int* indR, int* indC, int* perm, int n) {
+    const int lane = threadIdx.x & 63;
+    const double eps = DBL_EPSILON;
+    for (int e = lane; e < n * n; e += 64) V[e] = (e / n == e % n) ? 1. : 0.;
+    if (lane < n) {
+        const int k = lane;
+        W[k] = A[(n + 1) * k];
+        if (k < n - 1) {
+            int m = k + 1;
+            double mv = fabs(A[n * k + m]);
+            for (int i = k + 2; i < n; i++) {
+                const double val = fabs(A[n * k + i]);
+                if (mv < val) mv = val, m = i;
+            }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            int m = 0;
+            double mv = fabs(A[k]);
+            for (int i = 1; i < k; i++) {
+                const double val = fabs(A[n * i + k]);
+                if (mv < val) mv = val, m = i;
+            }
+            indC[k] = m;
+        }
+    }
+    __syncthreads();
+    const int maxIters = n * n * 30;
+    if (n > 1)
+        for (int iters = 0; iters < maxIters; iters++) {
+            // pivot: first maximum over rows 0..n-2 (through indR), then columns 1..n-1 (through indC)
+            double val = -1.;
+            int ck = 0, cl = 0;
+            if (lane < n - 1) {
+                ck = lane;
+                cl = indR[lane];
+                val = fabs(A[n * ck + cl]);
+            } else if (lane < 2 * n - 2) {
+                cl = lane - (n - 1) + 1;
+                ck = indC[cl];
+                val = fabs(A[n * ck + cl]);
+            }
+            const double mx = wave_max(val);
+            const unsigned long long hit = __ballot(val == mx);
+            const int win = __ffsll((long long)hit) - 1;
+            const int k = __shfl(ck, win), l = __shfl(cl, win);
+            const double p = A[n * k + l];
+            if (fabs(p) <= eps) break;
+            const double y = (W[l] - W[k]) * 0.5;
+            double t = fabs(y) + cv_hypot(p, y);
+            double s = cv_hypot(p, t);
+            const double c = t / s;
+            s = p / s;
+            t = (p / t) * p;
+            if (y < 0) s = -s, t = -t;
+            __syncthreads();
+            if (lane == 0) {
+                A[n * k + l] = 0;
+                W[k] -= t;
+                W[l] += t;
+            }
+            if (lane < n) {
+                const int i = lane;
+                if (i != k && i != l) {
+                    double *p0, *p1;
+                    if (i < k) {
+                        p0 = &A[n * i + k];
+                        p1 = &A[n * i + l];
+                    } else if (i < l) {
+                        p0 = &A[n * k + i];
+                        p1 = &A[n * i + l];
+                    } else {
+                        p0 = &A[n * k + i];
+                        p1 = &A[n * l + i];
+                    }
+                    const double a0 = *p0, b0 = *p1;
+                    *p0 = a0 * c - b0 * s;
+                    *p1 = a0 * s + b0 * c;
+                }
+            } else if (lane >= 16 && lane < 16 + n) {
+                const int i = lane - 16;
+                const double a0 = V[n * k + i], b0 = V[n * l + i];
+                V[n * k + i] = a0 * c - b0 * s;
+                V[n * l + i] = a0 * s + b0 * c;
+            }
+            __syncthreads();
+            if (lane < 4) {
+                const int idx = (lane & 2) ? l : k;
+                if ((lane & 1) == 0) {
+                    if (idx < n - 1) {
+                        int m = idx + 1;
+                        double mv = fabs(A[n * idx + m]);
+                        for (int i = idx + 2; i < n; i++) {
+                            const double v2 = fabs(A[n * idx + i]);
+                            if (mv < v2) mv = v2, m = i;
+                        }
+                        indR[idx] = m;
+                    }
+                } else {
+                    if (idx > 0) {
+                        int m = 0;
+                        double mv = fabs(A[idx]);
+                        for (int i = 1; i < idx; i++) {
+                            const double v2 = fabs(A[n * i + idx]);
+                            if (mv < v2) mv = v2, m = i;
+                        }
+                        indC[idx] = m;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    __syncthreads();
+    // selection sort (descending) with row swaps: lane 0 finds the permutation,
+    // every lane then moves its share of V through registers
+    if (lane == 0) {
+        double w[9];
+        int pr[9];
+        for (int i = 0; i < n; i++) w[i] = W[i], pr[i] = i;
+        for (int k = 0; k < n - 1; k++) {
+            int m = k;
+            for (int i = k + 1; i < n; i++)
+                if (w[m] < w[i]) m = i;
+            if (k != m) {
+                const double tw = w[m];
+                w[m] = w[k];
+                w[k] = tw;
+                const int tp = pr[m];
+                pr[m] = pr[k];
+                pr[k] = tp;
+            }
+        }
+        for (int i = 0; i < n; i++) W[i] = w[i], perm[i] = pr[i];
+    }
+    __syncthreads();
+    double v0 = 0, v1 = 0;
+    const int e0 = lane, e1 = lane + 64;
+    if (e0 < n * n) v0 = V[n * perm[e0 / n] + e0 % n];
+    if (e1 < n * n) v1 = V[n * perm[e1 / n] + e1 % n];
+    __syncthreads();
+    if (e0 < n * n) V[e0] = v0;
+    if (e1 < n * n) V[e1] = v1;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void mat3mul(const double* a, const double* b, double* d) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) d[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+
+struct JacobiLds {
+    double A[81], V[81], W[9];
+    int indR[16], indC[16], perm[16];
+};
+
+// HomographyEstimatorCallback::runKernel for `count` point pairs (M -> m), one wave.
+// Point i belongs to lane i % 64.  Returns 0 for a degenerate configuration,
+// else 1 with H (9 doubles, identical in every lane).
+__device__ int run_kernel_wave(const float* __restrict__ M, const float* __restrict__ m, int count, JacobiLds* L,
+                               double* H) {
+    const int lane = threadIdx.x & 63;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int i = lane; i < count; i += 64) {
+        a0 += m[2 * i];
+        a1 += m[2 * i + 1];
+        a2 += M[2 * i];
+        a3 += M[2 * i + 1];
+    }
+    const double cmx = wave_sum(a0) / count, cmy = wave_sum(a1) / count;
+    const double cMx = wave_sum(a2) / count, cMy = wave_sum(a3) / count;
+    a0 = a1 = a2 = a3 = 0;
+    for (int i = lane; i < count; i += 64) {
+        a0 += fabs(m[2 * i] - cmx);
+        a1 += fabs(m[2 * i + 1] - cmy);
+        a2 += fabs(M[2 * i] - cMx);
+        a3 += fabs(M[2 * i + 1] - cMy);
+    }
+    double smx = wave_sum(a0), smy = wave_sum(a1), sMx = wave_sum(a2), sMy = wave_sum(a3);
+    if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON)
+        return 0;
+    smx = count / smx;
+    smy = count / smy;
+    sMx = count / sMx;
+    sMy = count / sMy;
+    const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+    const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+    double acc[45];
+#pragma unroll
+    for (int e = 0; e < 45; e++) acc[e] = 0;
+    for (int i = lane; i < count; i += 64) {
+        const double x = (m[2 * i] - cmx) * smx, y = (m[2 * i + 1] - cmy) * smy;
+        const double X = (M[2 * i] - cMx) * sMx, Y = (M[2 * i + 1] - cMy) * sMy;
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+#pragma unroll
+            for (int k = j; k < 9; k++) acc[e++] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }
+    __syncthreads();
+    {
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+#pragma unroll
+            for (int k = j; k < 9; k++) {
+                const double v = wave_sum(acc[e++]);
+                if (lane == 0) {
+                    L->A[j * 9 + k] = v;
+                    L->A[k * 9 + j] = v;
+                }
+            }
+    }
+    __syncthreads();
+    jacobi_wave(L->A, L->W, L->V, L->indR, L->indC, L->perm, 9);
+    double H0v[9], Htemp[9], H0[9];
+    for (int i = 0; i < 9; i++) H0v[i] = L->V[72 + i];
+    mat3mul(invHnorm, H0v, Htemp);
+    mat3mul(Htemp, Hnorm2, H0);
+    const double sc = 1. / H0[8];
+    for (int i = 0; i < 9; i++) H[i] = H0[i] * sc;
+    __syncthreads();
+    return 1;
+}
+
+// HomographyEstimatorCallback::computeError in float32; inlier iff err <= thr
+__device__ __forceinline__ bool is_inlier(const float* Hf, float Mx, float My, float mx, float my, float thr) {
+    const float ww = 1.f / (Hf[6] * Mx + Hf[7] * My + 1.f);
+    const float dx = (Hf[0] * Mx + Hf[1] * My + Hf[2]) * ww - mx;
+    const float dy = (Hf[3] * Mx + Hf[4] * My + Hf[5]) * ww - my;
+    const float err = dx * dx + dy * dy;
+    return err <= thr;
+}
+
+// ------------------------------------------------------------------ subsets
+__device__ bool have_collinear4(const float* p) {
+    const int i = 3;
+    for (int j = 0; j < i; j++) {
+        const double dx1 = p[2 * j] - p[2 * i], dy1 = p[2 * j + 1] - p[2 * i + 1];
+        for (int k = 0; k < j; k++) {
+            const double dx2 = p[2 * k] - p[2 * i], dy2 = p[2 * k + 1] - p[2 * i + 1];
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)))
+                return true;
+        }
+    }
+    return false;
+}
+__device__ __forceinline__ double det3pts(const float* p, int a, int b, int c) {
+    const double m00 = p[2 * a], m01 = p[2 * a + 1], m10 = p[2 * b], m11 = p[2 * b + 1], m20 = p[2 * c], m21 = p[2 * c + 1];
+    return m00 * (m11 * 1. - 1. * m21) - m01 * (m10 * 1. - 1. * m20) + 1. * (m10 * m21 - m11 * m20);
+}
+__device__ bool check_subset(const float* ms1, const float* ms2) {
+    if (have_collinear4(ms1) || have_collinear4(ms2)) return false;
+    const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int negative = 0;
+    for (int i = 0; i < 4; i++)
+        negative += det3pts(ms1, tt[i][0], tt[i][1], tt[i][2]) * det3pts(ms2, tt[i][0], tt[i][1], tt[i][2]) < 0;
+    return negative == 0 || negative == 4;
+}
+
+// One RANSAC iteration's getSubset starting at draw `start` of the raw RNG stream:
+// returns the number of draws it consumes (or -1: no valid subset within the table
+// or within 10000 attempts) and the four indices.
+__device__ int sim_subset(const float* __restrict__ src, const float* __restrict__ dst, int count,
+                          const uint32_t* __restrict__ raw, int raw_n, int start, int* idx) {
+    int pos = start;
+    float ms1[8], ms2[8];
+    for (int attempt = 0; attempt < 10000; attempt++) {
+        for (int i = 0; i < 4; i++) {
+            int v;
+            for (;;) {
+                if (pos >= raw_n) return -1;
+                v = (int)(raw[pos++] % (uint32_t)count);
+                bool dup = false;
+                for (int k = 0; k < i; k++) dup |= idx[k] == v;
+                if (!dup) break;
+            }
+            idx[i] = v;
+            ms1[2 * i] = src[2 * v];
+            ms1[2 * i + 1] = src[2 * v + 1];
+            ms2[2 * i] = dst[2 * v];
+            ms2[2 * i + 1] = dst[2 * v + 1];
+        }
+        if (check_subset(ms1, ms2)) return pos - start;
+    }
+    return -1;
+}
+
+// Subsets of iterations [h0, h1) of one problem, 64 at a time: lane L guesses the
+// stream position of iteration h0+L, simulates it, the guesses are corrected by a
+// prefix sum of the consumed draws and the round repeats until nothing moves.
+__global__ __launch_bounds__(64) void k_rs_subsets(const float* __restrict__ src, const float* __restrict__ dst,
+                                                   const int* __restrict__ count_p, const uint32_t* __restrict__ raw,
+                                                   int raw_n, RsState* __restrict__ st, int* __restrict__ idx_out,
+                                                   int h0, int h1, double confidence, int max_iters, int first) {
+    const int lane = threadIdx.x;
+    const int count = *count_p;
+    if (first && lane == 0) {
+        st->niters = max_iters > 1 ? max_iters : 1;
+        st->max_good = 0;
+        st->best = -1;
+        st->done = count <= 4 ? 1 : 0;
+        st->found = 0;
+        st->fail_at = -1;
+        st->next_pos = 0;
+        st->next_iter = 0;
+    }
+    __syncthreads();
+    if (count <= 4) return;
+    if (!first && (st->done || st->fail_at >= 0)) return;
+    int base = first ? 0 : st->next_pos;
+    if (h1 > max_iters) h1 = max_iters;
+    if (!first && h1 > st->niters) h1 = st->niters;  // the budget only ever shrinks
+    for (int c0 = h0; c0 < h1; c0 += 64) {
+        const int h = c0 + lane;
+        int pos = base + 4 * lane, cons = 0, idx[4] = {0, 0, 0, 0};
+        bool fresh = true;
+        for (int round = 0; round < 65; round++) {
+            if (fresh) cons = sim_subset(src, dst, count, raw, raw_n, pos, idx);
+            // exclusive prefix sum of the draws consumed (a failed lane counts as 0)
+            int inc = cons > 0 ? cons : 0;
+            int scan = inc;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(scan, o);
+                if (lane >= o) scan += u;
+            }
+            const int npos = base + scan - inc;
+            fresh = npos != pos;
+            pos = npos;
+            if (!__any(fresh)) break;
+        }
+        // first failing lane ends the stream
+        const unsigned long long bad = __ballot(cons < 0 && h < h1);
+        const int first_bad = bad ? __ffsll((long long)bad) - 1 : 64;
+        if (h < h1 && lane < first_bad) {
+            idx_out[4 * h] = idx[0];
+            idx_out[4 * h + 1] = idx[1];
+            idx_out[4 * h + 2] = idx[2];
+            idx_out[4 * h + 3] = idx[3];
+        }
+        if (first_bad < 64) {
+            if (lane == 0) st->fail_at = c0 + first_bad;
+            return;
+        }
+        base = __shfl(pos + cons, 63);
+    }
+    if (lane == 0) {
+        st->next_pos = base;
+        st->next_iter = h1;
+    }
+}
+
+// One wave per hypothesis: solve the 4-point homography, count the inliers.
+__global__ __launch_bounds__(64) void k_rs_hyp(const float* __restrict__ src, const float* __restrict__ dst,
+                                               const int* __restrict__ count_p, const RsState* __restrict__ st,
+                                               const int* __restrict__ idx, int* __restrict__ good,
+                                               double* __restrict__ hypH, int h0, int h1, float thr) {
+    const int h = h0 + blockIdx.x;
+    const int count = *count_p;
+    if (h >= h1 || count <= 4 || st->done) return;
+    if (st->fail_at >= 0 && h >= st->fail_at) return;
+    if (h >= st->niters) return;
+    __shared__ JacobiLds L;
+    __shared__ float ms1[8], ms2[8];
+    const int lane = threadIdx.x;
+    if (lane < 4) {
+        const int v = idx[4 * h + lane];
+        ms1[2 * lane] = src[2 * v];
+        ms1[2 * lane + 1] = src[2 * v + 1];
+        ms2[2 * lane] = dst[2 * v];
+        ms2[2 * lane + 1] = dst[2 * v + 1];
+    }
+    __syncthreads();
+    double H[9];
+    if (!run_kernel_wave(ms1, ms2, 4, &L, H)) {
+        if (lane == 0) good[h] = -1;
+        return;
+    }
+    float Hf[8];
+    for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
+    int g = 0;
+    for (int i0 = 0; i0 < count; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false;
+        if (i < count) in = is_inlier(Hf, src[2 * i], src[2 * i + 1], dst[2 * i], dst[2 * i + 1], thr);
+        g += __popcll(__ballot(in));
+    }
+    if (lane == 0) good[h] = g;
+    if (lane < 9) hypH[9 * h + lane] = H[lane];
+}
+
+__device__ int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+    p = fmax(p, 0.);
+    p = fmin(p, 1.);
+    ep = fmax(ep, 0.);
+    ep = fmin(ep, 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : __double2int_rn(num / denom);
+}
+
+// The sequential keep/stop rule of RANSACPointSetRegistrator::run over the inlier
+// counts of iterations [h0, h1).
+__global__ void k_rs_replay(const int* __restrict__ count_p, RsState* __restrict__ st, const int* __restrict__ good,
+                            int h0, int h1, double confidence, int last) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int count = *count_p;
+    if (count <= 4 || st->done) return;
+    int niters = st->niters, max_good = st->max_good, best = st->best;
+    bool done = false;
+    for (int h = h0; h < h1; h++) {
+        if (h >= niters) {
+            done = true;
+            break;
+        }
+        if (st->fail_at == h) {
+            done = true;
+            break;
+        }
+        const int g = good[h];
+        if (g < 0) continue;
+        if (g > (max_good > 3 ? max_good : 3)) {
+            best = h;
+            max_good = g;
+            niters = update_num_iters(confidence, (double)(count - g) / count, 4, niters);
+        }
+    }
+    if (h1 >= niters || last) done = true;
+    st->niters = niters;
+    st->max_good = max_good;
+    st->best = best;
+    st->done = done ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ refine
+struct RefineLds {
+    JacobiLds J;
+    double A[64], Ap[64], v[8], d[8], D[8], x[8], xd[8], diag[8];
+};
+
+// residuals at parameters h over the compacted inliers: returns |r|^2; when
+// with_J, also JtJ -> S->A (8x8), Jt r -> S->v, and max |r| -> *rinf
+__device__ double lm_compute_wave(const float* __restrict__ M, const float* __restrict__ m, int count,
+                                  const double* h, bool with_J, RefineLds* S, double* rinf) {
+    const int lane = threadIdx.x & 63;
+    double acc[44];
+#pragma unroll
+    for (int e = 0; e < 44; e++) acc[e] = 0;
+    double ss = 0, rmax = 0;
+    for (int i = lane; i < count; i += 64) {
+        const double Mx = M[2 * i], My = M[2 * i + 1];
+        double ww = h[6] * Mx + h[7] * My + 1.;
+        ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+        const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+        const double ex = xi - m[2 * i], ey = yi - m[2 * i + 1];
+        ss += ex * ex + ey * ey;
+        rmax = fmax(rmax, fmax(fabs(ex), fabs(ey)));
+        if (with_J) {
+            const double Jx[8] = {Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi};
+            const double Jy[8] = {0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi};
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int b = a; b < 8; b++) acc[e++] += Jx[a] * Jx[b] + Jy[a] * Jy[b];
+#pragma unroll
+            for (int a = 0; a < 8; a++) acc[36 + a] += Jx[a] * ex + Jy[a] * ey;
+        }
+    }
+    if (with_J) {
+        __syncthreads();
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int b = a; b < 8; b++) {
+                const double v = wave_sum(acc[e++]);
+                if (lane == 0) {
+                    S->A[a * 8 + b] = v;
+                    S->A[b * 8 + a] = v;
+                }
+            }
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const double v = wave_sum(acc[36 + a]);
+            if (lane == 0) S->v[a] = v;
+        }
+        *rinf = wave_max(rmax);
+        __syncthreads();
+    }
+    return wave_sum(ss);
+}
+
+// Jacobi of the 8x8 in S->J.A (a copy), then either x = solve (to S->d) or diag(inverse) (to S->diag)
+__device__ void eig8_apply(RefineLds* S, const double* Asrc, bool solve) {
+    const int lane = threadIdx.x & 63;
+    __syncthreads();
+    S->J.A[lane] = Asrc[lane];
+    __syncthreads();
+    jacobi_wave(S->J.A, S->J.W, S->J.V, S->J.indR, S->J.indC, S->J.perm, 8);
+    if (lane == 0) {
+        double threshold = 0;
+        for (int i = 0; i < 8; i++) threshold += S->J.W[i];
+        threshold *= DBL_EPSILON * 2;
+        double out[8];
+        for (int j = 0; j < 8; j++) out[j] = 0;
+        for (int i = 0; i < 8; i++) {
+            double wi = S->J.W[i];
+            if (fabs(wi) <= threshold) continue;
+            wi = 1 / wi;
+            const double* vi = &S->J.V[i * 8];
+            if (solve) {
+                double s = 0;
+                for (int j = 0; j < 8; j++) s += vi[j] * S->v[j];
+                s *= wi;
+                for (int j = 0; j < 8; j++) out[j] = out[j] + s * vi[j];
+            } else {
+                for (int j = 0; j < 8; j++) out[j] = out[j] + vi[j] * (vi[j] * wi);
+            }
+        }
+        for (int j = 0; j < 8; j++) (solve ? S->d : S->diag)[j] = out[j];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double dot8(const double* a, const double* b) {
+    double r = 0;
+    r += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    r += a[4] * b[4] + a[5] * b[5] + a[6] * b[6] + a[7] * b[7];
+    return r;
+}
+
+// One wave per problem: the winner's inlier mask, runKernel on all inliers, LM polish.
+__global__ __launch_bounds__(64) void k_rs_refine(const float* __restrict__ src, const float* __restrict__ dst,
+                                                  const int* __restrict__ count_p, RsState* __restrict__ st,
+                                                  const double* __restrict__ hypH, float* __restrict__ csrc,
+                                                  float* __restrict__ cdst, double* __restrict__ outH,
+                                                  uint8_t* __restrict__ mask, int* __restrict__ found, float thr) {
+    __shared__ RefineLds S;
+    const int lane = threadIdx.x;
+    const int count = *count_p;
+    double H[9];
+    if (count < 4) {
+        if (lane == 0) *found = 0;
+        if (lane < 9) outH[lane] = 0;
+        return;
+    }
+    if (count == 4) {
+        const int ok = run_kernel_wave(src, dst, 4, &S.J, H);
+        if (lane == 0) *found = ok;
+        if (lane < 9) outH[lane] = ok ? H[lane] : 0;
+        if (lane < 4) mask[lane] = 1;
+        return;
+    }
+    const int best = st->best;
+    if (best < 0 || st->max_good <= 0) {
+        if (lane == 0) *found = 0;
+        if (lane < 9) outH[lane] = 0;
+        for (int i = lane; i < count; i += 64) mask[i] = 0;
+        return;
+    }
+    for (int i = 0; i < 9; i++) H[i] = hypH[9 * best + i];
+    float Hf[8];
+    for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
+    // inlier mask + order-preserving compaction
+    int n = 0;
+    for (int i0 = 0; i0 < count; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false;
+        float sx = 0, sy = 0, dx = 0, dy = 0;
+        if (i < count) {
+            sx = src[2 * i];
+            sy = src[2 * i + 1];
+            dx = dst[2 * i];
+            dy = dst[2 * i + 1];
+            in = is_inlier(Hf, sx, sy, dx, dy, thr);
+            mask[i] = in ? 1 : 0;
+        }
+        const unsigned long long bal = __ballot(in);
+        if (in) {
+            const int p = n + __popcll(bal & ((1ull << lane) - 1ull));
+            csrc[2 * p] = sx;
+            csrc[2 * p + 1] = sy;
+            cdst[2 * p] = dx;
+            cdst[2 * p + 1] = dy;
+        }
+        n += __popcll(bal);
+    }
+    __syncthreads();
+    if (n > 0) {
+        double H2[9];
+        if (run_kernel_wave(csrc, cdst, n, &S.J, H2))
+            for (int i = 0; i < 9; i++) H[i] = H2[i];
+        // LMSolverImpl::run, maxIters = 10, eps = FLT_EPSILON, 8 parameters
+        const int maxIters = 10;
+        const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
+        if (lane < 8) S.x[lane] = H[lane];
+        __syncthreads();
+        double rinf = 0;
+        double Sres = lm_compute_wave(csrc, cdst, n, S.x, true, &S, &rinf);
+        if (lane < 8) S.D[lane] = S.A[lane * 8 + lane];
+        const double Rlo = 0.25, Rhi = 0.75;
+        double lambda = 1, lc = 0.75;
+        int iter = 0;
+        for (;;) {
+            __syncthreads();
+            S.Ap[lane] = ((lane >> 3) == (lane & 7)) ? S.A[lane] + lambda * S.D[lane & 7] : S.A[lane];
+            eig8_apply(&S, S.Ap, true);
+            if (lane < 8) S.xd[lane] = S.x[lane] - S.d[lane];
+            __syncthreads();
+            const double Sd = lm_compute_wave(csrc, cdst, n, S.xd, false, &S, nullptr);
+            double temp_d[8], d[8], v[8];
+            for (int i = 0; i < 8; i++) d[i] = S.d[i], v[i] = S.v[i];
+            for (int i = 0; i < 8; i++) {
+                double s = 0;
+                for (int k = 0; k < 8; k++) s += S.A[i * 8 + k] * d[k];
+                temp_d[i] = s * -1. + v[i] * 2.;
+            }
+            const double dS = dot8(d, temp_d);
+            const double R = (Sres - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+            if (R > Rhi) {
+                lambda *= 0.5;
+                if (lambda < lc) lambda = 0;
+            } else if (R < Rlo) {
+                const double t = dot8(d, v);
+                double nu = (Sd - Sres) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
+                nu = fmin(fmax(nu, 2.), 10.);
+                if (lambda == 0) {
+                    eig8_apply(&S, S.A, false);
+                    double maxval = DBL_EPSILON;
+                    for (int i = 0; i < 8; i++) maxval = fmax(maxval, fabs(S.diag[i]));
+                    lambda = lc = 1. / maxval;
+                    nu *= 0.5;
+                }
+                lambda *= nu;
+            }
+            if (Sd < Sres) {
+                __syncthreads();
+                if (lane < 8) S.x[lane] = S.xd[lane];
+                __syncthreads();
+                Sres = lm_compute_wave(csrc, cdst, n, S.x, true, &S, &rinf);
+            }
+            iter++;
+            double dinf = 0;
+            for (int i = 0; i < 8; i++) dinf = fmax(dinf, fabs(d[i]));
+            const bool proceed = iter < maxIters && dinf >= epsx && rinf >= epsf;
+            if (!proceed) break;
+        }
+        __syncthreads();
+        for (int i = 0; i < 8; i++) H[i] = S.x[i];
+        const double sc = fabs(H[8]) > FLT_EPSILON ? 1. / H[8] : 1.;
+        for (int i = 0; i < 9; i++) H[i] *= sc;
+    }
+    if (lane == 0) *found = 1;
+    if (lane < 9) outH[lane] = H[lane];
+}
+
+}  // namespace
+
+size_t rtvm_ransac_state_bytes() { return sizeof(RsState); }
+
+// raw outputs of cv::RNG((uint64)-1): state = (uint32)state * 4164903690 + (state >> 32)
+void rtvm_ransac_raw_table(uint32_t* raw, int n) {
+    uint64_t state = 0xFFFFFFFFFFFFFFFFull;
+    for (int i = 0; i < n; i++) {
+        state = (uint64_t)(uint32_t)state * 4164903690ull + (uint32_t)(state >> 32);
+        raw[i] = (uint32_t)state;
+    }
+}
+
+// Queues the whole of findHomography(RANSAC) for the point pairs in d_src/d_dst
+// (count read from device memory, at most cap points).  Results: d_H (9 doubles),
+// d_mask (count bytes), d_found.
+int rtvm_launch_ransac(rtvm_ctx* c, const float* d_src, const float* d_dst, const int* d_count, double thresh,
+                       int max_iters, double confidence, double* d_H, uint8_t* d_mask, int* d_found) {
+    if (max_iters > RTVM_RANSAC_MAX_ITERS)
+        RTVM_FAIL(c, RTVM_E_ARG, "findHomography: maxIters above %d is not supported", RTVM_RANSAC_MAX_ITERS);
+    if (max_iters < 1) max_iters = 1;
+    if (!(confidence > 0 && confidence < 1)) RTVM_FAIL(c, RTVM_E_ARG, "findHomography: confidence must be in (0,1)");
+    const float thr = (float)(thresh * thresh);
+    RsState* st = (RsState*)c->d_rs_state;
+    const int b0 = max_iters < RS_BATCH0 ? max_iters : RS_BATCH0;
+    hipLaunchKernelGGL(k_rs_subsets, dim3(1), dim3(64), 0, c->stream, d_src, d_dst, d_count, c->d_rs_raw,
+                       c->rs_raw_n, st, c->d_rs_idx, 0, b0, confidence, max_iters, 1);
+    hipLaunchKernelGGL(k_rs_hyp, dim3(b0), dim3(64), 0, c->stream, d_src, d_dst, d_count, st, c->d_rs_idx,
+                       c->d_rs_good, c->d_rs_hypH, 0, b0, thr);
+    hipLaunchKernelGGL(k_rs_replay, dim3(1), dim3(64), 0, c->stream, d_count, st, c->d_rs_good, 0, b0, confidence,
+                       b0 >= max_iters ? 1 : 0);
+    if (b0 < max_iters) {
+        hipLaunchKernelGGL(k_rs_subsets, dim3(1), dim3(64), 0, c->stream, d_src, d_dst, d_count, c->d_rs_raw,
+                           c->rs_raw_n, st, c->d_rs_idx, b0, max_iters, confidence, max_iters, 0);
+        hipLaunchKernelGGL(k_rs_hyp, dim3(max_iters - b0), dim3(64), 0, c->stream, d_src, d_dst, d_count, st,
+                           c->d_rs_idx, c->d_rs_good, c->d_rs_hypH, b0, max_iters, thr);
+        hipLaunchKernelGGL(k_rs_replay, dim3(1), dim3(64), 0, c->stream, d_count, st, c->d_rs_good, b0, max_iters,
+                           confidence, 1);
+    }
+    hipLaunchKernelGGL(k_rs_refine, dim3(1), dim3(64), 0, c->stream, d_src, d_dst, d_count, st, c->d_rs_hypH,
+                       c->d_rs_csrc, c->d_rs_cdst, d_H, d_mask, d_found, thr);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}

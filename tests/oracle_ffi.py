@@ -80,3 +80,18 @@ def warp_blend(canvas, bgr, H, fixed):
                                       bgr.shape[1], _p(H), int(fixed))
     assert rc == 0
     return canvas
+
+
+def find_homography(src, dst, thresh=2.0, max_iters=2000, confidence=0.995):
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+    dst = np.ascontiguousarray(dst, np.float32).reshape(-1, 2)
+    m = len(src)
+    H = np.zeros(9, np.float64)
+    mask = np.zeros(max(m, 1), np.uint8)
+    found = C.c_int(0)
+    rc = lib().rtvm_oracle_find_homography_ransac(_p(src), _p(dst), m, C.c_double(thresh), max_iters,
+                                                  C.c_double(confidence), _p(H), _p(mask), C.byref(found))
+    assert rc == 0
+    if not found.value:
+        return None, mask[:m]
+    return H.reshape(3, 3), mask[:m]
