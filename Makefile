@@ -17,7 +17,11 @@ all: lib oracle
 
 lib: $(LIBDIR)/librtvm.so
 
-build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/rtvm.h
+# the rBRIEF pattern as a C initialiser list, generated from the data file
+$(CSRC)/orb_pattern.inc: $(PKG)/data/orb_pattern_31.txt
+	grep -v '^#' $< | awk '{printf "%d, %d, %d, %d,\n", $$1, $$2, $$3, $$4}' > $@
+
+build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/rtvm.h $(CSRC)/orb_pattern.inc
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

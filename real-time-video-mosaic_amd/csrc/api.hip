@@ -23,6 +23,25 @@ int dev_alloc(rtvm_ctx* c, T** p, size_t n) {
         if (r_ != RTVM_OK) return r_;                         \
     } while (0)
 
+int alloc_feat(rtvm_ctx* c, FeatSet* f, int n) {
+    int r;
+    if ((r = dev_alloc(c, &f->xy, (size_t)n * 2))) return r;
+    if ((r = dev_alloc(c, &f->size, n))) return r;
+    if ((r = dev_alloc(c, &f->angle, n))) return r;
+    if ((r = dev_alloc(c, &f->response, n))) return r;
+    if ((r = dev_alloc(c, &f->octave, n))) return r;
+    if ((r = dev_alloc(c, &f->lxy, (size_t)n * 2))) return r;
+    if ((r = dev_alloc(c, &f->desc, (size_t)n * 32))) return r;
+    if ((r = dev_alloc(c, &f->count, 4))) return r;
+    return RTVM_OK;
+}
+
+void free_feat(FeatSet* f) {
+    void* ptrs[] = {f->xy, f->size, f->angle, f->response, f->octave, f->lxy, f->desc, f->count};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+}
+
 int alloc_all(rtvm_ctx* c) {
     // matcher
     const int mk = RTVM_MAX_MATCH;
@@ -57,6 +76,25 @@ int alloc_all(rtvm_ctx* c) {
     ALLOC(c, d_jobs, 3);
     int r = rtvm_warp_setup(c);
     if (r != RTVM_OK) return r;
+    // ORB
+    if (c->fh > 0 && c->fw > 0) {
+        if ((r = rtvm_orb_plan(c))) return r;
+        ALLOC(c, d_pyr, c->orb_pyr_bytes);
+        ALLOC(c, d_pyr_blur, c->orb_pyr_bytes);
+        ALLOC(c, d_score, c->orb_pyr_bytes);
+        ALLOC(c, d_xofs, c->orb_xtab_total + 1);
+        ALLOC(c, d_xw, c->orb_xtab_total + 1);
+        ALLOC(c, d_yofs, c->orb_ytab_total + 1);
+        ALLOC(c, d_yw, c->orb_ytab_total + 1);
+        ALLOC(c, d_cand, c->orb_cand_total);
+        ALLOC(c, d_cand_count, RTVM_NLEVELS + RTVM_NLEVELS * 256);
+        ALLOC(c, d_sel_count, RTVM_NLEVELS);
+        ALLOC(c, d_sel_lxy, (size_t)c->orb_sel_total * 2);
+        ALLOC(c, d_sel_resp, c->orb_sel_total);
+        for (int k = 0; k < 2; k++)
+            if ((r = alloc_feat(c, &c->feat[k], c->orb.max_kp))) return r;
+        if ((r = rtvm_orb_setup(c))) return r;
+    }
     // RANSAC
     ALLOC(c, d_rs_src, (size_t)mk * 2);
     ALLOC(c, d_rs_dst, (size_t)mk * 2);
@@ -88,7 +126,11 @@ void free_all(rtvm_ctx* c) {
                     c->d_m_dist, c->d_m_count, c->d_bgr, c->d_canvas, c->d_warped, c->d_mask_new, c->d_mask_old,
                     c->d_dt_s, c->d_dt_r, c->d_dt_f, c->d_dist, c->d_wgt, c->d_rb, c->d_gk, c->d_H, c->d_wp,
                     c->d_jobs, c->d_rs_src, c->d_rs_dst, c->d_rs_count, c->d_rs_state, c->d_rs_raw, c->d_rs_idx,
-                    c->d_rs_good, c->d_rs_hypH, c->d_rs_csrc, c->d_rs_cdst, c->d_rs_H, c->d_rs_mask, c->d_rs_found};
+                    c->d_rs_good, c->d_rs_hypH, c->d_rs_csrc, c->d_rs_cdst, c->d_rs_H, c->d_rs_mask, c->d_rs_found,
+                    c->d_pyr, c->d_pyr_blur, c->d_score, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_cand,
+                    c->d_cand_count, c->d_sel_count, c->d_sel_lxy, c->d_sel_resp};
+    free_feat(&c->feat[0]);
+    free_feat(&c->feat[1]);
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -191,6 +233,57 @@ extern "C" int rtvm_match_hamming_xcheck_sorted(rtvm_ctx* c, const uint8_t* q, i
                                                 const uint8_t* t, int nt, int32_t* qidx,
                                                 int32_t* tidx, int32_t* dist, int* m_out) {
     return match_hamming_host(c, q, nq, t, nt, qidx, tidx, dist, m_out, 1);
+}
+
+// ---- gray / ORB ---------------------------------------------------------------
+extern "C" int rtvm_max_keypoints(const rtvm_ctx* c) { return c ? c->orb.max_kp : 0; }
+
+static int need_frame(rtvm_ctx* c, const char* who) {
+    if (c->fh <= 0 || c->fw <= 0) RTVM_FAIL(c, RTVM_E_STATE, "%s: context was created without a frame size", who);
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_orb(rtvm_ctx* c, const uint8_t* bgr, int* n_out, float* xy, float* size, float* angle_deg,
+                        float* response, int32_t* octave, uint8_t* desc) {
+    if (!c) return RTVM_E_ARG;
+    if (!bgr || !n_out) RTVM_FAIL(c, RTVM_E_ARG, "orb: null argument");
+    int r = need_frame(c, "orb");
+    if (r) return r;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
+    if ((r = rtvm_launch_orb(c, c->d_bgr, 0))) return r;
+    int* hc = (int*)c->h_pinned;
+    const FeatSet& F = c->feat[0];
+    HIP_TRY(c, hipMemcpyAsync(hc, F.count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int n = hc[0];
+    if (n < 0 || n > c->orb.max_kp) RTVM_FAIL(c, RTVM_E_HIP, "orb: device returned count %d", n);
+    if (n) {
+        if (xy) HIP_TRY(c, hipMemcpyAsync(xy, F.xy, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        if (size) HIP_TRY(c, hipMemcpyAsync(size, F.size, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (angle_deg) HIP_TRY(c, hipMemcpyAsync(angle_deg, F.angle, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (response) HIP_TRY(c, hipMemcpyAsync(response, F.response, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (octave) HIP_TRY(c, hipMemcpyAsync(octave, F.octave, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (desc) HIP_TRY(c, hipMemcpyAsync(desc, F.desc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    *n_out = n;
+    return RTVM_OK;
+}
+
+// gray = level 0 of the pyramid of the most recent frame; rtvm_gray runs the ORB front end
+extern "C" int rtvm_gray(rtvm_ctx* c, const uint8_t* bgr, uint8_t* gray) {
+    if (!c) return RTVM_E_ARG;
+    if (!bgr || !gray) RTVM_FAIL(c, RTVM_E_ARG, "gray: null argument");
+    int r = need_frame(c, "gray");
+    if (r) return r;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
+    if ((r = rtvm_launch_orb(c, c->d_bgr, 0))) return r;
+    HIP_TRY(c, hipMemcpy2DAsync(gray, c->fw, c->d_pyr + c->orb.off[0], c->orb.pitch[0], c->fw, c->fh,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTVM_OK;
 }
 
 // ---- RANSAC homography ------------------------------------------------------
@@ -319,9 +412,6 @@ extern "C" int rtvm_canvas_read(rtvm_ctx* c, uint8_t* out) {
 
 // ---- not yet implemented (stubs keep the ABI complete while stages land) ----
 #define RTVM_STUB(ctx) RTVM_FAIL(ctx, RTVM_E_STATE, "%s: not implemented yet", __func__)
-extern "C" int rtvm_max_keypoints(const rtvm_ctx* c) { return c ? c->plan.max_kp : 0; }
-extern "C" int rtvm_gray(rtvm_ctx* c, const uint8_t*, uint8_t*) { RTVM_STUB(c); }
-extern "C" int rtvm_orb(rtvm_ctx* c, const uint8_t*, int*, float*, float*, float*, float*, int32_t*, uint8_t*) { RTVM_STUB(c); }
 extern "C" int rtvm_match_l2_knn2(rtvm_ctx* c, const float*, int, const float*, int, int, int32_t*, float*) { RTVM_STUB(c); }
 extern "C" int rtvm_stream_begin(rtvm_ctx* c, const uint8_t*, int, int) { RTVM_STUB(c); }
 extern "C" int rtvm_process_frame(rtvm_ctx* c, const uint8_t*) { RTVM_STUB(c); }

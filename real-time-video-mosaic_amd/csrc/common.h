@@ -12,28 +12,20 @@
 #define RTVM_RANSAC_MAX_ITERS 2000
 
 // ---------------------------------------------------------------------------
-// ORB geometry (host side plan, mirrored in device constant tables)
-struct OrbLevel {
-    int w, h;          // level size
-    int pitch;         // row pitch in bytes of the level plane (multiple of 64)
-    size_t off;        // byte offset of the level plane inside a pyramid buffer
-    float scale;       // layerScale[level] = (float)pow(1.2f, level)
-    int quota;         // nfeaturesPerLevel
-    int cand_off;      // first slot of this level in the candidate arrays
-    int cand_cap;      // candidate capacity of this level
-    int sel_off;       // first slot of this level in the per-level selected arrays
-    int sel_cap;       // capacity of the per-level selected arrays
-    int xtab_off;      // offset into the resize x tables
-    int ytab_off;      // offset into the resize y tables
-};
-
-struct OrbPlan {
-    OrbLevel lv[RTVM_NLEVELS];
-    size_t pyr_bytes;  // bytes of one pyramid buffer (all levels)
-    int cand_total;
-    int sel_total;
-    int max_kp;        // capacity of the final keypoint arrays
-    int xtab_total, ytab_total;
+// ORB geometry and tables, passed to the kernels by value.
+struct OrbDev {
+    int w[RTVM_NLEVELS], h[RTVM_NLEVELS], pitch[RTVM_NLEVELS];
+    unsigned off[RTVM_NLEVELS];        // byte offset of the level plane in a pyramid buffer
+    float scale[RTVM_NLEVELS];         // (float)pow(1.2f, level)
+    int quota[RTVM_NLEVELS];           // nfeaturesPerLevel
+    int cand_off[RTVM_NLEVELS], cand_cap[RTVM_NLEVELS];
+    int sel_off[RTVM_NLEVELS];         // per-level selected arrays (capacity quota + 64)
+    int xtab_off[RTVM_NLEVELS], ytab_off[RTVM_NLEVELS];
+    int tile_off[RTVM_NLEVELS + 1];    // 64x8 tiles of the FAST region, prefix over levels
+    int btile_off[RTVM_NLEVELS + 1];   // 64x8 tiles of the whole level, prefix over levels
+    int umax[17];                      // half widths of the circular patch rows
+    int gk7[7];                        // 7-tap Gaussian, 8-bit fixed point
+    int max_kp;
 };
 
 // Feature set of one frame, device resident.
@@ -93,7 +85,9 @@ struct rtvm_ctx {
     char err[512];
 
     // --- ORB ---
-    OrbPlan plan;
+    OrbDev orb;
+    size_t orb_pyr_bytes;
+    int orb_cand_total, orb_sel_total, orb_xtab_total, orb_ytab_total;
     uint8_t* d_bgr;        // staging frame fh*fw*3
     uint8_t* d_pyr;        // pyramid (un-blurred)
     uint8_t* d_pyr_blur;   // pyramid after the 7x7 blur
@@ -102,7 +96,7 @@ struct rtvm_ctx {
     uint16_t* d_xw;
     uint16_t* d_yofs;
     uint16_t* d_yw;
-    uint32_t* d_cand;      // candidates: packed (score<<24 | y<<12 | x)?? see orb.hip
+    uint32_t* d_cand;      // candidates: packed (score << 24 | y << 12 | x)
     int* d_cand_count;     // RTVM_NLEVELS counters + RTVM_NLEVELS*256 histogram
     int* d_sel_count;      // per-level selected counts
     int32_t* d_sel_lxy;    // per-level selected (x,y)
@@ -188,6 +182,10 @@ int rtvm_warp_setup(rtvm_ctx* c);  // uploads constant tables (after allocation)
 int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_off);
 int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out);
 int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H);
+// orb.hip
+int rtvm_orb_plan(rtvm_ctx* c);   // host-side geometry (before allocation)
+int rtvm_orb_setup(rtvm_ctx* c);  // uploads tables (after allocation)
+int rtvm_launch_orb(rtvm_ctx* c, const uint8_t* d_bgr, int slot);
 // ransac.hip
 size_t rtvm_ransac_state_bytes();
 void rtvm_ransac_raw_table(uint32_t* raw, int n);

@@ -1,0 +1,634 @@
+// cv2.cvtColor(BGR2GRAY) + cv2.ORB_create(n).detectAndCompute for gfx950
+// (reference main.py:36,111-112,717-718).
+//
+// Pipeline (every stage keeps its data in HBM planes of one pyramid buffer, one
+// u8 plane per level, pitch a multiple of 64):
+//   k_gray        BGR -> level 0
+//   k_resize      level l-1 -> level l, bit-exact fixed-point bilinear (7 launches)
+//   k_fast_score  FAST-9/16 corner score, LDS-staged 70x14 tiles, all levels in one launch
+//   k_fast_nms    3x3 non-maximum suppression, 31-pixel border, wave-aggregated append
+//                 of candidates + per-level score histogram
+//   k_orb_select  one workgroup per level: retainBest(2n) from the histogram, raster
+//                 sort (bitonic, LDS), Harris response, retainBest(n) by rank counting
+//   k_blur7       7x7 Gaussian (integer, exact), all levels in one launch
+//   k_orb_describe one wave per keypoint: intensity-centroid angle, steered BRIEF-256
+// All integer stages are exact; the float stages (Harris response, angle, pattern
+// rotation) follow OpenCV's operation order without fused multiply-add.
+#include "common.h"
+
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int EDGE = 31;
+constexpr int FAST_T = 20;
+constexpr int SEL_CAP = 8192;  // FAST survivors per level the selection workgroup can hold
+
+__constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+// ------------------------------------------------------------------ gray / pyramid
+__global__ __launch_bounds__(256) void k_gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ out, int w, int h,
+                                              int pitch) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* p = bgr + ((size_t)y * w + x) * 3;
+    out[(size_t)y * pitch + x] = (uint8_t)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15);
+}
+
+// INTER_LINEAR_EXACT: 8.8 coefficients (xw/yw = weight of the second tap, 0xFFFF = clamped single tap)
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int sp, uint8_t* __restrict__ dst,
+                                                int dw, int dh, int dp, const uint16_t* __restrict__ xofs,
+                                                const uint16_t* __restrict__ xw, const uint16_t* __restrict__ yofs,
+                                                const uint16_t* __restrict__ yw) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    const int xo = xofs[x], yo = yofs[y];
+    const unsigned cx = xw[x], cy = yw[y];
+    const uint8_t* r0 = src + (size_t)yo * sp;
+    unsigned h0, h1 = 0;
+    if (cx == 0xFFFFu)
+        h0 = (unsigned)r0[xo] << 8;
+    else
+        h0 = (256u - cx) * r0[xo] + cx * r0[xo + 1];
+    unsigned v;
+    if (cy == 0xFFFFu) {
+        v = h0 << 8;
+    } else {
+        const uint8_t* r1 = r0 + sp;
+        if (cx == 0xFFFFu)
+            h1 = (unsigned)r1[xo] << 8;
+        else
+            h1 = (256u - cx) * r1[xo] + cx * r1[xo + 1];
+        v = (256u - cy) * h0 + cy * h1;
+    }
+    v = (v + 32768u) >> 16;
+    dst[(size_t)y * dp + x] = (uint8_t)(v > 255u ? 255u : v);
+}
+
+// ------------------------------------------------------------------ FAST
+__device__ __forceinline__ int tile_level(const OrbDev& P, int tile, int* local) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < RTVM_NLEVELS; k++)
+        if (tile >= P.tile_off[k]) l = k;
+    *local = tile - P.tile_off[l];
+    return l;
+}
+
+// Corner score of cv::FAST (type 9_16, threshold 20): max over the 16 arcs of 9
+// contiguous ring pixels of min(v - p) (bright centre) or min(p - v) (dark centre),
+// minus 1; 0 when no arc clears the threshold.  Scores are produced for the pixels
+// [30, W-30) x [30, H-30) of every level: the keypoints that survive the 31-pixel
+// border plus their 3x3 neighbourhood.
+__global__ __launch_bounds__(256) void k_fast_score(OrbDev P, const uint8_t* __restrict__ pyr,
+                                                    uint8_t* __restrict__ score) {
+    int local;
+    const int l = tile_level(P, blockIdx.x, &local);
+    const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
+    const int tiles_x = (W - 60 + 63) / 64;
+    const int tx0 = 30 + (local % tiles_x) * 64, ty0 = 30 + (local / tiles_x) * 8;
+    const uint8_t* img = pyr + P.off[l];
+    __shared__ uint8_t s[14][72];
+    for (int i = threadIdx.x; i < 14 * 70; i += 256) {
+        const int r = i / 70, c = i % 70;
+        const int y = min(ty0 - 3 + r, H - 1), x = min(tx0 - 3 + c, W - 1);
+        s[r][c] = img[(size_t)y * pitch + x];
+    }
+    __syncthreads();
+    const int cx = threadIdx.x & 63;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int cy = (threadIdx.x >> 6) + 4 * half;
+        const int x = tx0 + cx, y = ty0 + cy;
+        if (x >= W - 30 || y >= H - 30) continue;
+        const int v = s[cy + 3][cx + 3];
+        int d[16];
+        d[0] = v - s[cy + 6][cx + 3];
+        d[1] = v - s[cy + 6][cx + 4];
+        d[2] = v - s[cy + 5][cx + 5];
+        d[3] = v - s[cy + 4][cx + 6];
+        d[4] = v - s[cy + 3][cx + 6];
+        d[5] = v - s[cy + 2][cx + 6];
+        d[6] = v - s[cy + 1][cx + 5];
+        d[7] = v - s[cy + 0][cx + 4];
+        d[8] = v - s[cy + 0][cx + 3];
+        d[9] = v - s[cy + 0][cx + 2];
+        d[10] = v - s[cy + 1][cx + 1];
+        d[11] = v - s[cy + 2][cx + 0];
+        d[12] = v - s[cy + 3][cx + 0];
+        d[13] = v - s[cy + 4][cx + 0];
+        d[14] = v - s[cy + 5][cx + 1];
+        d[15] = v - s[cy + 6][cx + 2];
+        // an arc of 9 contains one pixel of every opposite pair
+        bool bright = true, dark = true;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            bright &= max(d[k], d[k + 8]) > FAST_T;
+            dark &= min(d[k], d[k + 8]) < -FAST_T;
+        }
+        int sc = 0;
+        if (bright || dark) {
+            int best = 0;
+            // min over arcs of 9 by doubling: m2, m4, m8, then one more element
+            int m2[16], m4[16], M2[16], M4[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                m2[k] = min(d[k], d[(k + 1) & 15]);
+                M2[k] = max(d[k], d[(k + 1) & 15]);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                m4[k] = min(m2[k], m2[(k + 2) & 15]);
+                M4[k] = max(M2[k], M2[(k + 2) & 15]);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int m9 = min(min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]);
+                const int M9 = max(max(M4[k], M4[(k + 4) & 15]), d[(k + 8) & 15]);
+                best = max(best, max(m9, -M9));
+            }
+            if (best > FAST_T) sc = best - 1;
+        }
+        score[P.off[l] + (size_t)y * pitch + x] = (uint8_t)sc;
+    }
+}
+
+// Keeps a scored pixel iff it beats its 8 neighbours strictly and lies at least
+// 31 pixels inside the level; appends (score << 24 | y << 12 | x) to the level's
+// candidate list (one atomic per wave) and counts the score in the level's histogram.
+__global__ __launch_bounds__(256) void k_fast_nms(OrbDev P, const uint8_t* __restrict__ score,
+                                                  uint32_t* __restrict__ cand, int* __restrict__ cand_count,
+                                                  int* __restrict__ hist) {
+    int local;
+    const int l = tile_level(P, blockIdx.x, &local);
+    const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
+    const int tiles_x = (W - 60 + 63) / 64;
+    const int x = 30 + (local % tiles_x) * 64 + (threadIdx.x & 63);
+    const uint8_t* S = score + P.off[l];
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int y = 30 + (local / tiles_x) * 8 + (threadIdx.x >> 6) + 4 * half;
+        bool keep = false;
+        int s = 0;
+        if (x >= EDGE && x < W - EDGE && y >= EDGE && y < H - EDGE) {
+            const uint8_t* p = S + (size_t)y * pitch + x;
+            s = p[0];
+            if (s) {
+                keep = s > p[-1] && s > p[1] && s > p[-pitch - 1] && s > p[-pitch] && s > p[-pitch + 1] &&
+                       s > p[pitch - 1] && s > p[pitch] && s > p[pitch + 1];
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&cand_count[l], __popcll(bal));
+            base = __shfl(base, 0);
+            if (keep) {
+                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < P.cand_cap[l]) cand[P.cand_off[l] + pos] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+                atomicAdd(&hist[l * 256 + s], 1);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ selection
+__device__ float harris_response(const uint8_t* __restrict__ img, int pitch, int x0, int y0) {
+    int a = 0, b = 0, c = 0;
+    for (int i = -3; i <= 3; i++) {
+        const uint8_t* r0 = img + (size_t)(y0 + i - 1) * pitch + x0;
+        const uint8_t* r1 = r0 + pitch;
+        const uint8_t* r2 = r1 + pitch;
+#pragma unroll
+        for (int j = -3; j <= 3; j++) {
+            const int Ix = (r1[j + 1] - r1[j - 1]) * 2 + (r0[j + 1] - r0[j - 1]) + (r2[j + 1] - r2[j - 1]);
+            const int Iy = (r2[j] - r0[j]) * 2 + (r2[j - 1] - r0[j - 1]) + (r2[j + 1] - r0[j + 1]);
+            a += Ix * Ix;
+            b += Iy * Iy;
+            c += Ix * Iy;
+        }
+    }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    const float fa = (float)a, fb = (float)b, fc = (float)c;
+    return (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
+}
+
+// One workgroup per level.  KeyPointsFilter::retainBest keeps everything whose
+// response is >= the n-th largest; a point is kept iff fewer than n points have a
+// strictly larger response.  Survivors keep row-major order.
+__global__ __launch_bounds__(1024) void k_orb_select(OrbDev P, const uint8_t* __restrict__ pyr,
+                                                     const uint32_t* __restrict__ cand,
+                                                     const int* __restrict__ cand_count, const int* __restrict__ hist,
+                                                     int* __restrict__ sel_count, int32_t* __restrict__ sel_lxy,
+                                                     float* __restrict__ sel_resp) {
+    const int l = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t s_key[SEL_CAP];
+    __shared__ float s_resp[SEL_CAP];
+    __shared__ int s_n, s_thr, s_base;
+    __shared__ int s_wave[16];
+    const int quota = P.quota[l];
+    const int n_cand = min(cand_count[l], P.cand_cap[l]);
+    if (tid == 0) {
+        s_n = 0;
+        s_base = 0;
+        int thr = 0;
+        const int want = 2 * quota;
+        if (want == 0) thr = 256;
+        else if (n_cand > want) {
+            int cum = 0;
+            for (int s = 255; s >= 0; s--) {
+                cum += hist[l * 256 + s];
+                if (cum >= want) {
+                    thr = s;
+                    break;
+                }
+            }
+            // more ties at the cut than the workgroup can hold: raise the cut
+            while (cum > SEL_CAP && thr < 256) {
+                cum -= hist[l * 256 + thr];
+                thr++;
+            }
+        } else if (n_cand > SEL_CAP) {
+            int cum = n_cand;
+            while (cum > SEL_CAP && thr < 256) {
+                cum -= hist[l * 256 + thr];
+                thr++;
+            }
+        }
+        s_thr = thr;
+    }
+    __syncthreads();
+    const int thr = s_thr;
+    for (int i = tid; i < n_cand; i += 1024) {
+        const uint32_t e = cand[P.cand_off[l] + i];
+        if ((int)(e >> 24) >= thr) {
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < SEL_CAP) s_key[pos] = e & 0x00FFFFFFu;
+        }
+    }
+    __syncthreads();
+    const int n = min(s_n, SEL_CAP);
+    // raster order: ascending (y << 12 | x)
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (int i = n + tid; i < n2; i += 1024) s_key[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = s_key[i], b = s_key[ixj];
+                    if ((a > b) == ((i & k) == 0)) {
+                        s_key[i] = b;
+                        s_key[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const uint8_t* img = pyr + P.off[l];
+    for (int i = tid; i < n; i += 1024) {
+        const uint32_t e = s_key[i];
+        s_resp[i] = harris_response(img, P.pitch[l], (int)(e & 0xFFFu), (int)(e >> 12));
+    }
+    __syncthreads();
+    const int out_cap = quota + 64;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        bool keep = false;
+        if (i < n) {
+            keep = true;
+            if (n > quota) {
+                const float r = s_resp[i];
+                int greater = 0;
+                for (int j = 0; j < n; j++) greater += s_resp[j] > r;
+                keep = greater < quota;
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += s_wave[w];
+        const int base = s_base;
+        if (keep) {
+            const int pos = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < out_cap) {
+                const uint32_t e = s_key[i];
+                sel_lxy[2 * (P.sel_off[l] + pos)] = (int)(e & 0xFFFu);
+                sel_lxy[2 * (P.sel_off[l] + pos) + 1] = (int)(e >> 12);
+                sel_resp[P.sel_off[l] + pos] = s_resp[i];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += s_wave[w];
+            s_base = base + tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) sel_count[l] = min(s_base, out_cap);
+}
+
+// ------------------------------------------------------------------ blur
+// GaussianBlur(7x7, sigma 2) as ORB runs it on each level: integer taps
+// cvRound(k * 256), exact row and column sums, round half to even, saturate.
+__global__ __launch_bounds__(256) void k_blur7(OrbDev P, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ out) {
+    int local;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < RTVM_NLEVELS; k++)
+        if ((int)blockIdx.x >= P.btile_off[k]) l = k;
+    local = blockIdx.x - P.btile_off[l];
+    const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
+    const int tiles_x = (W + 63) / 64;
+    const int tx0 = (local % tiles_x) * 64, ty0 = (local / tiles_x) * 8;
+    const uint8_t* img = pyr + P.off[l];
+    __shared__ uint8_t s[14][72];
+    __shared__ int r[14][64];
+    for (int i = threadIdx.x; i < 14 * 70; i += 256) {
+        const int rr = i / 70, c = i % 70;
+        const int y = reflect101(ty0 - 3 + rr, H), x = reflect101(tx0 - 3 + c, W);
+        s[rr][c] = img[(size_t)y * pitch + x];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 14 * 64; i += 256) {
+        const int rr = i >> 6, c = i & 63;
+        int a = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) a += P.gk7[k] * s[rr][c + k];
+        r[rr][c] = a;
+    }
+    __syncthreads();
+    const int cx = threadIdx.x & 63;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int cy = (threadIdx.x >> 6) + 4 * half;
+        const int x = tx0 + cx, y = ty0 + cy;
+        if (x >= W || y >= H) continue;
+        unsigned a = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) a += (unsigned)P.gk7[k] * (unsigned)r[cy + k][cx];
+        unsigned q = a >> 16;
+        const unsigned rem = a & 0xFFFFu;
+        if (rem > 32768u || (rem == 32768u && (q & 1u))) q++;
+        out[P.off[l] + (size_t)y * pitch + x] = (uint8_t)(q > 255u ? 255u : q);
+    }
+}
+
+// ------------------------------------------------------------------ describe
+__device__ float fast_atan2(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / M_PI), p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    const float p5 = 0.1555786518463281f * (float)(180 / M_PI), p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// One wave per output keypoint: orientation by intensity centroid on the level
+// image (31 lanes sum one row of the disc each), then the 256 steered BRIEF tests
+// on the blurred level (4 per lane, packed through ballot-free shuffles).
+__global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const uint8_t* __restrict__ pyr,
+                                                     const uint8_t* __restrict__ blur,
+                                                     const int* __restrict__ sel_count,
+                                                     const int32_t* __restrict__ sel_lxy,
+                                                     const float* __restrict__ sel_resp, FeatSet F) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    int l = -1, idx = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < RTVM_NLEVELS; k++) {
+        const int c = sel_count[k];
+        if (l < 0 && slot < total + c) {
+            l = k;
+            idx = slot - total;
+        }
+        total += c;
+    }
+    if (slot == 0 && lane == 0) *F.count = min(total, P.max_kp);
+    if (l < 0 || slot >= P.max_kp) return;
+    const int x0 = sel_lxy[2 * (P.sel_off[l] + idx)], y0 = sel_lxy[2 * (P.sel_off[l] + idx) + 1];
+    const int pitch = P.pitch[l];
+    const uint8_t* img = pyr + P.off[l];
+    // moments over the disc of radius 15: lane v+15 handles row v
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+        const int v = lane - 15;
+        const int d = P.umax[v < 0 ? -v : v];
+        const uint8_t* row = img + (size_t)(y0 + v) * pitch + x0;
+        int sum = 0;
+        for (int u = -d; u <= d; u++) {
+            const int val = row[u];
+            m10 += u * val;
+            sum += val;
+        }
+        m01 = v * sum;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        m10 += __shfl_xor(m10, m);
+        m01 += __shfl_xor(m01, m);
+    }
+    const float angle = fast_atan2((float)m01, (float)m10);
+    const float sf = P.scale[l];
+    if (lane == 0) {
+        F.xy[2 * slot] = (float)x0 * sf;
+        F.xy[2 * slot + 1] = (float)y0 * sf;
+        F.size[slot] = 31 * sf;
+        F.angle[slot] = angle;
+        F.response[slot] = sel_resp[P.sel_off[l] + idx];
+        F.octave[slot] = l;
+        F.lxy[2 * slot] = x0;
+        F.lxy[2 * slot + 1] = y0;
+    }
+    float ang = angle;
+    ang *= (float)(M_PI / 180.f);
+    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    const uint8_t* bimg = blur + P.off[l] + (size_t)y0 * pitch + x0;
+    unsigned nib = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int8_t* p = &c_pattern[(lane * 4 + t) * 4];
+        const float px1 = (float)p[0], py1 = (float)p[1], px2 = (float)p[2], py2 = (float)p[3];
+        const float x1 = px1 * a - py1 * b, y1 = px1 * b + py1 * a;
+        const float x2 = px2 * a - py2 * b, y2 = px2 * b + py2 * a;
+        const int t0 = bimg[(ptrdiff_t)__float2int_rn(y1) * pitch + __float2int_rn(x1)];
+        const int t1 = bimg[(ptrdiff_t)__float2int_rn(y2) * pitch + __float2int_rn(x2)];
+        nib |= (unsigned)(t0 < t1) << t;
+    }
+    const unsigned hi = __shfl_down(nib, 1);
+    if ((lane & 1) == 0) F.desc[(size_t)slot * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------- host
+static inline int cv_round_d(double v) { return (int)std::nearbyint(v); }
+
+static void lin_coeffs(int src, int dst, uint16_t* ofs, uint16_t* c1) {
+    const double inv_scale = (double)dst / src;
+    const double scale = 1.0 / inv_scale;
+    for (int v = 0; v < dst; v++) {
+        const double f = scale * ((double)v + 0.5) - 0.5;
+        const int i = (int)std::floor(f);
+        if (i >= 0 && src > 1) {
+            if (i < src - 1) {
+                ofs[v] = (uint16_t)i;
+                c1[v] = (uint16_t)cv_round_d((f - (double)i) * 256.0);
+            } else {
+                ofs[v] = (uint16_t)(src - 1);
+                c1[v] = 0xFFFF;
+            }
+        } else {
+            ofs[v] = 0;
+            c1[v] = 0xFFFF;
+        }
+    }
+}
+
+// Level geometry, quotas and tables of cv::ORB (nlevels 8, scaleFactor 1.2f).
+int rtvm_orb_plan(rtvm_ctx* c) {
+    OrbDev& P = c->orb;
+    memset(&P, 0, sizeof(P));
+    const int W = c->fw, H = c->fh, n = c->nfeatures;
+    if (W > 4095 || H > 4095) RTVM_FAIL(c, RTVM_E_ARG, "ORB: frame side above 4095 is not supported");
+    size_t off = 0;
+    int cand = 0, sel = 0, xt = 0, yt = 0, tiles = 0, btiles = 0;
+    for (int l = 0; l < RTVM_NLEVELS; l++) {
+        const float scale = (float)std::pow((double)1.2f, (double)l);
+        const float inv = 1.0f / scale;
+        P.scale[l] = scale;
+        P.w[l] = cv_round_d(W * inv);
+        P.h[l] = cv_round_d(H * inv);
+        P.pitch[l] = (P.w[l] + 63) & ~63;
+        P.off[l] = (unsigned)off;
+        off += (size_t)P.pitch[l] * (P.h[l] + 1);
+        off = (off + 255) & ~(size_t)255;
+        P.cand_off[l] = cand;
+        P.cand_cap[l] = (P.w[l] * P.h[l]) / 4 + 1024;
+        cand += P.cand_cap[l];
+        P.xtab_off[l] = xt;
+        P.ytab_off[l] = yt;
+        xt += P.w[l];
+        yt += P.h[l];
+        P.tile_off[l] = tiles;
+        if (P.w[l] > 2 * EDGE && P.h[l] > 2 * EDGE) tiles += ((P.w[l] - 60 + 63) / 64) * ((P.h[l] - 60 + 7) / 8);
+        P.btile_off[l] = btiles;
+        btiles += ((P.w[l] + 63) / 64) * ((P.h[l] + 7) / 8);
+    }
+    P.tile_off[RTVM_NLEVELS] = tiles;
+    P.btile_off[RTVM_NLEVELS] = btiles;
+    c->orb_pyr_bytes = off;
+    c->orb_cand_total = cand;
+    c->orb_xtab_total = xt;
+    c->orb_ytab_total = yt;
+    {  // nfeaturesPerLevel
+        const float factor = (float)(1.0 / (double)1.2f);
+        float nd = n * (1 - factor) / (1 - (float)std::pow((double)factor, (double)RTVM_NLEVELS));
+        int sum = 0;
+        for (int l = 0; l < RTVM_NLEVELS - 1; l++) {
+            P.quota[l] = (int)std::nearbyintf(nd);
+            sum += P.quota[l];
+            nd *= factor;
+        }
+        P.quota[RTVM_NLEVELS - 1] = n - sum > 0 ? n - sum : 0;
+    }
+    for (int l = 0; l < RTVM_NLEVELS; l++) {
+        P.sel_off[l] = sel;
+        sel += P.quota[l] + 64;
+    }
+    c->orb_sel_total = sel;
+    P.max_kp = n + 64 * RTVM_NLEVELS;
+    {  // umax of the circular patch (half size 15)
+        const int hp = 15;
+        int v, v0, vmax = (int)std::floor(hp * std::sqrt(2.f) / 2 + 1);
+        int vmin = (int)std::ceil(hp * std::sqrt(2.f) / 2);
+        for (v = 0; v <= vmax; ++v) P.umax[v] = cv_round_d(std::sqrt((double)hp * hp - v * v));
+        for (v = hp, v0 = 0; v >= vmin; --v) {
+            while (P.umax[v0] == P.umax[v0 + 1]) ++v0;
+            P.umax[v] = v0;
+            ++v0;
+        }
+    }
+    {  // 7-tap Gaussian, sigma 2, as 8-bit fixed point
+        double t[7], sum = 0;
+        const double sigma = 2.0, scale2 = -0.5 / (sigma * sigma);
+        for (int i = 0; i < 7; i++) {
+            const double x = i - 3.0;
+            t[i] = std::exp(scale2 * x * x);
+            sum += t[i];
+        }
+        sum = 1. / sum;
+        for (int i = 0; i < 7; i++) P.gk7[i] = (int)std::nearbyintf((float)(t[i] * sum) * 256.f);
+    }
+    return RTVM_OK;
+}
+
+// Resize tables of levels 1..7 (level l is resized from level l-1).
+int rtvm_orb_setup(rtvm_ctx* c) {
+    const OrbDev& P = c->orb;
+    std::vector<uint16_t> xo(c->orb_xtab_total + 1), xw(c->orb_xtab_total + 1), yo(c->orb_ytab_total + 1),
+        yw(c->orb_ytab_total + 1);
+    for (int l = 1; l < RTVM_NLEVELS; l++) {
+        lin_coeffs(P.w[l - 1], P.w[l], &xo[P.xtab_off[l]], &xw[P.xtab_off[l]]);
+        lin_coeffs(P.h[l - 1], P.h[l], &yo[P.ytab_off[l]], &yw[P.ytab_off[l]]);
+    }
+    HIP_TRY(c, hipMemcpy(c->d_xofs, xo.data(), xo.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_xw, xw.data(), xw.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_yofs, yo.data(), yo.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_yw, yw.data(), yw.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_score, 0, c->orb_pyr_bytes));
+    return RTVM_OK;
+}
+
+// Queues detectAndCompute of the device-resident BGR frame into feature slot `slot`.
+int rtvm_launch_orb(rtvm_ctx* c, const uint8_t* d_bgr, int slot) {
+    const OrbDev& P = c->orb;
+    HIP_TRY(c, hipMemsetAsync(c->d_cand_count, 0, (RTVM_NLEVELS + RTVM_NLEVELS * 256) * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_gray, dim3((P.w[0] + 255) / 256, P.h[0]), dim3(256), 0, c->stream, d_bgr, c->d_pyr + P.off[0],
+                       P.w[0], P.h[0], P.pitch[0]);
+    for (int l = 1; l < RTVM_NLEVELS; l++)
+        hipLaunchKernelGGL(k_resize, dim3((P.w[l] + 255) / 256, P.h[l]), dim3(256), 0, c->stream,
+                           c->d_pyr + P.off[l - 1], P.pitch[l - 1], c->d_pyr + P.off[l], P.w[l], P.h[l], P.pitch[l],
+                           c->d_xofs + P.xtab_off[l], c->d_xw + P.xtab_off[l], c->d_yofs + P.ytab_off[l],
+                           c->d_yw + P.ytab_off[l]);
+    int* hist = c->d_cand_count + RTVM_NLEVELS;
+    if (P.tile_off[RTVM_NLEVELS] > 0) {
+        hipLaunchKernelGGL(k_fast_score, dim3(P.tile_off[RTVM_NLEVELS]), dim3(256), 0, c->stream, P, c->d_pyr,
+                           c->d_score);
+        hipLaunchKernelGGL(k_fast_nms, dim3(P.tile_off[RTVM_NLEVELS]), dim3(256), 0, c->stream, P, c->d_score,
+                           c->d_cand, c->d_cand_count, hist);
+    }
+    hipLaunchKernelGGL(k_orb_select, dim3(RTVM_NLEVELS), dim3(1024), 0, c->stream, P, c->d_pyr, c->d_cand,
+                       c->d_cand_count, hist, c->d_sel_count, c->d_sel_lxy, c->d_sel_resp);
+    hipLaunchKernelGGL(k_blur7, dim3(P.btile_off[RTVM_NLEVELS]), dim3(256), 0, c->stream, P, c->d_pyr, c->d_pyr_blur);
+    hipLaunchKernelGGL(k_orb_describe, dim3(P.max_kp), dim3(64), 0, c->stream, P, c->d_pyr, c->d_pyr_blur,
+                       c->d_sel_count, c->d_sel_lxy, c->d_sel_resp, c->feat[slot]);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}

@@ -1,0 +1,117 @@
+"""gray + ORB: oracle sanity (CPU), HIP vs oracle (GPU, every output bit-exact)."""
+import numpy as np
+import pytest
+
+import oracle_ffi as orc
+import rtvm
+from rtvm import synth
+
+
+def frame(h, w, seed=0, t=0):
+    world = synth.make_world(h + 160, w + 160, seed=seed)
+    G = synth.camera_matrix(t, 40.0, 60.0, (0.3, -0.2), step=3.0, rot_deg=2.0, zoom=1e-3)
+    return synth.render_frame(world, G, h, w)
+
+
+# ------------------------------------------------------------------ CPU
+def test_gray_formula():
+    rng = np.random.default_rng(0)
+    f = rng.integers(0, 256, (37, 53, 3)).astype(np.uint8)
+    ref = ((f[..., 0].astype(np.int64) * 3735 + f[..., 1].astype(np.int64) * 19235 +
+            f[..., 2].astype(np.int64) * 9798 + 16384) >> 15).astype(np.uint8)
+    assert np.array_equal(orc.gray(f), ref)
+    assert orc.gray(np.full((4, 4, 3), 255, np.uint8)).min() == 255
+
+
+def test_pyramid_geometry_and_resize():
+    g = orc.gray(frame(240, 320))
+    pyr, blur = orc.orb_pyramid(g)
+    assert [p.shape for p in pyr][:3] == [(240, 320), (200, 267), (167, 222)]
+    assert np.array_equal(pyr[0], g)
+    # a constant image stays constant through resize and blur (kernel taps sum to 257/256)
+    cpyr, cblur = orc.orb_pyramid(np.full((120, 160), 100, np.uint8))
+    assert all((p == 100).all() for p in cpyr)
+    assert all((b == 101).all() for b in cblur)
+    # bilinear down-scaling stays within the range of the source
+    assert pyr[1].min() >= g.min() and pyr[1].max() <= g.max()
+
+
+def test_oracle_orb_invariants():
+    f = frame(240, 320)
+    r = orc.orb(f, 500)
+    n = len(r["xy"])
+    assert 300 < n <= 500
+    counts = np.bincount(r["octave"], minlength=8)
+    quota, nd, f = [], None, np.float32(1.0 / float(np.float32(1.2)))
+    nd = np.float32(500) * (np.float32(1) - f) / (np.float32(1) - np.float32(float(f) ** 8))
+    for _ in range(7):
+        quota.append(int(np.rint(nd)))
+        nd = np.float32(nd * f)
+    quota.append(max(500 - sum(quota), 0))
+    assert all(c <= q for c, q in zip(counts, quota))
+    assert np.all(np.diff(r["octave"]) >= 0)
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    lev = r["xy"] / scale[r["octave"]][:, None]
+    assert np.abs(lev - np.rint(lev)).max() < 1e-3          # integer level coordinates
+    lw = np.array([320, 267, 222, 185, 154, 129, 107, 89])[r["octave"]]
+    assert np.all(np.rint(lev[:, 0]) >= 31) and np.all(np.rint(lev[:, 0]) < lw - 31)
+    assert np.all((r["angle"] >= 0) & (r["angle"] < 360.0001))
+    assert np.allclose(r["size"], 31 * scale[r["octave"]])
+    # descriptors of the same scene under a 3 px shift mostly match
+    r2 = orc.orb(frame(240, 320, t=1), 500)
+    qi, ti, di = orc.match_hamming(r2["desc"], r["desc"], True)
+    assert len(qi) > 150 and np.median(di) < 40
+
+
+def test_fast_detects_a_synthetic_corner():
+    f = np.full((100, 100, 3), 40, np.uint8)
+    f[40:, 40:] = 200
+    r = orc.orb(f, 50)
+    lvl0 = r["xy"][r["octave"] == 0]
+    assert len(lvl0) >= 1
+    assert np.abs(lvl0 - np.array([40, 40])).max(axis=1).min() <= 3
+
+
+# ------------------------------------------------------------------ GPU
+def _check_equal(got, ref):
+    assert len(got["xy"]) == len(ref["xy"])
+    for k in ("octave", "xy", "size", "response", "angle", "desc"):
+        assert np.array_equal(got[k], ref[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,n", [(240, 320, 500), (200, 200, 50), (480, 640, 700), (720, 1280, 1000)])
+def test_hip_orb_bit_exact(h, w, n):
+    c = rtvm.Context(h, w, 0, 0, nfeatures=n)
+    for t in (0, 1):
+        f = frame(h, w, seed=3, t=t)
+        assert np.array_equal(c.gray(f), orc.gray(f))
+        _check_equal(c.orb(f), orc.orb(f, n))
+    c.close()
+
+
+@pytest.mark.gpu
+def test_hip_orb_featureless_and_tiny():
+    c = rtvm.Context(120, 160, 0, 0, nfeatures=100)
+    flat = np.full((120, 160, 3), 77, np.uint8)
+    assert len(c.orb(flat)["xy"]) == 0 and len(orc.orb(flat, 100)["xy"]) == 0
+    f = frame(120, 160, seed=9)
+    _check_equal(c.orb(f), orc.orb(f, 100))
+    c.close()
+    c = rtvm.Context(64, 64, 0, 0, nfeatures=100)   # only level 0 is larger than the 31 px border
+    f = frame(64, 64, seed=4)
+    _check_equal(c.orb(f), orc.orb(f, 100))
+    c.close()
+
+
+@pytest.mark.gpu
+def test_hip_orb_many_ties():
+    """A periodic pattern gives many equal FAST scores and Harris responses at the cuts."""
+    f = np.full((256, 256, 3), 30, np.uint8)
+    for y in range(8, 256, 24):
+        for x in range(8, 256, 24):
+            f[y:y + 10, x:x + 10] = 220
+    c = rtvm.Context(256, 256, 0, 0, nfeatures=60)
+    got, ref = c.orb(f), orc.orb(f, 60)
+    _check_equal(got, ref)
+    c.close()
