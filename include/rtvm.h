@@ -146,6 +146,24 @@ int rtvm_process_frame(rtvm_ctx* ctx, const uint8_t* bgr_dev);
  * rtvm_process_frame (any may be NULL).  Syncs the stream. */
 int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_matches, double H_abs[9]);
 
+/* ---- two-call form of process_frame for hosts that keep the validate / smooth /
+ * chain arithmetic of main.py:733-746 on their side (the Python VideMosaic) ----- */
+
+/* process_first_frame + canvas set-up (main.py:78-94, 104-112), host frame.  Syncs. */
+int rtvm_first_frame(rtvm_ctx* ctx, const uint8_t* bgr, int row_off, int col_off);
+/* main.py:716-731: upload the frame, detect, match against the previous frame,
+ * RANSAC.  *found = 0 when there are fewer than 4 matches or no model.  Syncs. */
+int rtvm_frame_register(rtvm_ctx* ctx, const uint8_t* bgr, int* n_matches, int* found, double H_rel[9]);
+/* main.py:748, 756-759: warp + blend the registered frame with the absolute
+ * homography H, then make it the previous frame. */
+int rtvm_frame_commit(rtvm_ctx* ctx, const double H[9]);
+/* kp_cur/des_cur (slot 0) or kp_prev/des_prev (slot 1) of the stream; any output may
+ * be NULL; capacity rtvm_max_keypoints(). */
+int rtvm_get_features(rtvm_ctx* ctx, int slot, int* n_out, float* xy, float* size, float* angle_deg,
+                      float* response, int32_t* octave, uint8_t* desc);
+/* self.matches of the most recent frame (sorted by distance); capacity rtvm_max_keypoints(). */
+int rtvm_get_matches(rtvm_ctx* ctx, int* m_out, int32_t* qidx, int32_t* tidx, int32_t* dist);
+
 #ifdef __cplusplus
 }
 #endif

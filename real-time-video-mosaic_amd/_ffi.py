@@ -45,6 +45,11 @@ SIGNATURES = {
     "rtvm_stream_begin": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_process_frame": (C.c_int, [_vp, _vp]),
     "rtvm_frame_status": (C.c_int, [_vp, _intp, _intp, _intp, _vp]),
+    "rtvm_first_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "rtvm_frame_register": (C.c_int, [_vp, _vp, _intp, _intp, _vp]),
+    "rtvm_frame_commit": (C.c_int, [_vp, _vp]),
+    "rtvm_get_features": (C.c_int, [_vp, C.c_int, _intp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rtvm_get_matches": (C.c_int, [_vp, _intp, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -205,6 +210,49 @@ class Context:
 
     def sync(self):
         self._check(lib().rtvm_sync(self._h))
+
+    # ---- two-call stream form (host frames, glue on the host) ---------------
+    def first_frame(self, bgr, row_off, col_off):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        assert bgr.shape == (self.frame_h, self.frame_w, 3)
+        self._check(lib().rtvm_first_frame(self._h, ptr(bgr), int(row_off), int(col_off)))
+
+    def frame_register(self, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        assert bgr.shape == (self.frame_h, self.frame_w, 3)
+        m, found = C.c_int(0), C.c_int(0)
+        H = np.zeros(9, np.float64)
+        self._check(lib().rtvm_frame_register(self._h, ptr(bgr), C.byref(m), C.byref(found), ptr(H)))
+        return m.value, bool(found.value), H.reshape(3, 3)
+
+    def frame_commit(self, H):
+        H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
+        self._check(lib().rtvm_frame_commit(self._h, ptr(H)))
+
+    def get_features(self, slot):
+        cap = max(self.max_keypoints(), 1)
+        n = C.c_int(0)
+        xy = np.empty((cap, 2), np.float32)
+        size = np.empty(cap, np.float32)
+        angle = np.empty(cap, np.float32)
+        resp = np.empty(cap, np.float32)
+        octave = np.empty(cap, np.int32)
+        desc = np.empty((cap, 32), np.uint8)
+        self._check(lib().rtvm_get_features(self._h, int(slot), C.byref(n), ptr(xy), ptr(size), ptr(angle),
+                                            ptr(resp), ptr(octave), ptr(desc)))
+        k = n.value
+        return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=angle[:k].copy(),
+                    response=resp[:k].copy(), octave=octave[:k].copy(), desc=desc[:k].copy())
+
+    def get_matches(self):
+        cap = max(self.max_keypoints(), 1)
+        m = C.c_int(0)
+        qi = np.empty(cap, np.int32)
+        ti = np.empty(cap, np.int32)
+        di = np.empty(cap, np.int32)
+        self._check(lib().rtvm_get_matches(self._h, C.byref(m), ptr(qi), ptr(ti), ptr(di)))
+        k = m.value
+        return qi[:k].copy(), ti[:k].copy(), di[:k].copy()
 
     # ---- device-resident stream path -------------------------------------
     def stream_begin(self, bgr_dev_ptr, row_off, col_off):

@@ -95,6 +95,11 @@ int alloc_all(rtvm_ctx* c) {
             if ((r = alloc_feat(c, &c->feat[k], c->orb.max_kp))) return r;
         if ((r = rtvm_orb_setup(c))) return r;
     }
+    // stream state
+    ALLOC(c, d_state, 1);
+    ALLOC(c, d_wtab, 32);
+    ALLOC(c, d_skip, 4);
+    if ((r = rtvm_stream_setup(c))) return r;
     // RANSAC
     ALLOC(c, d_rs_src, (size_t)mk * 2);
     ALLOC(c, d_rs_dst, (size_t)mk * 2);
@@ -128,7 +133,7 @@ void free_all(rtvm_ctx* c) {
                     c->d_jobs, c->d_rs_src, c->d_rs_dst, c->d_rs_count, c->d_rs_state, c->d_rs_raw, c->d_rs_idx,
                     c->d_rs_good, c->d_rs_hypH, c->d_rs_csrc, c->d_rs_cdst, c->d_rs_H, c->d_rs_mask, c->d_rs_found,
                     c->d_pyr, c->d_pyr_blur, c->d_score, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_cand,
-                    c->d_cand_count, c->d_sel_count, c->d_sel_lxy, c->d_sel_resp};
+                    c->d_cand_count, c->d_sel_count, c->d_sel_lxy, c->d_sel_resp, c->d_state, c->d_wtab, c->d_skip};
     free_feat(&c->feat[0]);
     free_feat(&c->feat[1]);
     for (void* p : ptrs)
@@ -393,7 +398,7 @@ extern "C" int rtvm_warp_blend(rtvm_ctx* c, const uint8_t* bgr, const double H[9
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
     if ((r = upload_H(c, H))) return r;
-    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H))) return r;
+    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H, nullptr))) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RTVM_OK;
 }
@@ -413,6 +418,3 @@ extern "C" int rtvm_canvas_read(rtvm_ctx* c, uint8_t* out) {
 // ---- not yet implemented (stubs keep the ABI complete while stages land) ----
 #define RTVM_STUB(ctx) RTVM_FAIL(ctx, RTVM_E_STATE, "%s: not implemented yet", __func__)
 extern "C" int rtvm_match_l2_knn2(rtvm_ctx* c, const float*, int, const float*, int, int, int32_t*, float*) { RTVM_STUB(c); }
-extern "C" int rtvm_stream_begin(rtvm_ctx* c, const uint8_t*, int, int) { RTVM_STUB(c); }
-extern "C" int rtvm_process_frame(rtvm_ctx* c, const uint8_t*) { RTVM_STUB(c); }
-extern "C" int rtvm_frame_status(rtvm_ctx* c, int*, int*, int*, double*) { RTVM_STUB(c); }

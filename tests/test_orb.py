@@ -65,7 +65,9 @@ def test_oracle_orb_invariants():
 
 def test_fast_detects_a_synthetic_corner():
     f = np.full((100, 100, 3), 40, np.uint8)
-    f[40:, 40:] = 200
+    yy, xx = np.mgrid[0:100, 0:100]
+    shade = (250 - 2 * np.hypot(yy - 40, xx - 40)).clip(120, 250).astype(np.uint8)   # unique maximum at the tip
+    f[40:, 40:] = shade[40:, 40:, None]
     r = orc.orb(f, 50)
     lvl0 = r["xy"][r["octave"] == 0]
     assert len(lvl0) >= 1
