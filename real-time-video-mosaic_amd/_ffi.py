@@ -53,6 +53,32 @@ SIGNATURES = {
 }
 
 _lib = None
+HIP_RUNTIME = None   # path of the HIP runtime preloaded for librtvm.so (None: the linker's choice)
+
+
+def _preload_hip_runtime():
+    """One process can host only one HIP runtime.  PyTorch's wheel ships its own
+    libamdhip64.so (same SONAME as the system one), so when torch is installed its copy
+    is loaded first and librtvm.so binds to it; a later `import torch` then finds the
+    very same file.  RTVM_HIP_RUNTIME=<path> overrides, RTVM_HIP_RUNTIME=system skips."""
+    global HIP_RUNTIME
+    choice = os.environ.get("RTVM_HIP_RUNTIME", "")
+    if choice == "system":
+        return
+    path = choice
+    if not path:
+        import importlib.util
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is not None and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                path = cand
+    if path:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        HIP_RUNTIME = path
 
 
 def lib():
@@ -63,6 +89,7 @@ def lib():
             raise RuntimeError(
                 "librtvm.so not found at %s: build it with `make lib` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

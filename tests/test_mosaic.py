@@ -115,7 +115,7 @@ def test_stage_methods(capsys):
     assert rtvm.VideMosaic.findHomography(vm.kp_cur, vm.kp_prev, ms[:3]) is None
     c = rtvm.VideMosaic.get_transformed_corners(frames[0], np.array([[1, 0, 2.7], [0, 1, -3.2], [0, 0, 1.0]]))
     assert c.dtype == np.int32 and c.shape == (1, 4, 2)
-    assert c[0].tolist() == [[2, -3], [FW + 2, -3], [FW + 2, FH - 3], [2, FH - 3]]
+    assert c[0].tolist() == [[2, -3], [FW + 2, -3], [FW + 2, FH - 4], [2, FH - 4]]
     out = vm.warp(frames[2], vm.H_old)
     assert out.dtype == np.float64 and out.shape == vm.output_img.shape
     with pytest.raises(NotImplementedError):
