@@ -164,6 +164,16 @@ int rtvm_get_features(rtvm_ctx* ctx, int slot, int* n_out, float* xy, float* siz
 /* self.matches of the most recent frame (sorted by distance); capacity rtvm_max_keypoints(). */
 int rtvm_get_matches(rtvm_ctx* ctx, int* m_out, int32_t* qidx, int32_t* tidx, int32_t* dist);
 
+/* ---- measurement aid (no counterpart in the reference) ----------------------- */
+
+/* Times kernels with HIP events on the context's stream: every kernel (filter NULL
+ * or "") or those whose name contains filter. */
+int rtvm_profile_start(rtvm_ctx* ctx, const char* filter);
+/* Syncs, accumulates the intervals, stops timing. */
+int rtvm_profile_stop(rtvm_ctx* ctx);
+/* Text report, one line per kernel: "name launches total_ms".  Returns bytes needed. */
+int rtvm_profile_report(rtvm_ctx* ctx, char* buf, int buflen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,9 @@ SIGNATURES = {
     "rtvm_frame_commit": (C.c_int, [_vp, _vp]),
     "rtvm_get_features": (C.c_int, [_vp, C.c_int, _intp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtvm_get_matches": (C.c_int, [_vp, _intp, _vp, _vp, _vp]),
+    "rtvm_profile_start": (C.c_int, [_vp, C.c_char_p]),
+    "rtvm_profile_stop": (C.c_int, [_vp]),
+    "rtvm_profile_report": (C.c_int, [_vp, C.c_char_p, C.c_int]),
 }
 
 _lib = None
@@ -280,6 +283,22 @@ class Context:
         self._check(lib().rtvm_get_matches(self._h, C.byref(m), ptr(qi), ptr(ti), ptr(di)))
         k = m.value
         return qi[:k].copy(), ti[:k].copy(), di[:k].copy()
+
+    # ---- per-kernel timing ----------------------------------------------------
+    def profile_start(self, name_filter=None):
+        self._check(lib().rtvm_profile_start(self._h, name_filter.encode() if name_filter else None))
+
+    def profile_stop(self):
+        """Returns {kernel name: (launches, total_ms)}."""
+        self._check(lib().rtvm_profile_stop(self._h))
+        n = lib().rtvm_profile_report(self._h, None, 0)
+        buf = C.create_string_buffer(n + 16)
+        lib().rtvm_profile_report(self._h, buf, n + 16)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.rsplit(" ", 2)
+            out[name] = (int(cnt), float(ms))
+        return out
 
     # ---- device-resident stream path -------------------------------------
     def stream_begin(self, bgr_dev_ptr, row_off, col_off):

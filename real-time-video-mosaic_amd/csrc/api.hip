@@ -184,6 +184,7 @@ extern "C" void rtvm_destroy(rtvm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    rtvm_prof_free(c);
     free_all(c);
     (void)hipStreamDestroy(c->stream);
     delete c;

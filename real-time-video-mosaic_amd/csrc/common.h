@@ -158,6 +158,9 @@ struct rtvm_ctx {
     int* d_skip;           // 1 when the current frame was rejected
     int stream_ready;
     void* h_pinned;        // small pinned host buffer for read-backs
+    int prof_mode;         // 0 off, 1 every kernel, 2 kernels whose name contains prof_filter
+    char prof_filter[64];
+    void* prof;            // timing records (prof.hip)
 };
 
 #define RTVM_FAIL(ctx, code, ...)                         \
@@ -198,3 +201,15 @@ int rtvm_launch_ransac(rtvm_ctx* c, const float* d_src, const float* d_dst, cons
                        int max_iters, double confidence, double* d_H, uint8_t* d_mask, int* d_found);
 int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim,
                         int32_t* d_idx, float* d_dist);
+
+// ---- optional per-kernel timing with HIP events on the context's stream (prof.hip) ----
+int rtvm_prof_begin(rtvm_ctx* c, const char* name);
+void rtvm_prof_end(rtvm_ctx* c, int rec);
+void rtvm_prof_free(rtvm_ctx* c);
+
+#define RTVM_LAUNCH(c, kernel, grid, block, shmem, ...)                          \
+    do {                                                                         \
+        const int pr_ = (c)->prof_mode ? rtvm_prof_begin((c), #kernel) : -1;     \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (c)->stream, __VA_ARGS__); \
+        if (pr_ >= 0) rtvm_prof_end((c), pr_);                                   \
+    } while (0)

@@ -216,9 +216,9 @@ int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int m
     if (max_w <= 0 || max_h <= 0) return RTVM_OK;
     if (max_w > 16384 || max_h > 16384) RTVM_FAIL(c, RTVM_E_ARG, "distance transform: image side above 16384");
     const int nlines = max_w + max_h - 1;
-    hipLaunchKernelGGL(k_dt_diag, dim3((nlines + 63) / 64, 2, njobs), dim3(64, NCH), 0, c->stream, d_jobs);
-    hipLaunchKernelGGL(k_dt_rows, dim3(max_h, njobs), dim3(256), 0, c->stream, d_jobs);
-    hipLaunchKernelGGL(k_dt_cols, dim3((max_w + 63) / 64, njobs), dim3(64, NCH), 0, c->stream, d_jobs);
+    RTVM_LAUNCH(c, k_dt_diag, dim3((nlines + 63) / 64, 2, njobs), dim3(64, NCH), 0, d_jobs);
+    RTVM_LAUNCH(c, k_dt_rows, dim3(max_h, njobs), dim3(256), 0, d_jobs);
+    RTVM_LAUNCH(c, k_dt_cols, dim3((max_w + 63) / 64, njobs), dim3(64, NCH), 0, d_jobs);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }

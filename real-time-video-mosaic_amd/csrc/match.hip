@@ -153,15 +153,15 @@ int rtvm_launch_hamming(rtvm_ctx* c, const uint8_t* dq, const uint8_t* dt, const
         RTVM_FAIL(c, RTVM_E_ARG, "hamming matcher: at most %d descriptors per side", RTVM_MAX_MATCH);
     const int nfill = cap_q > cap_t ? cap_q : cap_t;
     if (nfill > 0) {
-        hipLaunchKernelGGL(k_fill_u32, dim3((nfill + 255) / 256), dim3(256), 0, c->stream, c->d_qkey,
+        RTVM_LAUNCH(c, k_fill_u32, dim3((nfill + 255) / 256), dim3(256), 0, c->d_qkey,
                            0xFFFFFFFFu, cap_q);
-        hipLaunchKernelGGL(k_fill_u32, dim3((nfill + 255) / 256), dim3(256), 0, c->stream, c->d_tkey,
+        RTVM_LAUNCH(c, k_fill_u32, dim3((nfill + 255) / 256), dim3(256), 0, c->d_tkey,
                            0xFFFFFFFFu, cap_t);
         const int tiles = (nfill + 63) / 64;
-        hipLaunchKernelGGL(k_hamming_argmin, dim3(tiles, tiles, 2), dim3(64), 0, c->stream, dq, dt, d_nq,
+        RTVM_LAUNCH(c, k_hamming_argmin, dim3(tiles, tiles, 2), dim3(64), 0, dq, dt, d_nq,
                            d_nt, c->d_qkey, c->d_tkey);
     }
-    hipLaunchKernelGGL(k_xcheck_compact, dim3(1), dim3(1024), 0, c->stream, c->d_qkey, c->d_tkey, d_nq,
+    RTVM_LAUNCH(c, k_xcheck_compact, dim3(1), dim3(1024), 0, c->d_qkey, c->d_tkey, d_nq,
                        d_nt, c->d_m_qidx, c->d_m_tidx, c->d_m_dist, c->d_m_count, sorted);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;

@@ -610,24 +610,24 @@ int rtvm_orb_setup(rtvm_ctx* c) {
 int rtvm_launch_orb(rtvm_ctx* c, const uint8_t* d_bgr, int slot) {
     const OrbDev& P = c->orb;
     HIP_TRY(c, hipMemsetAsync(c->d_cand_count, 0, (RTVM_NLEVELS + RTVM_NLEVELS * 256) * sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_gray, dim3((P.w[0] + 255) / 256, P.h[0]), dim3(256), 0, c->stream, d_bgr, c->d_pyr + P.off[0],
+    RTVM_LAUNCH(c, k_gray, dim3((P.w[0] + 255) / 256, P.h[0]), dim3(256), 0, d_bgr, c->d_pyr + P.off[0],
                        P.w[0], P.h[0], P.pitch[0]);
     for (int l = 1; l < RTVM_NLEVELS; l++)
-        hipLaunchKernelGGL(k_resize, dim3((P.w[l] + 255) / 256, P.h[l]), dim3(256), 0, c->stream,
+        RTVM_LAUNCH(c, k_resize, dim3((P.w[l] + 255) / 256, P.h[l]), dim3(256), 0,
                            c->d_pyr + P.off[l - 1], P.pitch[l - 1], c->d_pyr + P.off[l], P.w[l], P.h[l], P.pitch[l],
                            c->d_xofs + P.xtab_off[l], c->d_xw + P.xtab_off[l], c->d_yofs + P.ytab_off[l],
                            c->d_yw + P.ytab_off[l]);
     int* hist = c->d_cand_count + RTVM_NLEVELS;
     if (P.tile_off[RTVM_NLEVELS] > 0) {
-        hipLaunchKernelGGL(k_fast_score, dim3(P.tile_off[RTVM_NLEVELS]), dim3(256), 0, c->stream, P, c->d_pyr,
+        RTVM_LAUNCH(c, k_fast_score, dim3(P.tile_off[RTVM_NLEVELS]), dim3(256), 0, P, c->d_pyr,
                            c->d_score);
-        hipLaunchKernelGGL(k_fast_nms, dim3(P.tile_off[RTVM_NLEVELS]), dim3(256), 0, c->stream, P, c->d_score,
+        RTVM_LAUNCH(c, k_fast_nms, dim3(P.tile_off[RTVM_NLEVELS]), dim3(256), 0, P, c->d_score,
                            c->d_cand, c->d_cand_count, hist);
     }
-    hipLaunchKernelGGL(k_orb_select, dim3(RTVM_NLEVELS), dim3(1024), 0, c->stream, P, c->d_pyr, c->d_cand,
+    RTVM_LAUNCH(c, k_orb_select, dim3(RTVM_NLEVELS), dim3(1024), 0, P, c->d_pyr, c->d_cand,
                        c->d_cand_count, hist, c->d_sel_count, c->d_sel_lxy, c->d_sel_resp);
-    hipLaunchKernelGGL(k_blur7, dim3(P.btile_off[RTVM_NLEVELS]), dim3(256), 0, c->stream, P, c->d_pyr, c->d_pyr_blur);
-    hipLaunchKernelGGL(k_orb_describe, dim3(P.max_kp), dim3(64), 0, c->stream, P, c->d_pyr, c->d_pyr_blur,
+    RTVM_LAUNCH(c, k_blur7, dim3(P.btile_off[RTVM_NLEVELS]), dim3(256), 0, P, c->d_pyr, c->d_pyr_blur);
+    RTVM_LAUNCH(c, k_orb_describe, dim3(P.max_kp), dim3(64), 0, P, c->d_pyr, c->d_pyr_blur,
                        c->d_sel_count, c->d_sel_lxy, c->d_sel_resp, c->feat[slot]);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;

@@ -752,21 +752,21 @@ int rtvm_launch_ransac(rtvm_ctx* c, const float* d_src, const float* d_dst, cons
     const float thr = (float)(thresh * thresh);
     RsState* st = (RsState*)c->d_rs_state;
     const int b0 = max_iters < RS_BATCH0 ? max_iters : RS_BATCH0;
-    hipLaunchKernelGGL(k_rs_subsets, dim3(1), dim3(64), 0, c->stream, d_src, d_dst, d_count, c->d_rs_raw,
+    RTVM_LAUNCH(c, k_rs_subsets, dim3(1), dim3(64), 0, d_src, d_dst, d_count, c->d_rs_raw,
                        c->rs_raw_n, st, c->d_rs_idx, 0, b0, confidence, max_iters, 1);
-    hipLaunchKernelGGL(k_rs_hyp, dim3(b0), dim3(64), 0, c->stream, d_src, d_dst, d_count, st, c->d_rs_idx,
+    RTVM_LAUNCH(c, k_rs_hyp, dim3(b0), dim3(64), 0, d_src, d_dst, d_count, st, c->d_rs_idx,
                        c->d_rs_good, c->d_rs_hypH, 0, b0, thr);
-    hipLaunchKernelGGL(k_rs_replay, dim3(1), dim3(64), 0, c->stream, d_count, st, c->d_rs_good, 0, b0, confidence,
+    RTVM_LAUNCH(c, k_rs_replay, dim3(1), dim3(64), 0, d_count, st, c->d_rs_good, 0, b0, confidence,
                        b0 >= max_iters ? 1 : 0);
     if (b0 < max_iters) {
-        hipLaunchKernelGGL(k_rs_subsets, dim3(1), dim3(64), 0, c->stream, d_src, d_dst, d_count, c->d_rs_raw,
+        RTVM_LAUNCH(c, k_rs_subsets, dim3(1), dim3(64), 0, d_src, d_dst, d_count, c->d_rs_raw,
                            c->rs_raw_n, st, c->d_rs_idx, b0, max_iters, confidence, max_iters, 0);
-        hipLaunchKernelGGL(k_rs_hyp, dim3(max_iters - b0), dim3(64), 0, c->stream, d_src, d_dst, d_count, st,
+        RTVM_LAUNCH(c, k_rs_hyp, dim3(max_iters - b0), dim3(64), 0, d_src, d_dst, d_count, st,
                            c->d_rs_idx, c->d_rs_good, c->d_rs_hypH, b0, max_iters, thr);
-        hipLaunchKernelGGL(k_rs_replay, dim3(1), dim3(64), 0, c->stream, d_count, st, c->d_rs_good, b0, max_iters,
+        RTVM_LAUNCH(c, k_rs_replay, dim3(1), dim3(64), 0, d_count, st, c->d_rs_good, b0, max_iters,
                            confidence, 1);
     }
-    hipLaunchKernelGGL(k_rs_refine, dim3(1), dim3(64), 0, c->stream, d_src, d_dst, d_count, st, c->d_rs_hypH,
+    RTVM_LAUNCH(c, k_rs_refine, dim3(1), dim3(64), 0, d_src, d_dst, d_count, st, c->d_rs_hypH,
                        c->d_rs_csrc, c->d_rs_cdst, d_H, d_mask, d_found, thr);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;

@@ -172,7 +172,7 @@ int queue_front_half(rtvm_ctx* c, const uint8_t* d_bgr) {
     const int cap = c->orb.max_kp;
     if ((r = rtvm_launch_hamming(c, c->feat[0].desc, c->feat[1].desc, c->feat[0].count, c->feat[1].count, cap, cap, 1)))
         return r;
-    hipLaunchKernelGGL(k_gather_pts, dim3((cap + 255) / 256), dim3(256), 0, c->stream, c->d_m_count, c->d_m_qidx,
+    RTVM_LAUNCH(c, k_gather_pts, dim3((cap + 255) / 256), dim3(256), 0, c->d_m_count, c->d_m_qidx,
                        c->d_m_tidx, c->feat[0].xy, c->feat[1].xy, c->d_rs_src, c->d_rs_dst, c->d_rs_count);
     return rtvm_launch_ransac(c, c->d_rs_src, c->d_rs_dst, c->d_rs_count, 2.0, 2000, 0.995, c->d_rs_H, c->d_rs_mask,
                               c->d_rs_found);
@@ -181,10 +181,10 @@ int queue_front_half(rtvm_ctx* c, const uint8_t* d_bgr) {
 int queue_first_frame(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_off) {
     int r;
     if ((r = rtvm_launch_orb(c, d_bgr, 0))) return r;
-    hipLaunchKernelGGL(k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->stream, (const int*)nullptr,
+    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, (const int*)nullptr,
                        c->feat[0], c->feat[1], c->orb.max_kp);
     if ((r = rtvm_launch_canvas_init(c, d_bgr, row_off, col_off))) return r;
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, c->stream, c->d_state, row_off, col_off, c->d_skip);
+    RTVM_LAUNCH(c, k_state_init, dim3(1), dim3(64), 0, c->d_state, row_off, col_off, c->d_skip);
     HIP_TRY(c, hipGetLastError());
     c->stream_ready = 1;
     return RTVM_OK;
@@ -237,10 +237,10 @@ extern "C" int rtvm_process_frame(rtvm_ctx* c, const uint8_t* bgr_dev) {
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "process_frame: call rtvm_stream_begin first");
     HIP_TRY(c, hipSetDevice(c->device));
     if ((r = queue_front_half(c, bgr_dev))) return r;
-    hipLaunchKernelGGL(k_frame_update, dim3(1), dim3(64), 0, c->stream, c->d_state, c->d_m_count, c->d_rs_found,
+    RTVM_LAUNCH(c, k_frame_update, dim3(1), dim3(64), 0, c->d_state, c->d_m_count, c->d_rs_found,
                        c->d_rs_H, c->d_wtab, c->d_H, c->d_skip, c->feat[0].count, 50.0, 0.3);
     if ((r = rtvm_launch_warp_blend(c, bgr_dev, c->d_H, c->d_skip))) return r;
-    hipLaunchKernelGGL(k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->stream, c->d_skip,
+    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_skip,
                        c->feat[0], c->feat[1], c->orb.max_kp);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
@@ -298,7 +298,7 @@ extern "C" int rtvm_frame_commit(rtvm_ctx* c, const double H[9]) {
     HIP_TRY(c, hipMemcpyAsync(c->d_H, hp, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int r;
     if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H, nullptr))) return r;
-    hipLaunchKernelGGL(k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->stream, (const int*)nullptr,
+    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, (const int*)nullptr,
                        c->feat[0], c->feat[1], c->orb.max_kp);
     HIP_TRY(c, hipGetLastError());
     // the pinned staging of H is reused by the next call

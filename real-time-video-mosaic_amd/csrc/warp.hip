@@ -330,7 +330,7 @@ int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int 
     const size_t n_px = (size_t)c->ch * c->cw;
     HIP_TRY(c, hipMemsetAsync(c->d_canvas, 0, n_px * 3, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_mask_old, 0, n_px, c->stream));
-    hipLaunchKernelGGL(k_canvas_paste, dim3((c->fw + 63) / 64, (c->fh + 3) / 4), dim3(256), 0, c->stream, d_bgr,
+    RTVM_LAUNCH(c, k_canvas_paste, dim3((c->fw + 63) / 64, (c->fh + 3) / 4), dim3(256), 0, d_bgr,
                        c->d_canvas, c->d_mask_old, c->fh, c->fw, c->ch, c->cw, row_off, col_off);
     HIP_TRY(c, hipGetLastError());
     c->canvas_ready = 1;
@@ -339,14 +339,14 @@ int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int 
 
 // Full-canvas warp into d_out (stage parity of cv2.warpPerspective alone).
 int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out) {
-    hipLaunchKernelGGL(k_warp_prep, dim3(1), dim3(64), 0, c->stream, d_H, c->d_wp, (DtJob*)nullptr, c->fh, c->fw,
+    RTVM_LAUNCH(c, k_warp_prep, dim3(1), dim3(64), 0, d_H, c->d_wp, (DtJob*)nullptr, c->fh, c->fw,
                        c->ch, c->cw, 1, (const int*)nullptr);
     const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
     if (c->flags & RTVM_FLAG_WARP_FIXED)
-        hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, c->stream, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
+        RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
                            c->fh, c->fw, c->ch, c->cw);
     else
-        hipLaunchKernelGGL(k_warp<false>, grid, dim3(256), 0, c->stream, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
+        RTVM_LAUNCH(c, k_warp<false>, grid, dim3(256), 0, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
                            c->fh, c->fw, c->ch, c->cw);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
@@ -355,14 +355,14 @@ int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, 
 // The whole of VideMosaic.warp() for one frame, H read from device memory.
 int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, const int* d_skip) {
     const size_t n_px = (size_t)c->ch * c->cw;
-    hipLaunchKernelGGL(k_warp_prep, dim3(1), dim3(64), 0, c->stream, d_H, c->d_wp, c->d_jobs, c->fh, c->fw, c->ch,
+    RTVM_LAUNCH(c, k_warp_prep, dim3(1), dim3(64), 0, d_H, c->d_wp, c->d_jobs, c->fh, c->fw, c->ch,
                        c->cw, 0, d_skip);
     const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
     if (c->flags & RTVM_FLAG_WARP_FIXED)
-        hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, c->stream, d_bgr, c->d_wp, c->d_warped, c->d_mask_new,
+        RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, d_bgr, c->d_wp, c->d_warped, c->d_mask_new,
                            c->fh, c->fw, c->ch, c->cw);
     else
-        hipLaunchKernelGGL(k_warp<false>, grid, dim3(256), 0, c->stream, d_bgr, c->d_wp, c->d_warped, c->d_mask_new,
+        RTVM_LAUNCH(c, k_warp<false>, grid, dim3(256), 0, d_bgr, c->d_wp, c->d_warped, c->d_mask_new,
                            c->fh, c->fw, c->ch, c->cw);
     int r = rtvm_launch_dt(c, c->d_jobs, 2, c->cw, c->ch);
     if (r != RTVM_OK) return r;
@@ -370,10 +370,10 @@ int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H,
     float* wo = c->d_wgt + n_px;
     float* rbn = c->d_rb;
     float* rbo = c->d_rb + n_px;
-    hipLaunchKernelGGL(k_weights, grid, dim3(256), 0, c->stream, c->d_wp, c->d_dist, c->d_dist + n_px, wn, wo, c->cw);
-    hipLaunchKernelGGL(k_blur_rows, dim3((c->cw + 255) / 256, c->ch), dim3(256), 0, c->stream, c->d_wp, c->d_gk, wn,
+    RTVM_LAUNCH(c, k_weights, grid, dim3(256), 0, c->d_wp, c->d_dist, c->d_dist + n_px, wn, wo, c->cw);
+    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, c->ch), dim3(256), 0, c->d_wp, c->d_gk, wn,
                        wo, rbn, rbo, c->cw);
-    hipLaunchKernelGGL(k_blur_cols_commit, grid, dim3(256), 0, c->stream, c->d_wp, c->d_gk, rbn, rbo, c->d_warped,
+    RTVM_LAUNCH(c, k_blur_cols_commit, grid, dim3(256), 0, c->d_wp, c->d_gk, rbn, rbo, c->d_warped,
                        c->d_mask_new, c->d_mask_old, c->d_canvas, c->ch, c->cw);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;

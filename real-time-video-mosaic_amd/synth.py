@@ -103,3 +103,27 @@ def relative_h(G_prev, G_cur):
     """Homography taking frame-cur pixel coordinates to frame-prev pixel coordinates."""
     Hr = np.linalg.inv(G_prev) @ G_cur
     return Hr / Hr[2, 2]
+
+
+def render_video_torch(world, Gs, fh, fw, device):
+    """All frames of a camera path rendered on the GPU (float32 bilinear, rounded, clamped to
+    [1, 255]); returns a uint8 tensor [T, fh, fw, 3] resident on `device`."""
+    import torch
+    wt = torch.from_numpy(world).to(device).float()
+    H, W = world.shape[:2]
+    ys, xs = torch.meshgrid(torch.arange(fh, device=device, dtype=torch.float32),
+                            torch.arange(fw, device=device, dtype=torch.float32), indexing="ij")
+    out = torch.empty((len(Gs), fh, fw, 3), dtype=torch.uint8, device=device)
+    for t, G in enumerate(Gs):
+        g = [[float(v) for v in row] for row in G]
+        d = g[2][0] * xs + g[2][1] * ys + g[2][2]
+        u = (g[0][0] * xs + g[0][1] * ys + g[0][2]) / d
+        v = (g[1][0] * xs + g[1][1] * ys + g[1][2]) / d
+        u0 = u.floor().clamp(0, W - 2)
+        v0 = v.floor().clamp(0, H - 2)
+        a = (u - u0).clamp(0, 1)[..., None]
+        b = (v - v0).clamp(0, 1)[..., None]
+        iu, iv = u0.long(), v0.long()
+        p = (wt[iv, iu] * (1 - a) + wt[iv, iu + 1] * a) * (1 - b) + (wt[iv + 1, iu] * (1 - a) + wt[iv + 1, iu + 1] * a) * b
+        out[t] = p.round().clamp(1, 255).to(torch.uint8)
+    return out
