@@ -56,7 +56,8 @@ enum {
     RTVM_FRAME_OK = 0,
     RTVM_FRAME_FEW_MATCHES = 1, /* < 4 matches: frame skipped, state not advanced (main.py:722-724) */
     RTVM_FRAME_NO_HOMOGRAPHY = 2, /* RANSAC found no model: skipped (main.py:729-731) */
-    RTVM_FRAME_INVALID_H = 4    /* validate_homography() failed: identity used (main.py:734-737) */
+    RTVM_FRAME_INVALID_H = 4,   /* validate_homography() failed: identity used (main.py:734-737) */
+    RTVM_FRAME_PENDING = 8      /* not processed: an earlier frame of the same batch was skipped */
 };
 
 typedef struct rtvm_ctx rtvm_ctx;
@@ -142,6 +143,18 @@ int rtvm_stream_begin(rtvm_ctx* ctx, const uint8_t* bgr_dev, int row_off, int co
  * match, RANSAC, validate, smooth, chain, warp+blend, state advance, all queued on
  * the context's stream without a host round trip.  Asynchronous. */
 int rtvm_process_frame(rtvm_ctx* ctx, const uint8_t* bgr_dev);
+/* Room for batches of up to n frames (1..32) in rtvm_process_batch.  Allocates. */
+int rtvm_reserve_batch(rtvm_ctx* ctx, int n);
+/* process_frame for n consecutive device-resident frames (bgr_dev: n device pointers
+ * in a host array).  Detection, matching and RANSAC run for the whole batch at once,
+ * the warp + blend frame by frame.  When a frame in the middle of the batch is
+ * skipped (main.py:722-731) the later frames are left unprocessed with status
+ * RTVM_FRAME_PENDING; rtvm_batch_status reports how many frames were consumed and
+ * the caller resubmits the rest.  Asynchronous. */
+int rtvm_process_batch(rtvm_ctx* ctx, const uint8_t* const* bgr_dev, int n);
+/* Of the most recent batch: frames consumed and, per frame (arrays of cap entries,
+ * any may be NULL), status bits, match count, keypoint count.  Syncs the stream. */
+int rtvm_batch_status(rtvm_ctx* ctx, int* n_done, int* status, int* n_matches, int* n_keypoints, int cap);
 /* Status bits, match count and the absolute homography of the most recent
  * rtvm_process_frame (any may be NULL).  Syncs the stream. */
 int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_matches, double H_abs[9]);

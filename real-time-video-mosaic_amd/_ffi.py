@@ -45,6 +45,9 @@ SIGNATURES = {
     "rtvm_stream_begin": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_process_frame": (C.c_int, [_vp, _vp]),
     "rtvm_frame_status": (C.c_int, [_vp, _intp, _intp, _intp, _vp]),
+    "rtvm_reserve_batch": (C.c_int, [_vp, C.c_int]),
+    "rtvm_process_batch": (C.c_int, [_vp, _vp, C.c_int]),
+    "rtvm_batch_status": (C.c_int, [_vp, _intp, _vp, _vp, _vp, C.c_int]),
     "rtvm_first_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_frame_register": (C.c_int, [_vp, _vp, _intp, _intp, _vp]),
     "rtvm_frame_commit": (C.c_int, [_vp, _vp]),
@@ -306,6 +309,38 @@ class Context:
 
     def process_frame(self, bgr_dev_ptr):
         self._check(lib().rtvm_process_frame(self._h, C.c_void_p(bgr_dev_ptr)))
+
+    def reserve_batch(self, n):
+        self._check(lib().rtvm_reserve_batch(self._h, int(n)))
+
+    def process_batch(self, bgr_dev_ptrs):
+        """Queue process_frame for consecutive device-resident frames (list of device pointers)."""
+        n = len(bgr_dev_ptrs)
+        arr = (C.c_void_p * n)(*bgr_dev_ptrs)
+        self._check(lib().rtvm_process_batch(self._h, arr, n))
+
+    def batch_status(self, n):
+        """(frames consumed, status[n], matches[n], keypoints[n]) of the most recent batch.  Syncs."""
+        done = C.c_int(0)
+        st = np.zeros(n, np.int32)
+        nm = np.zeros(n, np.int32)
+        nk = np.zeros(n, np.int32)
+        self._check(lib().rtvm_batch_status(self._h, C.byref(done), ptr(st), ptr(nm), ptr(nk), n))
+        return done.value, st, nm, nk
+
+    def process_video(self, bgr_dev_ptrs, batch=16):
+        """process_frame over a whole list of device-resident frames in batches, resubmitting the
+        frames a skipped frame left pending.  Returns the per-frame status codes."""
+        self.reserve_batch(batch)
+        n, i = len(bgr_dev_ptrs), 0
+        status = np.zeros(n, np.int32)
+        while i < n:
+            k = min(batch, n - i)
+            self.process_batch(bgr_dev_ptrs[i:i + k])
+            done, st, _, _ = self.batch_status(k)
+            status[i:i + done] = st[:done]
+            i += max(done, 1)
+        return status
 
     def frame_status(self):
         st, nk, nm = C.c_int(0), C.c_int(0), C.c_int(0)

@@ -42,19 +42,103 @@ void free_feat(FeatSet* f) {
         if (p) (void)hipFree(p);
 }
 
+// Carves one device allocation into the buffers of a frame slot.
+struct Carver {
+    char* base;
+    size_t off;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += (n ? n : 1) * sizeof(T);
+        return p;
+    }
+};
+
+void carve_slot(rtvm_ctx* c, Carver& k, FrameSlot& S, int cap, int with_orb) {
+    if (with_orb) {
+        S.pyr = k.take<uint8_t>(c->orb_pyr_bytes);
+        S.pyr_blur = k.take<uint8_t>(c->orb_pyr_bytes);
+        S.score = k.take<uint8_t>(c->orb_pyr_bytes);
+        S.cand = k.take<uint32_t>(c->orb_cand_total);
+        S.cand_count = k.take<int>(RTVM_NLEVELS + RTVM_NLEVELS * 256);
+        S.sel_count = k.take<int>(RTVM_NLEVELS);
+        S.sel_lxy = k.take<int32_t>((size_t)c->orb_sel_total * 2);
+        S.sel_resp = k.take<float>(c->orb_sel_total);
+        S.feat.xy = k.take<float>((size_t)cap * 2);
+        S.feat.size = k.take<float>(cap);
+        S.feat.angle = k.take<float>(cap);
+        S.feat.response = k.take<float>(cap);
+        S.feat.octave = k.take<int32_t>(cap);
+        S.feat.lxy = k.take<int32_t>((size_t)cap * 2);
+        S.feat.desc = k.take<uint8_t>((size_t)cap * 32);
+        S.feat.count = k.take<int>(4);
+    }
+    S.qkey = k.take<uint32_t>(cap);
+    S.tkey = k.take<uint32_t>(cap);
+    S.m_qidx = k.take<int32_t>(cap);
+    S.m_tidx = k.take<int32_t>(cap);
+    S.m_dist = k.take<int32_t>(cap);
+    S.m_count = k.take<int>(4);
+    S.rs_src = k.take<float>((size_t)cap * 2);
+    S.rs_dst = k.take<float>((size_t)cap * 2);
+    S.rs_count = k.take<int>(4);
+    S.rs_state = k.take<char>(rtvm_ransac_state_bytes());
+    S.rs_idx = k.take<int>(RTVM_RANSAC_MAX_ITERS * 4);
+    S.rs_good = k.take<int>(RTVM_RANSAC_MAX_ITERS);
+    S.rs_hypH = k.take<double>(RTVM_RANSAC_MAX_ITERS * 9);
+    S.rs_csrc = k.take<float>((size_t)cap * 2);
+    S.rs_cdst = k.take<float>((size_t)cap * 2);
+    S.rs_H = k.take<double>(16);
+    S.rs_mask = k.take<uint8_t>(cap);
+    S.rs_found = k.take<int>(4);
+}
+
+}  // namespace
+
+// Allocates the buffers of one frame slot (one device allocation) and publishes the
+// slot to the device copy of the slot array.
+int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int with_orb) {
+    FrameSlot& S = c->h_slots[slot];
+    memset(&S, 0, sizeof(S));
+    Carver dry{nullptr, 0};
+    carve_slot(c, dry, S, cap_kp, with_orb);
+    const size_t bytes = dry.off + 256;
+    void* arena = nullptr;
+    hipError_t e = hipMalloc(&arena, bytes);
+    if (e != hipSuccess) RTVM_FAIL(c, RTVM_E_NOMEM, "hipMalloc(%zu bytes) for frame slot %d failed: %s", bytes, slot, hipGetErrorString(e));
+    c->slot_arena[slot] = arena;
+    HIP_TRY(c, hipMemset(arena, 0, bytes));
+    Carver k{(char*)arena, 0};
+    memset(&S, 0, sizeof(S));
+    carve_slot(c, k, S, cap_kp, with_orb);
+    if (slot == RTVM_STAGE_SLOT) {  // host-buffer matcher: descriptors come from the staging buffers
+        S.feat.desc = c->d_mq;
+        S.feat.count = c->d_mcount;
+        S.prev.desc = c->d_mt;
+        S.prev.count = c->d_mcount + 1;
+    } else if (slot == 0) {
+        S.prev = c->feat_prev;
+    } else {
+        S.prev = c->h_slots[slot - 1].feat;
+    }
+    HIP_TRY(c, hipMemcpy(&c->d_slots[slot], &S, sizeof(FrameSlot), hipMemcpyHostToDevice));
+    return RTVM_OK;
+}
+
+namespace {
+
 int alloc_all(rtvm_ctx* c) {
-    // matcher
     const int mk = RTVM_MAX_MATCH;
+    int r;
+    HIP_TRY(c, hipHostMalloc(&c->h_pinned, 1 << 16, hipHostMallocDefault));
+    c->h_slots = (FrameSlot*)calloc(RTVM_MAX_BATCH + 1, sizeof(FrameSlot));
+    if (!c->h_slots) RTVM_FAIL(c, RTVM_E_NOMEM, "host allocation failed");
+    ALLOC(c, d_slots, RTVM_MAX_BATCH + 1);
+    // matcher staging
     ALLOC(c, d_mq, (size_t)mk * 32);
     ALLOC(c, d_mt, (size_t)mk * 32);
     ALLOC(c, d_mcount, 4);
-    ALLOC(c, d_qkey, mk);
-    ALLOC(c, d_tkey, mk);
-    ALLOC(c, d_m_qidx, mk);
-    ALLOC(c, d_m_tidx, mk);
-    ALLOC(c, d_m_dist, mk);
-    ALLOC(c, d_m_count, 4);
-    HIP_TRY(c, hipHostMalloc(&c->h_pinned, 1 << 16, hipHostMallocDefault));
     // frame staging
     const size_t f_px = (size_t)c->fh * c->fw;
     ALLOC(c, d_bgr, f_px * 3);
@@ -71,50 +155,13 @@ int alloc_all(rtvm_ctx* c) {
     ALLOC(c, d_wgt, n_px * 2);
     ALLOC(c, d_rb, n_px * 2);
     ALLOC(c, d_gk, 32);
-    ALLOC(c, d_H, 16);
+    ALLOC(c, d_H, RTVM_MAX_BATCH * 9 + 16);
     ALLOC(c, d_wp, 1);
     ALLOC(c, d_jobs, 3);
-    int r = rtvm_warp_setup(c);
-    if (r != RTVM_OK) return r;
-    // ORB
-    if (c->fh > 0 && c->fw > 0) {
-        if ((r = rtvm_orb_plan(c))) return r;
-        ALLOC(c, d_pyr, c->orb_pyr_bytes);
-        ALLOC(c, d_pyr_blur, c->orb_pyr_bytes);
-        ALLOC(c, d_score, c->orb_pyr_bytes);
-        ALLOC(c, d_xofs, c->orb_xtab_total + 1);
-        ALLOC(c, d_xw, c->orb_xtab_total + 1);
-        ALLOC(c, d_yofs, c->orb_ytab_total + 1);
-        ALLOC(c, d_yw, c->orb_ytab_total + 1);
-        ALLOC(c, d_cand, c->orb_cand_total);
-        ALLOC(c, d_cand_count, RTVM_NLEVELS + RTVM_NLEVELS * 256);
-        ALLOC(c, d_sel_count, RTVM_NLEVELS);
-        ALLOC(c, d_sel_lxy, (size_t)c->orb_sel_total * 2);
-        ALLOC(c, d_sel_resp, c->orb_sel_total);
-        for (int k = 0; k < 2; k++)
-            if ((r = alloc_feat(c, &c->feat[k], c->orb.max_kp))) return r;
-        if ((r = rtvm_orb_setup(c))) return r;
-    }
-    // stream state
-    ALLOC(c, d_state, 1);
-    ALLOC(c, d_wtab, 32);
-    ALLOC(c, d_skip, 4);
-    if ((r = rtvm_stream_setup(c))) return r;
-    // RANSAC
-    ALLOC(c, d_rs_src, (size_t)mk * 2);
-    ALLOC(c, d_rs_dst, (size_t)mk * 2);
-    ALLOC(c, d_rs_count, 4);
-    HIP_TRY(c, hipMalloc(&c->d_rs_state, rtvm_ransac_state_bytes()));
+    if ((r = rtvm_warp_setup(c))) return r;
+    // RANSAC constant table
     c->rs_raw_n = 32768;
     ALLOC(c, d_rs_raw, c->rs_raw_n);
-    ALLOC(c, d_rs_idx, RTVM_RANSAC_MAX_ITERS * 4);
-    ALLOC(c, d_rs_good, RTVM_RANSAC_MAX_ITERS);
-    ALLOC(c, d_rs_hypH, RTVM_RANSAC_MAX_ITERS * 9);
-    ALLOC(c, d_rs_csrc, (size_t)mk * 2);
-    ALLOC(c, d_rs_cdst, (size_t)mk * 2);
-    ALLOC(c, d_rs_H, 16);
-    ALLOC(c, d_rs_mask, mk);
-    ALLOC(c, d_rs_found, 4);
     {
         uint32_t* raw = new (std::nothrow) uint32_t[c->rs_raw_n];
         if (!raw) RTVM_FAIL(c, RTVM_E_NOMEM, "host allocation failed");
@@ -123,21 +170,38 @@ int alloc_all(rtvm_ctx* c) {
         delete[] raw;
         HIP_TRY(c, e);
     }
+    // stage slot (host-buffer matcher / RANSAC entry points)
+    if ((r = rtvm_slots_alloc(c, RTVM_STAGE_SLOT, mk, 0))) return r;
+    // ORB + stream
+    if (c->fh > 0 && c->fw > 0) {
+        if ((r = rtvm_orb_plan(c))) return r;
+        ALLOC(c, d_xofs, c->orb_xtab_total + 1);
+        ALLOC(c, d_xw, c->orb_xtab_total + 1);
+        ALLOC(c, d_yofs, c->orb_ytab_total + 1);
+        ALLOC(c, d_yw, c->orb_ytab_total + 1);
+        if ((r = alloc_feat(c, &c->feat_prev, c->orb.max_kp))) return r;
+        if ((r = rtvm_slots_alloc(c, 0, c->orb.max_kp, 1))) return r;
+        c->n_batch = 1;
+        if ((r = rtvm_orb_setup(c))) return r;
+    }
+    ALLOC(c, d_state, 1);
+    ALLOC(c, d_wtab, 32);
+    ALLOC(c, d_skip, RTVM_MAX_BATCH);
+    if ((r = rtvm_stream_setup(c))) return r;
     return RTVM_OK;
 }
 
 void free_all(rtvm_ctx* c) {
-    void* ptrs[] = {c->d_mq, c->d_mt, c->d_mcount, c->d_qkey, c->d_tkey, c->d_m_qidx, c->d_m_tidx,
-                    c->d_m_dist, c->d_m_count, c->d_bgr, c->d_canvas, c->d_warped, c->d_mask_new, c->d_mask_old,
-                    c->d_dt_s, c->d_dt_r, c->d_dt_f, c->d_dist, c->d_wgt, c->d_rb, c->d_gk, c->d_H, c->d_wp,
-                    c->d_jobs, c->d_rs_src, c->d_rs_dst, c->d_rs_count, c->d_rs_state, c->d_rs_raw, c->d_rs_idx,
-                    c->d_rs_good, c->d_rs_hypH, c->d_rs_csrc, c->d_rs_cdst, c->d_rs_H, c->d_rs_mask, c->d_rs_found,
-                    c->d_pyr, c->d_pyr_blur, c->d_score, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_cand,
-                    c->d_cand_count, c->d_sel_count, c->d_sel_lxy, c->d_sel_resp, c->d_state, c->d_wtab, c->d_skip};
-    free_feat(&c->feat[0]);
-    free_feat(&c->feat[1]);
+    void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas, c->d_warped, c->d_mask_new,
+                    c->d_mask_old, c->d_dt_s, c->d_dt_r, c->d_dt_f, c->d_dist, c->d_wgt, c->d_rb, c->d_gk, c->d_H,
+                    c->d_wp, c->d_jobs, c->d_rs_raw, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
+                    c->d_skip};
+    free_feat(&c->feat_prev);
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (int i = 0; i <= RTVM_MAX_BATCH; i++)
+        if (c->slot_arena[i]) (void)hipFree(c->slot_arena[i]);
+    free(c->h_slots);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
 }
 
@@ -206,23 +270,24 @@ static int match_hamming_host(rtvm_ctx* c, const uint8_t* q, int nq, const uint8
     if (nq > RTVM_MAX_MATCH || nt > RTVM_MAX_MATCH)
         RTVM_FAIL(c, RTVM_E_ARG, "match_hamming: at most %d descriptors per side", RTVM_MAX_MATCH);
     HIP_TRY(c, hipSetDevice(c->device));
+    const FrameSlot& S = c->h_slots[RTVM_STAGE_SLOT];
     int* hc = (int*)c->h_pinned;
     hc[0] = nq;
     hc[1] = nt;
     HIP_TRY(c, hipMemcpyAsync(c->d_mcount, hc, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
     if (nq) HIP_TRY(c, hipMemcpyAsync(c->d_mq, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
     if (nt) HIP_TRY(c, hipMemcpyAsync(c->d_mt, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
-    int r = rtvm_launch_hamming(c, c->d_mq, c->d_mt, c->d_mcount, c->d_mcount + 1, nq, nt, sorted);
+    int r = rtvm_launch_hamming(c, RTVM_STAGE_SLOT, 1, nq, nt, sorted);
     if (r != RTVM_OK) return r;
-    HIP_TRY(c, hipMemcpyAsync(hc + 2, c->d_m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hc + 2, S.m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const int m = hc[2];
     if (m < 0 || m > nq) RTVM_FAIL(c, RTVM_E_HIP, "match_hamming: device returned count %d", m);
     if (m) {
         if (!qidx || !tidx || !dist) RTVM_FAIL(c, RTVM_E_ARG, "match_hamming: null output");
-        HIP_TRY(c, hipMemcpyAsync(qidx, c->d_m_qidx, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(tidx, c->d_m_tidx, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(dist, c->d_m_dist, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(qidx, S.m_qidx, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(tidx, S.m_tidx, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(dist, S.m_dist, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     *m_out = m;
@@ -249,46 +314,39 @@ static int need_frame(rtvm_ctx* c, const char* who) {
     return RTVM_OK;
 }
 
+int rtvm_orb_host(rtvm_ctx* c, const uint8_t* bgr, int* n_out, float* xy, float* size, float* angle_deg,
+                  float* response, int32_t* octave, uint8_t* desc, uint8_t* gray);  // stream.hip
+
 extern "C" int rtvm_orb(rtvm_ctx* c, const uint8_t* bgr, int* n_out, float* xy, float* size, float* angle_deg,
                         float* response, int32_t* octave, uint8_t* desc) {
     if (!c) return RTVM_E_ARG;
     if (!bgr || !n_out) RTVM_FAIL(c, RTVM_E_ARG, "orb: null argument");
     int r = need_frame(c, "orb");
     if (r) return r;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
-    if ((r = rtvm_launch_orb(c, c->d_bgr, 0))) return r;
-    int* hc = (int*)c->h_pinned;
-    const FeatSet& F = c->feat[0];
-    HIP_TRY(c, hipMemcpyAsync(hc, F.count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const int n = hc[0];
-    if (n < 0 || n > c->orb.max_kp) RTVM_FAIL(c, RTVM_E_HIP, "orb: device returned count %d", n);
-    if (n) {
-        if (xy) HIP_TRY(c, hipMemcpyAsync(xy, F.xy, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-        if (size) HIP_TRY(c, hipMemcpyAsync(size, F.size, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-        if (angle_deg) HIP_TRY(c, hipMemcpyAsync(angle_deg, F.angle, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-        if (response) HIP_TRY(c, hipMemcpyAsync(response, F.response, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-        if (octave) HIP_TRY(c, hipMemcpyAsync(octave, F.octave, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-        if (desc) HIP_TRY(c, hipMemcpyAsync(desc, F.desc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    *n_out = n;
-    return RTVM_OK;
+    return rtvm_orb_host(c, bgr, n_out, xy, size, angle_deg, response, octave, desc, nullptr);
 }
 
-// gray = level 0 of the pyramid of the most recent frame; rtvm_gray runs the ORB front end
+// gray = level 0 of the pyramid; rtvm_gray runs the ORB front end and copies it out
 extern "C" int rtvm_gray(rtvm_ctx* c, const uint8_t* bgr, uint8_t* gray) {
     if (!c) return RTVM_E_ARG;
     if (!bgr || !gray) RTVM_FAIL(c, RTVM_E_ARG, "gray: null argument");
     int r = need_frame(c, "gray");
     if (r) return r;
+    int n = 0;
+    return rtvm_orb_host(c, bgr, &n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gray);
+}
+
+extern "C" int rtvm_reserve_batch(rtvm_ctx* c, int n) {
+    if (!c) return RTVM_E_ARG;
+    if (n < 1 || n > RTVM_MAX_BATCH) RTVM_FAIL(c, RTVM_E_ARG, "reserve_batch: batch size must be 1..%d", RTVM_MAX_BATCH);
+    int r = need_frame(c, "reserve_batch");
+    if (r) return r;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
-    if ((r = rtvm_launch_orb(c, c->d_bgr, 0))) return r;
-    HIP_TRY(c, hipMemcpy2DAsync(gray, c->fw, c->d_pyr + c->orb.off[0], c->orb.pitch[0], c->fw, c->fh,
-                                hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int s = c->n_batch; s < n; s++) {
+        if ((r = rtvm_slots_alloc(c, s, c->orb.max_kp, 1))) return r;
+        c->n_batch = s + 1;
+    }
     return RTVM_OK;
 }
 
@@ -301,20 +359,20 @@ extern "C" int rtvm_find_homography_ransac(rtvm_ctx* c, const float* src_xy, con
         RTVM_FAIL(c, RTVM_E_ARG, "find_homography: bad argument");
     if (m > RTVM_MAX_MATCH) RTVM_FAIL(c, RTVM_E_ARG, "find_homography: at most %d point pairs", RTVM_MAX_MATCH);
     HIP_TRY(c, hipSetDevice(c->device));
+    const FrameSlot& S = c->h_slots[RTVM_STAGE_SLOT];
     int* hc = (int*)c->h_pinned;
     hc[0] = m;
-    HIP_TRY(c, hipMemcpyAsync(c->d_rs_count, hc, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(S.rs_count, hc, sizeof(int), hipMemcpyHostToDevice, c->stream));
     if (m) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_rs_src, src_xy, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->d_rs_dst, dst_xy, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(S.rs_src, src_xy, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(S.rs_dst, dst_xy, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
     }
-    int r = rtvm_launch_ransac(c, c->d_rs_src, c->d_rs_dst, c->d_rs_count, thresh, max_iters, confidence,
-                               c->d_rs_H, c->d_rs_mask, c->d_rs_found);
+    int r = rtvm_launch_ransac(c, RTVM_STAGE_SLOT, 1, thresh, max_iters, confidence);
     if (r) return r;
     double* hH = (double*)c->h_pinned + 8;
-    HIP_TRY(c, hipMemcpyAsync(hH, c->d_rs_H, 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(hc + 1, c->d_rs_found, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (inlier_mask && m) HIP_TRY(c, hipMemcpyAsync(inlier_mask, c->d_rs_mask, (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hH, S.rs_H, 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hc + 1, S.rs_found, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (inlier_mask && m) HIP_TRY(c, hipMemcpyAsync(inlier_mask, S.rs_mask, (size_t)m, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *found = hc[1];
     memcpy(H, hH, 9 * sizeof(double));

@@ -40,6 +40,46 @@ struct FeatSet {
     int* count;        // 1
 };
 
+// Everything the front half of process_frame (detect, match, RANSAC) needs for one
+// in-flight frame.  A batch of frames uses slots 0..n-1 and every front-half kernel
+// takes the slot array plus a batch index in its grid, so one launch serves the
+// whole batch.  slot[0].prev is the persistent "previous frame" feature set,
+// slot[j].prev aliases slot[j-1].feat.
+struct FrameSlot {
+    const uint8_t* bgr;    // frame pixels (device)
+    uint8_t* pyr;          // pyramid (un-blurred)
+    uint8_t* pyr_blur;     // pyramid after the 7x7 blur
+    uint8_t* score;        // FAST score planes, same layout
+    uint32_t* cand;        // candidates: packed (score << 24 | y << 12 | x)
+    int* cand_count;       // RTVM_NLEVELS counters + RTVM_NLEVELS*256 histogram
+    int* sel_count;        // per-level selected counts
+    int32_t* sel_lxy;      // per-level selected (x,y)
+    float* sel_resp;       // per-level selected Harris response
+    FeatSet feat;          // features of this frame (query side)
+    FeatSet prev;          // features it is matched against (train side)
+    uint32_t* qkey;        // packed (dist << 16 | idx) per query
+    uint32_t* tkey;        // per train
+    int32_t* m_qidx;       // matches
+    int32_t* m_tidx;
+    int32_t* m_dist;
+    int* m_count;
+    float* rs_src;         // matched points, current frame
+    float* rs_dst;         // matched points, previous frame
+    int* rs_count;
+    void* rs_state;        // RsState (ransac.hip)
+    int* rs_idx;           // 4 indices per iteration
+    int* rs_good;          // inlier count per iteration
+    double* rs_hypH;       // 9 doubles per iteration
+    float* rs_csrc;        // compacted inliers
+    float* rs_cdst;
+    double* rs_H;          // 9 doubles
+    uint8_t* rs_mask;
+    int* rs_found;
+};
+
+#define RTVM_MAX_BATCH 32
+#define RTVM_STAGE_SLOT RTVM_MAX_BATCH   // slot used by the host-buffer matcher / RANSAC entry points
+
 // One distance-transform job: a rectangle of a mask plane and the planes the
 // scans write (all indexed y*pitch + x like the mask).
 struct DtJob {
@@ -74,8 +114,14 @@ struct StreamState {
     int n_matches;
     int n_kp;
     int frame_index;
-    int pad;
+    int abort;         // a frame in the middle of a batch was skipped: later frames stay pending
+    int n_done;        // frames of the last batch that were consumed (stitched or skipped)
+    int last_good;     // batch index of the last frame that advanced the state, -1 if none
+    int b_status[RTVM_MAX_BATCH];
+    int b_matches[RTVM_MAX_BATCH];
+    int b_kp[RTVM_MAX_BATCH];
 };
+
 
 struct rtvm_ctx {
     int device;
@@ -89,30 +135,21 @@ struct rtvm_ctx {
     size_t orb_pyr_bytes;
     int orb_cand_total, orb_sel_total, orb_xtab_total, orb_ytab_total;
     uint8_t* d_bgr;        // staging frame fh*fw*3
-    uint8_t* d_pyr;        // pyramid (un-blurred)
-    uint8_t* d_pyr_blur;   // pyramid after the 7x7 blur
-    uint8_t* d_score;      // FAST score planes, same layout as d_pyr
     uint16_t* d_xofs;      // resize tables
     uint16_t* d_xw;
     uint16_t* d_yofs;
     uint16_t* d_yw;
-    uint32_t* d_cand;      // candidates: packed (score << 24 | y << 12 | x)
-    int* d_cand_count;     // RTVM_NLEVELS counters + RTVM_NLEVELS*256 histogram
-    int* d_sel_count;      // per-level selected counts
-    int32_t* d_sel_lxy;    // per-level selected (x,y)
-    float* d_sel_resp;     // per-level selected harris response
-    FeatSet feat[2];
+    FrameSlot* h_slots;    // host mirror of d_slots (RTVM_MAX_BATCH + 1 entries)
+    FrameSlot* d_slots;
+    void* slot_arena[RTVM_MAX_BATCH + 1];  // one device allocation per slot
+    int n_batch;           // slots 0..n_batch-1 are allocated
+    FeatSet feat_prev;     // features of the previous (last accepted) frame
+    const uint8_t** h_bgr_ptrs;  // frame pointers of the batch being queued
 
-    // --- matcher ---
-    uint8_t* d_mq;         // staging descriptors for the stage API
+    // --- matcher staging for the host-buffer entry points ---
+    uint8_t* d_mq;
     uint8_t* d_mt;
     int* d_mcount;         // [nq, nt]
-    uint32_t* d_qkey;      // packed (dist<<16 | idx) per query
-    uint32_t* d_tkey;      // per train
-    int32_t* d_m_qidx;     // matches
-    int32_t* d_m_tidx;
-    int32_t* d_m_dist;
-    int* d_m_count;
     // L2 matcher
     float* d_lq;
     float* d_lt;
@@ -121,20 +158,8 @@ struct rtvm_ctx {
     size_t l_cap_q, l_cap_t;
 
     // --- RANSAC ---
-    float* d_rs_src;       // m*2 matched points (cur)
-    float* d_rs_dst;       // m*2 matched points (prev)
-    int* d_rs_count;
-    void* d_rs_state;      // RsState (ransac.hip)
     uint32_t* d_rs_raw;    // raw outputs of the fixed-seed RNG
     int rs_raw_n;
-    int* d_rs_idx;         // 4 indices per iteration
-    int* d_rs_good;        // inlier count per iteration
-    double* d_rs_hypH;     // 9 doubles per iteration
-    float* d_rs_csrc;      // compacted inliers
-    float* d_rs_cdst;
-    double* d_rs_H;        // 9 doubles
-    uint8_t* d_rs_mask;
-    int* d_rs_found;
 
     // --- canvas / warp / blend ---
     uint8_t* d_canvas;     // ch*cw*3
@@ -148,14 +173,14 @@ struct rtvm_ctx {
     float* d_wgt;          // blend weights [2][ch*cw]
     float* d_rb;           // row-blurred weights [2][ch*cw]
     float* d_gk;           // 31 Gaussian taps
-    double* d_H;           // 9 doubles: homography handed to the warp
+    double* d_H;           // RTVM_MAX_BATCH x 9 doubles: homographies handed to the warp
     WarpParams* d_wp;
     DtJob* d_jobs;         // [0] = new mask on the ROI, [1] = old mask on the canvas, [2] = stage API
     int canvas_ready;
 
     StreamState* d_state;
     double* d_wtab;        // smoothing weights, row n = linspace(0.5, 1, n) / sum
-    int* d_skip;           // 1 when the current frame was rejected
+    int* d_skip;           // RTVM_MAX_BATCH flags: 1 when the frame is not to be stitched
     int stream_ready;
     void* h_pinned;        // small pinned host buffer for read-backs
     int prof_mode;         // 0 off, 1 every kernel, 2 kernels whose name contains prof_filter
@@ -179,8 +204,7 @@ struct rtvm_ctx {
 
 // ---- launchers implemented by the stage files (all asynchronous on ctx->stream) ----
 // match.hip
-int rtvm_launch_hamming(rtvm_ctx* c, const uint8_t* dq, const uint8_t* dt, const int* d_nq,
-                        const int* d_nt, int cap_q, int cap_t, int sorted);
+int rtvm_launch_hamming(rtvm_ctx* c, int sb, int nb, int cap_q, int cap_t, int sorted);
 // dt.hip
 int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h);
 // warp.hip
@@ -191,14 +215,14 @@ int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H,
 // orb.hip
 int rtvm_orb_plan(rtvm_ctx* c);   // host-side geometry (before allocation)
 int rtvm_orb_setup(rtvm_ctx* c);  // uploads tables (after allocation)
-int rtvm_launch_orb(rtvm_ctx* c, const uint8_t* d_bgr, int slot);
+int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb);
 // stream.hip
 int rtvm_stream_setup(rtvm_ctx* c);
+int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int with_orb);  // api.hip
 // ransac.hip
 size_t rtvm_ransac_state_bytes();
 void rtvm_ransac_raw_table(uint32_t* raw, int n);
-int rtvm_launch_ransac(rtvm_ctx* c, const float* d_src, const float* d_dst, const int* d_count, double thresh,
-                       int max_iters, double confidence, double* d_H, uint8_t* d_mask, int* d_found);
+int rtvm_launch_ransac(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence);
 int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim,
                         int32_t* d_idx, float* d_dist);
 

@@ -16,14 +16,16 @@ namespace {
 // is merged across B chunks with one atomicMin on a packed (dist << 16 | index)
 // key, whose integer order is exactly "smaller distance first, then lower
 // index", i.e. OpenCV's first-minimum rule.
-// blockIdx.z = 0: A = query, B = train; 1: A = train, B = query.
-__global__ __launch_bounds__(64) void k_hamming_argmin(const uint8_t* __restrict__ q,
-                                                       const uint8_t* __restrict__ t,
-                                                       const int* __restrict__ nq_p,
-                                                       const int* __restrict__ nt_p,
-                                                       uint32_t* __restrict__ qkey,
-                                                       uint32_t* __restrict__ tkey) {
-    const int dir = blockIdx.z;
+// blockIdx.z = 2 * frame + direction; direction 0: A = query, B = train; 1: A = train, B = query.
+__global__ __launch_bounds__(64) void k_hamming_argmin(const FrameSlot* __restrict__ slots, int sb) {
+    const FrameSlot& S = slots[sb + (blockIdx.z >> 1)];
+    const uint8_t* __restrict__ q = S.feat.desc;
+    const uint8_t* __restrict__ t = S.prev.desc;
+    const int* __restrict__ nq_p = S.feat.count;
+    const int* __restrict__ nt_p = S.prev.count;
+    uint32_t* __restrict__ qkey = S.qkey;
+    uint32_t* __restrict__ tkey = S.tkey;
+    const int dir = blockIdx.z & 1;
     const uint8_t* A = dir ? t : q;
     const uint8_t* B = dir ? q : t;
     const int nA = dir ? *nt_p : *nq_p;
@@ -56,22 +58,27 @@ __global__ __launch_bounds__(64) void k_hamming_argmin(const uint8_t* __restrict
     if (a0 + lane < nA) atomicMin(&key[a0 + lane], best);
 }
 
-__global__ void k_fill_u32(uint32_t* p, uint32_t v, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+// Nearest-neighbour keys start at "no neighbour" for both directions.
+__global__ __launch_bounds__(256) void k_match_init(const FrameSlot* __restrict__ slots, int sb, int cap_q, int cap_t) {
+    const FrameSlot& S = slots[sb + blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < cap_q) S.qkey[i] = 0xFFFFFFFFu;
+    if (i < cap_t) S.tkey[i] = 0xFFFFFFFFu;
 }
 
 // Single workgroup: mutual-NN filter, order-preserving compaction (ascending
 // query index) and, when sorted != 0, a bitonic sort of (dist << 16 | position)
 // keys, which is the stable sort by distance of main.py:698.
-__global__ __launch_bounds__(1024) void k_xcheck_compact(const uint32_t* __restrict__ qkey,
-                                                         const uint32_t* __restrict__ tkey,
-                                                         const int* __restrict__ nq_p,
-                                                         const int* __restrict__ nt_p,
-                                                         int32_t* __restrict__ m_qidx,
-                                                         int32_t* __restrict__ m_tidx,
-                                                         int32_t* __restrict__ m_dist,
-                                                         int* __restrict__ m_count, int sorted) {
+__global__ __launch_bounds__(1024) void k_xcheck_compact(const FrameSlot* __restrict__ slots, int sb, int sorted) {
+    const FrameSlot& S = slots[sb + blockIdx.x];
+    const uint32_t* __restrict__ qkey = S.qkey;
+    const uint32_t* __restrict__ tkey = S.tkey;
+    const int* __restrict__ nq_p = S.feat.count;
+    const int* __restrict__ nt_p = S.prev.count;
+    int32_t* __restrict__ m_qidx = S.m_qidx;
+    int32_t* __restrict__ m_tidx = S.m_tidx;
+    int32_t* __restrict__ m_dist = S.m_dist;
+    int* __restrict__ m_count = S.m_count;
     __shared__ uint32_t s_key[RTVM_MAX_MATCH];  // (dist << 16 | position)
     __shared__ uint16_t s_q[RTVM_MAX_MATCH];
     __shared__ int s_wave[16];
@@ -145,24 +152,18 @@ __global__ __launch_bounds__(1024) void k_xcheck_compact(const uint32_t* __restr
 
 }  // namespace
 
-// dq/dt: device descriptors; d_nq/d_nt: device counts; cap_q/cap_t: upper bounds
-// of the counts (grid sizing).  Results land in c->d_m_* / c->d_m_count.
-int rtvm_launch_hamming(rtvm_ctx* c, const uint8_t* dq, const uint8_t* dt, const int* d_nq,
-                        const int* d_nt, int cap_q, int cap_t, int sorted) {
+// Matches slot.feat (query) against slot.prev (train) for slots sb .. sb+nb-1; cap_q /
+// cap_t bound the descriptor counts (grid sizing).  Results land in slot.m_*.
+int rtvm_launch_hamming(rtvm_ctx* c, int sb, int nb, int cap_q, int cap_t, int sorted) {
     if (cap_q > RTVM_MAX_MATCH || cap_t > RTVM_MAX_MATCH)
         RTVM_FAIL(c, RTVM_E_ARG, "hamming matcher: at most %d descriptors per side", RTVM_MAX_MATCH);
     const int nfill = cap_q > cap_t ? cap_q : cap_t;
     if (nfill > 0) {
-        RTVM_LAUNCH(c, k_fill_u32, dim3((nfill + 255) / 256), dim3(256), 0, c->d_qkey,
-                           0xFFFFFFFFu, cap_q);
-        RTVM_LAUNCH(c, k_fill_u32, dim3((nfill + 255) / 256), dim3(256), 0, c->d_tkey,
-                           0xFFFFFFFFu, cap_t);
+        RTVM_LAUNCH(c, k_match_init, dim3((nfill + 255) / 256, nb), dim3(256), 0, c->d_slots, sb, cap_q, cap_t);
         const int tiles = (nfill + 63) / 64;
-        RTVM_LAUNCH(c, k_hamming_argmin, dim3(tiles, tiles, 2), dim3(64), 0, dq, dt, d_nq,
-                           d_nt, c->d_qkey, c->d_tkey);
+        RTVM_LAUNCH(c, k_hamming_argmin, dim3(tiles, tiles, 2 * nb), dim3(64), 0, c->d_slots, sb);
     }
-    RTVM_LAUNCH(c, k_xcheck_compact, dim3(1), dim3(1024), 0, c->d_qkey, c->d_tkey, d_nq,
-                       d_nt, c->d_m_qidx, c->d_m_tidx, c->d_m_dist, c->d_m_count, sorted);
+    RTVM_LAUNCH(c, k_xcheck_compact, dim3(nb), dim3(1024), 0, c->d_slots, sb, sorted);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }

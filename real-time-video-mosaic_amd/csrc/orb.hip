@@ -37,8 +37,14 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 }
 
 // ------------------------------------------------------------------ gray / pyramid
-__global__ __launch_bounds__(256) void k_gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ out, int w, int h,
+// Also clears the slot's candidate counters and score histograms for the FAST stage.
+__global__ __launch_bounds__(256) void k_gray(const FrameSlot* __restrict__ slots, int sb, unsigned off0, int w, int h,
                                               int pitch) {
+    const FrameSlot& S = slots[sb + blockIdx.z];
+    const uint8_t* __restrict__ bgr = S.bgr;
+    uint8_t* __restrict__ out = S.pyr + off0;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < RTVM_NLEVELS + RTVM_NLEVELS * 256; i += 256) S.cand_count[i] = 0;
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const uint8_t* p = bgr + ((size_t)y * w + x) * 3;
@@ -46,10 +52,13 @@ __global__ __launch_bounds__(256) void k_gray(const uint8_t* __restrict__ bgr, u
 }
 
 // INTER_LINEAR_EXACT: 8.8 coefficients (xw/yw = weight of the second tap, 0xFFFF = clamped single tap)
-__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int sp, uint8_t* __restrict__ dst,
-                                                int dw, int dh, int dp, const uint16_t* __restrict__ xofs,
-                                                const uint16_t* __restrict__ xw, const uint16_t* __restrict__ yofs,
-                                                const uint16_t* __restrict__ yw) {
+__global__ __launch_bounds__(256) void k_resize(const FrameSlot* __restrict__ slots, int sb, unsigned soff, int sp,
+                                                unsigned doff, int dw, int dh, int dp,
+                                                const uint16_t* __restrict__ xofs, const uint16_t* __restrict__ xw,
+                                                const uint16_t* __restrict__ yofs, const uint16_t* __restrict__ yw) {
+    const FrameSlot& S = slots[sb + blockIdx.z];
+    const uint8_t* __restrict__ src = S.pyr + soff;
+    uint8_t* __restrict__ dst = S.pyr + doff;
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= dw || y >= dh) return;
     const int xo = xofs[x], yo = yofs[y];
@@ -90,8 +99,10 @@ __device__ __forceinline__ int tile_level(const OrbDev& P, int tile, int* local)
 // minus 1; 0 when no arc clears the threshold.  Scores are produced for the pixels
 // [30, W-30) x [30, H-30) of every level: the keypoints that survive the 31-pixel
 // border plus their 3x3 neighbourhood.
-__global__ __launch_bounds__(256) void k_fast_score(OrbDev P, const uint8_t* __restrict__ pyr,
-                                                    uint8_t* __restrict__ score) {
+__global__ __launch_bounds__(256) void k_fast_score(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
+    const FrameSlot& S = slots[sb + blockIdx.y];
+    const uint8_t* __restrict__ pyr = S.pyr;
+    uint8_t* __restrict__ score = S.score;
     int local;
     const int l = tile_level(P, blockIdx.x, &local);
     const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
@@ -166,9 +177,12 @@ __global__ __launch_bounds__(256) void k_fast_score(OrbDev P, const uint8_t* __r
 // Keeps a scored pixel iff it beats its 8 neighbours strictly and lies at least
 // 31 pixels inside the level; appends (score << 24 | y << 12 | x) to the level's
 // candidate list (one atomic per wave) and counts the score in the level's histogram.
-__global__ __launch_bounds__(256) void k_fast_nms(OrbDev P, const uint8_t* __restrict__ score,
-                                                  uint32_t* __restrict__ cand, int* __restrict__ cand_count,
-                                                  int* __restrict__ hist) {
+__global__ __launch_bounds__(256) void k_fast_nms(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
+    const FrameSlot& SL = slots[sb + blockIdx.y];
+    const uint8_t* __restrict__ score = SL.score;
+    uint32_t* __restrict__ cand = SL.cand;
+    int* __restrict__ cand_count = SL.cand_count;
+    int* __restrict__ hist = SL.cand_count + RTVM_NLEVELS;
     int local;
     const int l = tile_level(P, blockIdx.x, &local);
     const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
@@ -228,11 +242,15 @@ __device__ float harris_response(const uint8_t* __restrict__ img, int pitch, int
 // One workgroup per level.  KeyPointsFilter::retainBest keeps everything whose
 // response is >= the n-th largest; a point is kept iff fewer than n points have a
 // strictly larger response.  Survivors keep row-major order.
-__global__ __launch_bounds__(1024) void k_orb_select(OrbDev P, const uint8_t* __restrict__ pyr,
-                                                     const uint32_t* __restrict__ cand,
-                                                     const int* __restrict__ cand_count, const int* __restrict__ hist,
-                                                     int* __restrict__ sel_count, int32_t* __restrict__ sel_lxy,
-                                                     float* __restrict__ sel_resp) {
+__global__ __launch_bounds__(1024) void k_orb_select(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
+    const FrameSlot& SL = slots[sb + blockIdx.y];
+    const uint8_t* __restrict__ pyr = SL.pyr;
+    const uint32_t* __restrict__ cand = SL.cand;
+    const int* __restrict__ cand_count = SL.cand_count;
+    const int* __restrict__ hist = SL.cand_count + RTVM_NLEVELS;
+    int* __restrict__ sel_count = SL.sel_count;
+    int32_t* __restrict__ sel_lxy = SL.sel_lxy;
+    float* __restrict__ sel_resp = SL.sel_resp;
     const int l = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ uint32_t s_key[SEL_CAP];
@@ -348,7 +366,10 @@ __global__ __launch_bounds__(1024) void k_orb_select(OrbDev P, const uint8_t* __
 // ------------------------------------------------------------------ blur
 // GaussianBlur(7x7, sigma 2) as ORB runs it on each level: integer taps
 // cvRound(k * 256), exact row and column sums, round half to even, saturate.
-__global__ __launch_bounds__(256) void k_blur7(OrbDev P, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_blur7(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
+    const FrameSlot& SL = slots[sb + blockIdx.y];
+    const uint8_t* __restrict__ pyr = SL.pyr;
+    uint8_t* __restrict__ out = SL.pyr_blur;
     int local;
     int l = 0;
 #pragma unroll
@@ -414,11 +435,14 @@ __device__ float fast_atan2(float y, float x) {
 // One wave per output keypoint: orientation by intensity centroid on the level
 // image (31 lanes sum one row of the disc each), then the 256 steered BRIEF tests
 // on the blurred level (4 per lane, packed through ballot-free shuffles).
-__global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const uint8_t* __restrict__ pyr,
-                                                     const uint8_t* __restrict__ blur,
-                                                     const int* __restrict__ sel_count,
-                                                     const int32_t* __restrict__ sel_lxy,
-                                                     const float* __restrict__ sel_resp, FeatSet F) {
+__global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
+    const FrameSlot& SL = slots[sb + blockIdx.y];
+    const uint8_t* __restrict__ pyr = SL.pyr;
+    const uint8_t* __restrict__ blur = SL.pyr_blur;
+    const int* __restrict__ sel_count = SL.sel_count;
+    const int32_t* __restrict__ sel_lxy = SL.sel_lxy;
+    const float* __restrict__ sel_resp = SL.sel_resp;
+    const FeatSet F = SL.feat;
     const int slot = blockIdx.x, lane = threadIdx.x;
     int l = -1, idx = 0, total = 0;
 #pragma unroll
@@ -602,33 +626,26 @@ int rtvm_orb_setup(rtvm_ctx* c) {
     HIP_TRY(c, hipMemcpy(c->d_xw, xw.data(), xw.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_yofs, yo.data(), yo.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_yw, yw.data(), yw.size() * 2, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->d_score, 0, c->orb_pyr_bytes));
     return RTVM_OK;
 }
 
-// Queues detectAndCompute of the device-resident BGR frame into feature slot `slot`.
-int rtvm_launch_orb(rtvm_ctx* c, const uint8_t* d_bgr, int slot) {
+// Queues detectAndCompute for the frames of slots sb .. sb+nb-1 (slot.bgr -> slot.feat).
+int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
     const OrbDev& P = c->orb;
-    HIP_TRY(c, hipMemsetAsync(c->d_cand_count, 0, (RTVM_NLEVELS + RTVM_NLEVELS * 256) * sizeof(int), c->stream));
-    RTVM_LAUNCH(c, k_gray, dim3((P.w[0] + 255) / 256, P.h[0]), dim3(256), 0, d_bgr, c->d_pyr + P.off[0],
-                       P.w[0], P.h[0], P.pitch[0]);
+    const FrameSlot* sl = c->d_slots;
+    RTVM_LAUNCH(c, k_gray, dim3((P.w[0] + 255) / 256, P.h[0], nb), dim3(256), 0, sl, sb, P.off[0], P.w[0], P.h[0],
+                P.pitch[0]);
     for (int l = 1; l < RTVM_NLEVELS; l++)
-        RTVM_LAUNCH(c, k_resize, dim3((P.w[l] + 255) / 256, P.h[l]), dim3(256), 0,
-                           c->d_pyr + P.off[l - 1], P.pitch[l - 1], c->d_pyr + P.off[l], P.w[l], P.h[l], P.pitch[l],
-                           c->d_xofs + P.xtab_off[l], c->d_xw + P.xtab_off[l], c->d_yofs + P.ytab_off[l],
-                           c->d_yw + P.ytab_off[l]);
-    int* hist = c->d_cand_count + RTVM_NLEVELS;
+        RTVM_LAUNCH(c, k_resize, dim3((P.w[l] + 255) / 256, P.h[l], nb), dim3(256), 0, sl, sb, P.off[l - 1],
+                    P.pitch[l - 1], P.off[l], P.w[l], P.h[l], P.pitch[l], c->d_xofs + P.xtab_off[l],
+                    c->d_xw + P.xtab_off[l], c->d_yofs + P.ytab_off[l], c->d_yw + P.ytab_off[l]);
     if (P.tile_off[RTVM_NLEVELS] > 0) {
-        RTVM_LAUNCH(c, k_fast_score, dim3(P.tile_off[RTVM_NLEVELS]), dim3(256), 0, P, c->d_pyr,
-                           c->d_score);
-        RTVM_LAUNCH(c, k_fast_nms, dim3(P.tile_off[RTVM_NLEVELS]), dim3(256), 0, P, c->d_score,
-                           c->d_cand, c->d_cand_count, hist);
+        RTVM_LAUNCH(c, k_fast_score, dim3(P.tile_off[RTVM_NLEVELS], nb), dim3(256), 0, P, sl, sb);
+        RTVM_LAUNCH(c, k_fast_nms, dim3(P.tile_off[RTVM_NLEVELS], nb), dim3(256), 0, P, sl, sb);
     }
-    RTVM_LAUNCH(c, k_orb_select, dim3(RTVM_NLEVELS), dim3(1024), 0, P, c->d_pyr, c->d_cand,
-                       c->d_cand_count, hist, c->d_sel_count, c->d_sel_lxy, c->d_sel_resp);
-    RTVM_LAUNCH(c, k_blur7, dim3(P.btile_off[RTVM_NLEVELS]), dim3(256), 0, P, c->d_pyr, c->d_pyr_blur);
-    RTVM_LAUNCH(c, k_orb_describe, dim3(P.max_kp), dim3(64), 0, P, c->d_pyr, c->d_pyr_blur,
-                       c->d_sel_count, c->d_sel_lxy, c->d_sel_resp, c->feat[slot]);
+    RTVM_LAUNCH(c, k_orb_select, dim3(RTVM_NLEVELS, nb), dim3(1024), 0, P, sl, sb);
+    RTVM_LAUNCH(c, k_blur7, dim3(P.btile_off[RTVM_NLEVELS], nb), dim3(256), 0, P, sl, sb);
+    RTVM_LAUNCH(c, k_orb_describe, dim3(P.max_kp, nb), dim3(64), 0, P, sl, sb);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }

@@ -357,10 +357,15 @@ __device__ int sim_subset(const float* __restrict__ src, const float* __restrict
 // Subsets of iterations [h0, h1) of one problem, 64 at a time: lane L guesses the
 // stream position of iteration h0+L, simulates it, the guesses are corrected by a
 // prefix sum of the consumed draws and the round repeats until nothing moves.
-__global__ __launch_bounds__(64) void k_rs_subsets(const float* __restrict__ src, const float* __restrict__ dst,
-                                                   const int* __restrict__ count_p, const uint32_t* __restrict__ raw,
-                                                   int raw_n, RsState* __restrict__ st, int* __restrict__ idx_out,
-                                                   int h0, int h1, double confidence, int max_iters, int first) {
+__global__ __launch_bounds__(64) void k_rs_subsets(const FrameSlot* __restrict__ slots, int sb,
+                                                   const uint32_t* __restrict__ raw, int raw_n, int h0, int h1,
+                                                   double confidence, int max_iters, int first) {
+    const FrameSlot& S = slots[sb + blockIdx.x];
+    const float* __restrict__ src = S.rs_src;
+    const float* __restrict__ dst = S.rs_dst;
+    const int* __restrict__ count_p = S.rs_count;
+    RsState* __restrict__ st = (RsState*)S.rs_state;
+    int* __restrict__ idx_out = S.rs_idx;
     const int lane = threadIdx.x;
     const int count = *count_p;
     if (first && lane == 0) {
@@ -419,10 +424,16 @@ __global__ __launch_bounds__(64) void k_rs_subsets(const float* __restrict__ src
 }
 
 // One wave per hypothesis: solve the 4-point homography, count the inliers.
-__global__ __launch_bounds__(64) void k_rs_hyp(const float* __restrict__ src, const float* __restrict__ dst,
-                                               const int* __restrict__ count_p, const RsState* __restrict__ st,
-                                               const int* __restrict__ idx, int* __restrict__ good,
-                                               double* __restrict__ hypH, int h0, int h1, float thr) {
+__global__ __launch_bounds__(64) void k_rs_hyp(const FrameSlot* __restrict__ slots, int sb, int h0, int h1,
+                                               float thr) {
+    const FrameSlot& S = slots[sb + blockIdx.y];
+    const float* __restrict__ src = S.rs_src;
+    const float* __restrict__ dst = S.rs_dst;
+    const int* __restrict__ count_p = S.rs_count;
+    const RsState* __restrict__ st = (const RsState*)S.rs_state;
+    const int* __restrict__ idx = S.rs_idx;
+    int* __restrict__ good = S.rs_good;
+    double* __restrict__ hypH = S.rs_hypH;
     const int h = h0 + blockIdx.x;
     const int count = *count_p;
     if (h >= h1 || count <= 4 || st->done) return;
@@ -472,9 +483,13 @@ __device__ int update_num_iters(double p, double ep, int modelPoints, int maxIte
 
 // The sequential keep/stop rule of RANSACPointSetRegistrator::run over the inlier
 // counts of iterations [h0, h1).
-__global__ void k_rs_replay(const int* __restrict__ count_p, RsState* __restrict__ st, const int* __restrict__ good,
-                            int h0, int h1, double confidence, int last) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void k_rs_replay(const FrameSlot* __restrict__ slots, int sb, int h0, int h1, double confidence,
+                            int last) {
+    if (threadIdx.x != 0) return;
+    const FrameSlot& S = slots[sb + blockIdx.x];
+    const int* __restrict__ count_p = S.rs_count;
+    RsState* __restrict__ st = (RsState*)S.rs_state;
+    const int* __restrict__ good = S.rs_good;
     const int count = *count_p;
     if (count <= 4 || st->done) return;
     int niters = st->niters, max_good = st->max_good, best = st->best;
@@ -603,11 +618,18 @@ __device__ __forceinline__ double dot8(const double* a, const double* b) {
 }
 
 // One wave per problem: the winner's inlier mask, runKernel on all inliers, LM polish.
-__global__ __launch_bounds__(64) void k_rs_refine(const float* __restrict__ src, const float* __restrict__ dst,
-                                                  const int* __restrict__ count_p, RsState* __restrict__ st,
-                                                  const double* __restrict__ hypH, float* __restrict__ csrc,
-                                                  float* __restrict__ cdst, double* __restrict__ outH,
-                                                  uint8_t* __restrict__ mask, int* __restrict__ found, float thr) {
+__global__ __launch_bounds__(64) void k_rs_refine(const FrameSlot* __restrict__ slots, int sb, float thr) {
+    const FrameSlot& SL = slots[sb + blockIdx.x];
+    const float* __restrict__ src = SL.rs_src;
+    const float* __restrict__ dst = SL.rs_dst;
+    const int* __restrict__ count_p = SL.rs_count;
+    RsState* __restrict__ st = (RsState*)SL.rs_state;
+    const double* __restrict__ hypH = SL.rs_hypH;
+    float* __restrict__ csrc = SL.rs_csrc;
+    float* __restrict__ cdst = SL.rs_cdst;
+    double* __restrict__ outH = SL.rs_H;
+    uint8_t* __restrict__ mask = SL.rs_mask;
+    int* __restrict__ found = SL.rs_found;
     __shared__ RefineLds S;
     const int lane = threadIdx.x;
     const int count = *count_p;
@@ -740,34 +762,27 @@ void rtvm_ransac_raw_table(uint32_t* raw, int n) {
     }
 }
 
-// Queues the whole of findHomography(RANSAC) for the point pairs in d_src/d_dst
-// (count read from device memory, at most cap points).  Results: d_H (9 doubles),
-// d_mask (count bytes), d_found.
-int rtvm_launch_ransac(rtvm_ctx* c, const float* d_src, const float* d_dst, const int* d_count, double thresh,
-                       int max_iters, double confidence, double* d_H, uint8_t* d_mask, int* d_found) {
+// Queues the whole of findHomography(RANSAC) for slots sb .. sb+nb-1: point pairs in
+// slot.rs_src / rs_dst (count in slot.rs_count); results in slot.rs_H (9 doubles),
+// slot.rs_mask (count bytes), slot.rs_found.
+int rtvm_launch_ransac(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence) {
     if (max_iters > RTVM_RANSAC_MAX_ITERS)
         RTVM_FAIL(c, RTVM_E_ARG, "findHomography: maxIters above %d is not supported", RTVM_RANSAC_MAX_ITERS);
     if (max_iters < 1) max_iters = 1;
     if (!(confidence > 0 && confidence < 1)) RTVM_FAIL(c, RTVM_E_ARG, "findHomography: confidence must be in (0,1)");
     const float thr = (float)(thresh * thresh);
-    RsState* st = (RsState*)c->d_rs_state;
+    const FrameSlot* sl = c->d_slots;
     const int b0 = max_iters < RS_BATCH0 ? max_iters : RS_BATCH0;
-    RTVM_LAUNCH(c, k_rs_subsets, dim3(1), dim3(64), 0, d_src, d_dst, d_count, c->d_rs_raw,
-                       c->rs_raw_n, st, c->d_rs_idx, 0, b0, confidence, max_iters, 1);
-    RTVM_LAUNCH(c, k_rs_hyp, dim3(b0), dim3(64), 0, d_src, d_dst, d_count, st, c->d_rs_idx,
-                       c->d_rs_good, c->d_rs_hypH, 0, b0, thr);
-    RTVM_LAUNCH(c, k_rs_replay, dim3(1), dim3(64), 0, d_count, st, c->d_rs_good, 0, b0, confidence,
-                       b0 >= max_iters ? 1 : 0);
+    RTVM_LAUNCH(c, k_rs_subsets, dim3(nb), dim3(64), 0, sl, sb, c->d_rs_raw, c->rs_raw_n, 0, b0, confidence, max_iters, 1);
+    RTVM_LAUNCH(c, k_rs_hyp, dim3(b0, nb), dim3(64), 0, sl, sb, 0, b0, thr);
+    RTVM_LAUNCH(c, k_rs_replay, dim3(nb), dim3(64), 0, sl, sb, 0, b0, confidence, b0 >= max_iters ? 1 : 0);
     if (b0 < max_iters) {
-        RTVM_LAUNCH(c, k_rs_subsets, dim3(1), dim3(64), 0, d_src, d_dst, d_count, c->d_rs_raw,
-                           c->rs_raw_n, st, c->d_rs_idx, b0, max_iters, confidence, max_iters, 0);
-        RTVM_LAUNCH(c, k_rs_hyp, dim3(max_iters - b0), dim3(64), 0, d_src, d_dst, d_count, st,
-                           c->d_rs_idx, c->d_rs_good, c->d_rs_hypH, b0, max_iters, thr);
-        RTVM_LAUNCH(c, k_rs_replay, dim3(1), dim3(64), 0, d_count, st, c->d_rs_good, b0, max_iters,
-                           confidence, 1);
+        RTVM_LAUNCH(c, k_rs_subsets, dim3(nb), dim3(64), 0, sl, sb, c->d_rs_raw, c->rs_raw_n, b0, max_iters, confidence,
+                    max_iters, 0);
+        RTVM_LAUNCH(c, k_rs_hyp, dim3(max_iters - b0, nb), dim3(64), 0, sl, sb, b0, max_iters, thr);
+        RTVM_LAUNCH(c, k_rs_replay, dim3(nb), dim3(64), 0, sl, sb, b0, max_iters, confidence, 1);
     }
-    RTVM_LAUNCH(c, k_rs_refine, dim3(1), dim3(64), 0, d_src, d_dst, d_count, st, c->d_rs_hypH,
-                       c->d_rs_csrc, c->d_rs_cdst, d_H, d_mask, d_found, thr);
+    RTVM_LAUNCH(c, k_rs_refine, dim3(nb), dim3(64), 0, sl, sb, thr);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }

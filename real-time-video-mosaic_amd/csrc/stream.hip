@@ -1,10 +1,19 @@
 // VideMosaic.process_frame (reference main.py:710-759) with every piece of state
 // resident on the device: features of the previous frame, H_old, the smoothing
-// history and the canvas.  One call queues ORB, matching, RANSAC, the
-// validate / smooth / chain arithmetic and the warp + blend on the context's
-// stream; the skip rules of the reference (fewer than 4 matches, no homography)
-// become a device-side flag that empties the warp's region of interest and
-// suppresses the state advance.
+// history and the canvas.
+//
+// Frames are processed in batches.  The front half of process_frame (detect,
+// match against the previous frame, RANSAC) of frame t depends only on frames t and
+// t-1, never on the canvas or on H_old, so it runs for a whole batch at once: every
+// front-half kernel is launched once with the batch index in its grid.  The back
+// half is sequential: one thread chains validate / smooth / H_old @ H for the batch
+// in frame order, then each frame is warped and blended into the canvas in turn.
+//
+// The reference does not advance its state on a skipped frame (fewer than 4 matches,
+// or no homography).  Inside a batch frame t+1 was matched against frame t on the
+// assumption that t would be accepted; when t is skipped in the middle of a batch,
+// the later frames of the batch are left untouched (RTVM_FRAME_PENDING) for the
+// caller to resubmit, so the result is the reference's for any batch size.
 #include "common.h"
 
 #include <cmath>
@@ -13,19 +22,17 @@ namespace {
 
 // points of the matches, in match order: src = current frame, dst = previous frame
 // (main.py:850-854)
-__global__ __launch_bounds__(256) void k_gather_pts(const int* __restrict__ m_count, const int32_t* __restrict__ qidx,
-                                                    const int32_t* __restrict__ tidx, const float* __restrict__ xy_cur,
-                                                    const float* __restrict__ xy_prev, float* __restrict__ src,
-                                                    float* __restrict__ dst, int* __restrict__ rs_count) {
-    const int m = *m_count;
+__global__ __launch_bounds__(256) void k_gather_pts(const FrameSlot* __restrict__ slots, int sb) {
+    const FrameSlot& S = slots[sb + blockIdx.y];
+    const int m = *S.m_count;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) *rs_count = m;
+    if (i == 0) *S.rs_count = m;
     if (i >= m) return;
-    const int q = qidx[i], t = tidx[i];
-    src[2 * i] = xy_cur[2 * q];
-    src[2 * i + 1] = xy_cur[2 * q + 1];
-    dst[2 * i] = xy_prev[2 * t];
-    dst[2 * i + 1] = xy_prev[2 * t + 1];
+    const int q = S.m_qidx[i], t = S.m_tidx[i];
+    S.rs_src[2 * i] = S.feat.xy[2 * q];
+    S.rs_src[2 * i + 1] = S.feat.xy[2 * q + 1];
+    S.rs_dst[2 * i] = S.prev.xy[2 * t];
+    S.rs_dst[2 * i + 1] = S.prev.xy[2 * t + 1];
 }
 
 // validate_homography (main.py:761-801).  The 2x2 determinant is evaluated the way
@@ -52,78 +59,91 @@ __device__ bool validate_h(const double* H, double trans_thr, double scale_thr) 
     return true;
 }
 
-// main.py:722-746 and 756: skip rules, validate, smooth (weighted mean of at most
-// five relative homographies), H = H_old @ H_smoothed, H_old = H.
-__global__ void k_frame_update(StreamState* __restrict__ st, const int* __restrict__ m_count,
-                               const int* __restrict__ found, const double* __restrict__ H_rel_in,
-                               const double* __restrict__ wtab, double* __restrict__ H_out, int* __restrict__ skip,
-                               const int* __restrict__ n_kp, double trans_thr, double scale_thr) {
+// main.py:722-746 and 756 for the n frames of a batch, in order: skip rules,
+// validate, smooth (weighted mean of at most five relative homographies),
+// H = H_old @ H_smoothed, H_old = H.  Writes the absolute homography and the
+// "do not stitch" flag of every frame.
+__global__ void k_batch_glue(const FrameSlot* __restrict__ slots, int sb, int n, StreamState* __restrict__ st,
+                             const double* __restrict__ wtab, double* __restrict__ H_out, int* __restrict__ skip,
+                             double trans_thr, double scale_thr) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    st->frame_index += 1;
-    const int m = *m_count;
-    st->n_matches = m;
-    st->n_kp = *n_kp;
-    if (m < 4) {
-        st->status = RTVM_FRAME_FEW_MATCHES;
-        *skip = 1;
-        return;
-    }
-    if (!*found) {
-        st->status = RTVM_FRAME_NO_HOMOGRAPHY;
-        *skip = 1;
-        return;
-    }
-    double Hr[9];
-    for (int i = 0; i < 9; i++) Hr[i] = H_rel_in[i];
-    int status = 0;
-    if (!validate_h(Hr, trans_thr, scale_thr)) {
-        for (int i = 0; i < 9; i++) Hr[i] = (i % 4 == 0) ? 1. : 0.;
-        status |= RTVM_FRAME_INVALID_H;
-    } else {
-        for (int i = 0; i < 9; i++) st->last_valid_H[i] = Hr[i];
-    }
-    // smooth_homography
-    int n = st->hist_len;
-    if (n == 5) {
-        for (int k = 0; k < 4; k++)
-            for (int i = 0; i < 9; i++) st->hist[k][i] = st->hist[k + 1][i];
-        n = 4;
-    }
-    for (int i = 0; i < 9; i++) st->hist[n][i] = Hr[i];
-    n++;
-    st->hist_len = n;
-    double Hs[9];
-    if (n < 2) {
-        for (int i = 0; i < 9; i++) Hs[i] = Hr[i];
-    } else {
-        for (int i = 0; i < 9; i++) {
-            double s = 0.;
-            for (int k = 0; k < n; k++) s += wtab[n * 5 + k] * st->hist[k][i];
-            Hs[i] = s;
+    int n_done = 0, last_good = -1;
+    bool abort = st->abort != 0;
+    for (int j = 0; j < n; j++) {
+        const FrameSlot& S = slots[sb + j];
+        skip[j] = 1;
+        if (abort) {
+            st->b_status[j] = RTVM_FRAME_PENDING;
+            st->b_matches[j] = 0;
+            st->b_kp[j] = 0;
+            continue;
         }
+        n_done = j + 1;
+        st->frame_index += 1;
+        const int m = *S.m_count;
+        st->n_matches = st->b_matches[j] = m;
+        st->n_kp = st->b_kp[j] = *S.feat.count;
+        int status = 0;
+        if (m < 4)
+            status = RTVM_FRAME_FEW_MATCHES;
+        else if (!*S.rs_found)
+            status = RTVM_FRAME_NO_HOMOGRAPHY;
+        if (status) {
+            st->status = st->b_status[j] = status;
+            if (j < n - 1) abort = true;  // the later frames were matched against this one
+            continue;
+        }
+        double Hr[9];
+        for (int i = 0; i < 9; i++) Hr[i] = S.rs_H[i];
+        if (!validate_h(Hr, trans_thr, scale_thr)) {
+            for (int i = 0; i < 9; i++) Hr[i] = (i % 4 == 0) ? 1. : 0.;
+            status |= RTVM_FRAME_INVALID_H;
+        } else {
+            for (int i = 0; i < 9; i++) st->last_valid_H[i] = Hr[i];
+        }
+        // smooth_homography
+        int k = st->hist_len;
+        if (k == 5) {
+            for (int a = 0; a < 4; a++)
+                for (int i = 0; i < 9; i++) st->hist[a][i] = st->hist[a + 1][i];
+            k = 4;
+        }
+        for (int i = 0; i < 9; i++) st->hist[k][i] = Hr[i];
+        k++;
+        st->hist_len = k;
+        double Hs[9];
+        if (k < 2) {
+            for (int i = 0; i < 9; i++) Hs[i] = Hr[i];
+        } else {
+            for (int i = 0; i < 9; i++) {
+                double s = 0.;
+                for (int a = 0; a < k; a++) s += wtab[k * 5 + a] * st->hist[a][i];
+                Hs[i] = s;
+            }
+        }
+        // self.H = np.matmul(self.H_old, H_relative_smoothed)
+        double H[9];
+        for (int r = 0; r < 3; r++)
+            for (int c2 = 0; c2 < 3; c2++)
+                H[r * 3 + c2] =
+                    (st->H_old[r * 3] * Hs[c2] + st->H_old[r * 3 + 1] * Hs[3 + c2]) + st->H_old[r * 3 + 2] * Hs[6 + c2];
+        for (int i = 0; i < 9; i++) {
+            st->H_abs[i] = H[i];
+            st->H_old[i] = H[i];
+            H_out[9 * j + i] = H[i];
+        }
+        st->status = st->b_status[j] = status;
+        skip[j] = 0;
+        last_good = j;
     }
-    // self.H = np.matmul(self.H_old, H_relative_smoothed)
-    double H[9];
-    for (int r = 0; r < 3; r++)
-        for (int c2 = 0; c2 < 3; c2++)
-            H[r * 3 + c2] = (st->H_old[r * 3] * Hs[c2] + st->H_old[r * 3 + 1] * Hs[3 + c2]) + st->H_old[r * 3 + 2] * Hs[6 + c2];
-    for (int i = 0; i < 9; i++) {
-        st->H_abs[i] = H[i];
-        st->H_old[i] = H[i];
-        H_out[i] = H[i];
-    }
-    st->status = status;
-    *skip = 0;
+    st->abort = abort ? 1 : 0;
+    st->n_done = n_done;
+    st->last_good = last_good;
 }
 
-// kp_prev, des_prev <- kp_cur, des_cur (main.py:757-758) unless the frame was skipped
-__global__ __launch_bounds__(256) void k_advance_feats(const int* __restrict__ skip, FeatSet cur, FeatSet prev,
-                                                       int max_kp) {
-    if (skip && *skip) return;
-    const int n = *cur.count;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void copy_feat(const FeatSet& cur, const FeatSet& prev, int i, int n) {
     if (i == 0) *prev.count = n;
-    if (i >= n || i >= max_kp) return;
+    if (i >= n) return;
     prev.xy[2 * i] = cur.xy[2 * i];
     prev.xy[2 * i + 1] = cur.xy[2 * i + 1];
     prev.size[i] = cur.size[i];
@@ -136,6 +156,19 @@ __global__ __launch_bounds__(256) void k_advance_feats(const int* __restrict__ s
     uint4* d = reinterpret_cast<uint4*>(prev.desc + (size_t)i * 32);
     d[0] = s[0];
     d[1] = s[1];
+}
+
+// kp_prev, des_prev <- features of the last frame of the batch that advanced the state
+// (main.py:757-758); which == -1 reads the index from the stream state, otherwise it is
+// the slot to copy.
+__global__ __launch_bounds__(256) void k_advance_feats(const FrameSlot* __restrict__ slots, int sb,
+                                                       const StreamState* __restrict__ st, int which, FeatSet prev,
+                                                       int max_kp) {
+    const int j = which >= 0 ? which : st->last_good;
+    if (j < 0) return;
+    const FeatSet cur = slots[sb + j].feat;
+    const int n = min(*cur.count, max_kp);
+    copy_feat(cur, prev, blockIdx.x * 256 + threadIdx.x, n);
 }
 
 __global__ void k_state_init(StreamState* st, int row_off, int col_off, int* skip) {
@@ -155,7 +188,10 @@ __global__ void k_state_init(StreamState* st, int row_off, int col_off, int* ski
     st->n_matches = 0;
     st->n_kp = 0;
     st->frame_index = 0;
-    *skip = 0;
+    st->abort = 0;
+    st->n_done = 0;
+    st->last_good = -1;
+    for (int j = 0; j < RTVM_MAX_BATCH; j++) skip[j] = 0;
 }
 
 int need_stream_ctx(rtvm_ctx* c, const char* who) {
@@ -165,28 +201,56 @@ int need_stream_ctx(rtvm_ctx* c, const char* who) {
     return RTVM_OK;
 }
 
-// detect + match against the previous frame + gather points + RANSAC, all queued
-int queue_front_half(rtvm_ctx* c, const uint8_t* d_bgr) {
+// Publishes the frame pointers of a batch to the device copies of the slots.
+int set_frame_ptrs(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
+    for (int j = 0; j < n; j++) {
+        if (!ptrs[j]) RTVM_FAIL(c, RTVM_E_ARG, "null frame pointer at batch index %d", j);
+        if (c->h_slots[j].bgr != ptrs[j]) {
+            c->h_slots[j].bgr = ptrs[j];
+            HIP_TRY(c, hipMemcpyAsync(&c->d_slots[j].bgr, &c->h_slots[j].bgr, sizeof(uint8_t*), hipMemcpyHostToDevice,
+                                      c->stream));
+        }
+    }
+    return RTVM_OK;
+}
+
+// detect + match against the previous frame + gather points + RANSAC for slots 0..n-1
+int queue_front_half(rtvm_ctx* c, int n) {
     int r;
-    if ((r = rtvm_launch_orb(c, d_bgr, 0))) return r;
+    if ((r = rtvm_launch_orb(c, 0, n))) return r;
     const int cap = c->orb.max_kp;
-    if ((r = rtvm_launch_hamming(c, c->feat[0].desc, c->feat[1].desc, c->feat[0].count, c->feat[1].count, cap, cap, 1)))
-        return r;
-    RTVM_LAUNCH(c, k_gather_pts, dim3((cap + 255) / 256), dim3(256), 0, c->d_m_count, c->d_m_qidx,
-                       c->d_m_tidx, c->feat[0].xy, c->feat[1].xy, c->d_rs_src, c->d_rs_dst, c->d_rs_count);
-    return rtvm_launch_ransac(c, c->d_rs_src, c->d_rs_dst, c->d_rs_count, 2.0, 2000, 0.995, c->d_rs_H, c->d_rs_mask,
-                              c->d_rs_found);
+    if ((r = rtvm_launch_hamming(c, 0, n, cap, cap, 1))) return r;
+    RTVM_LAUNCH(c, k_gather_pts, dim3((cap + 255) / 256, n), dim3(256), 0, c->d_slots, 0);
+    return rtvm_launch_ransac(c, 0, n, 2.0, 2000, 0.995);
 }
 
 int queue_first_frame(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_off) {
     int r;
-    if ((r = rtvm_launch_orb(c, d_bgr, 0))) return r;
-    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, (const int*)nullptr,
-                       c->feat[0], c->feat[1], c->orb.max_kp);
+    if ((r = set_frame_ptrs(c, &d_bgr, 1))) return r;
+    if ((r = rtvm_launch_orb(c, 0, 1))) return r;
+    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
+                c->feat_prev, c->orb.max_kp);
     if ((r = rtvm_launch_canvas_init(c, d_bgr, row_off, col_off))) return r;
     RTVM_LAUNCH(c, k_state_init, dim3(1), dim3(64), 0, c->d_state, row_off, col_off, c->d_skip);
     HIP_TRY(c, hipGetLastError());
     c->stream_ready = 1;
+    return RTVM_OK;
+}
+
+int queue_batch(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
+    int r;
+    if (n < 1 || n > c->n_batch)
+        RTVM_FAIL(c, RTVM_E_ARG, "batch of %d frames: reserve it first (rtvm_reserve_batch), at most %d", n,
+                  RTVM_MAX_BATCH);
+    if ((r = set_frame_ptrs(c, ptrs, n))) return r;
+    if ((r = queue_front_half(c, n))) return r;
+    RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, 0, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
+                50.0, 0.3);
+    for (int j = 0; j < n; j++)
+        if ((r = rtvm_launch_warp_blend(c, ptrs[j], c->d_H + 9 * j, c->d_skip + j))) return r;
+    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, -1,
+                c->feat_prev, c->orb.max_kp);
+    HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
 
@@ -231,18 +295,47 @@ extern "C" int rtvm_first_frame(rtvm_ctx* c, const uint8_t* bgr, int row_off, in
 
 extern "C" int rtvm_process_frame(rtvm_ctx* c, const uint8_t* bgr_dev) {
     if (!c) return RTVM_E_ARG;
-    if (!bgr_dev) RTVM_FAIL(c, RTVM_E_ARG, "process_frame: null frame");
     int r = need_stream_ctx(c, "process_frame");
     if (r) return r;
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "process_frame: call rtvm_stream_begin first");
     HIP_TRY(c, hipSetDevice(c->device));
-    if ((r = queue_front_half(c, bgr_dev))) return r;
-    RTVM_LAUNCH(c, k_frame_update, dim3(1), dim3(64), 0, c->d_state, c->d_m_count, c->d_rs_found,
-                       c->d_rs_H, c->d_wtab, c->d_H, c->d_skip, c->feat[0].count, 50.0, 0.3);
-    if ((r = rtvm_launch_warp_blend(c, bgr_dev, c->d_H, c->d_skip))) return r;
-    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_skip,
-                       c->feat[0], c->feat[1], c->orb.max_kp);
-    HIP_TRY(c, hipGetLastError());
+    return queue_batch(c, &bgr_dev, 1);
+}
+
+extern "C" int rtvm_process_batch(rtvm_ctx* c, const uint8_t* const* bgr_dev, int n) {
+    if (!c) return RTVM_E_ARG;
+    if (!bgr_dev) RTVM_FAIL(c, RTVM_E_ARG, "process_batch: null argument");
+    int r = need_stream_ctx(c, "process_batch");
+    if (r) return r;
+    if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "process_batch: call rtvm_stream_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return queue_batch(c, bgr_dev, n);
+}
+
+static int read_state(rtvm_ctx* c, StreamState** hs_out) {
+    StreamState* hs = (StreamState*)((char*)c->h_pinned + 4096);
+    HIP_TRY(c, hipMemcpyAsync(hs, c->d_state, sizeof(StreamState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *hs_out = hs;
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_batch_status(rtvm_ctx* c, int* n_done, int* status, int* n_matches, int* n_keypoints, int cap) {
+    if (!c) return RTVM_E_ARG;
+    if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "batch_status: no stream");
+    HIP_TRY(c, hipSetDevice(c->device));
+    StreamState* hs;
+    int r = read_state(c, &hs);
+    if (r) return r;
+    if (n_done) *n_done = hs->n_done;
+    for (int j = 0; j < cap && j < RTVM_MAX_BATCH; j++) {
+        if (status) status[j] = hs->b_status[j];
+        if (n_matches) n_matches[j] = hs->b_matches[j];
+        if (n_keypoints) n_keypoints[j] = hs->b_kp[j];
+    }
+    if (hs->abort) {  // the caller now knows; frames resubmitted from here on are processed again
+        HIP_TRY(c, hipMemsetAsync(&c->d_state->abort, 0, sizeof(int), c->stream));
+    }
     return RTVM_OK;
 }
 
@@ -250,9 +343,9 @@ extern "C" int rtvm_frame_status(rtvm_ctx* c, int* status, int* n_keypoints, int
     if (!c) return RTVM_E_ARG;
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "frame_status: no stream");
     HIP_TRY(c, hipSetDevice(c->device));
-    StreamState* hs = (StreamState*)((char*)c->h_pinned + 4096);
-    HIP_TRY(c, hipMemcpyAsync(hs, c->d_state, sizeof(StreamState), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    StreamState* hs;
+    int r = read_state(c, &hs);
+    if (r) return r;
     if (status) *status = hs->status;
     if (n_keypoints) *n_keypoints = hs->n_kp;
     if (n_matches) *n_matches = hs->n_matches;
@@ -263,8 +356,6 @@ extern "C" int rtvm_frame_status(rtvm_ctx* c, int* status, int* n_keypoints, int
 // ---- two-call form used by the Python VideMosaic: the glue between RANSAC and the
 // warp (validate, smooth, chain; main.py:733-746) stays in the caller's numpy -------
 
-// Uploads the frame and queues ORB, matching against the previous frame and RANSAC;
-// returns the match count, whether a homography was found and the relative H.
 extern "C" int rtvm_frame_register(rtvm_ctx* c, const uint8_t* bgr, int* n_matches, int* found, double H_rel[9]) {
     if (!c) return RTVM_E_ARG;
     if (!bgr || !n_matches || !found || !H_rel) RTVM_FAIL(c, RTVM_E_ARG, "frame_register: null argument");
@@ -273,12 +364,15 @@ extern "C" int rtvm_frame_register(rtvm_ctx* c, const uint8_t* bgr, int* n_match
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "frame_register: call rtvm_first_frame first");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
-    if ((r = queue_front_half(c, c->d_bgr))) return r;
+    const uint8_t* p = c->d_bgr;
+    if ((r = set_frame_ptrs(c, &p, 1))) return r;
+    if ((r = queue_front_half(c, 1))) return r;
+    const FrameSlot& S = c->h_slots[0];
     int* hc = (int*)c->h_pinned;
     double* hH = (double*)c->h_pinned + 8;
-    HIP_TRY(c, hipMemcpyAsync(hc, c->d_m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(hc + 1, c->d_rs_found, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(hH, c->d_rs_H, 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hc, S.m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hc + 1, S.rs_found, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hH, S.rs_H, 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *n_matches = hc[0];
     *found = hc[0] >= 4 ? hc[1] : 0;
@@ -286,8 +380,6 @@ extern "C" int rtvm_frame_register(rtvm_ctx* c, const uint8_t* bgr, int* n_match
     return RTVM_OK;
 }
 
-// Warps and blends the registered frame with the absolute homography H and makes it
-// the previous frame (main.py:748, 756-759).  Asynchronous.
 extern "C" int rtvm_frame_commit(rtvm_ctx* c, const double H[9]) {
     if (!c) return RTVM_E_ARG;
     if (!H) RTVM_FAIL(c, RTVM_E_ARG, "frame_commit: null homography");
@@ -298,27 +390,20 @@ extern "C" int rtvm_frame_commit(rtvm_ctx* c, const double H[9]) {
     HIP_TRY(c, hipMemcpyAsync(c->d_H, hp, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int r;
     if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H, nullptr))) return r;
-    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, (const int*)nullptr,
-                       c->feat[0], c->feat[1], c->orb.max_kp);
+    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
+                c->feat_prev, c->orb.max_kp);
     HIP_TRY(c, hipGetLastError());
-    // the pinned staging of H is reused by the next call
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the pinned staging of H is reused by the next call
     return RTVM_OK;
 }
 
-// Features of the current (slot 0) or previous (slot 1) frame of the stream.
-extern "C" int rtvm_get_features(rtvm_ctx* c, int slot, int* n_out, float* xy, float* size, float* angle_deg,
-                                 float* response, int32_t* octave, uint8_t* desc) {
-    if (!c) return RTVM_E_ARG;
-    if (!n_out || slot < 0 || slot > 1) RTVM_FAIL(c, RTVM_E_ARG, "get_features: bad argument");
-    if (c->fh <= 0) RTVM_FAIL(c, RTVM_E_STATE, "get_features: context has no frame size");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const FeatSet& F = c->feat[slot];
+static int read_feat(rtvm_ctx* c, const FeatSet& F, int* n_out, float* xy, float* size, float* angle_deg,
+                     float* response, int32_t* octave, uint8_t* desc) {
     int* hc = (int*)c->h_pinned;
     HIP_TRY(c, hipMemcpyAsync(hc, F.count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const int n = hc[0];
-    if (n < 0 || n > c->orb.max_kp) RTVM_FAIL(c, RTVM_E_HIP, "get_features: device returned count %d", n);
+    if (n < 0 || n > c->orb.max_kp) RTVM_FAIL(c, RTVM_E_HIP, "device returned keypoint count %d", n);
     if (n) {
         if (xy) HIP_TRY(c, hipMemcpyAsync(xy, F.xy, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
         if (size) HIP_TRY(c, hipMemcpyAsync(size, F.size, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -332,20 +417,51 @@ extern "C" int rtvm_get_features(rtvm_ctx* c, int slot, int* n_out, float* xy, f
     return RTVM_OK;
 }
 
+// Features of the current (slot 0) or previous (slot 1) frame of the stream.
+extern "C" int rtvm_get_features(rtvm_ctx* c, int slot, int* n_out, float* xy, float* size, float* angle_deg,
+                                 float* response, int32_t* octave, uint8_t* desc) {
+    if (!c) return RTVM_E_ARG;
+    if (!n_out || slot < 0 || slot > 1) RTVM_FAIL(c, RTVM_E_ARG, "get_features: bad argument");
+    if (c->fh <= 0) RTVM_FAIL(c, RTVM_E_STATE, "get_features: context has no frame size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return read_feat(c, slot == 0 ? c->h_slots[0].feat : c->feat_prev, n_out, xy, size, angle_deg, response, octave,
+                     desc);
+}
+
+// cv2.ORB detectAndCompute of a host frame (stage entry point): slot 0's features.
+int rtvm_orb_host(rtvm_ctx* c, const uint8_t* bgr, int* n_out, float* xy, float* size, float* angle_deg,
+                  float* response, int32_t* octave, uint8_t* desc, uint8_t* gray) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
+    const uint8_t* p = c->d_bgr;
+    int r;
+    if ((r = set_frame_ptrs(c, &p, 1))) return r;
+    if ((r = rtvm_launch_orb(c, 0, 1))) return r;
+    if (gray) {
+        HIP_TRY(c, hipMemcpy2DAsync(gray, c->fw, c->h_slots[0].pyr + c->orb.off[0], c->orb.pitch[0], c->fw, c->fh,
+                                    hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return RTVM_OK;
+    }
+    return read_feat(c, c->h_slots[0].feat, n_out, xy, size, angle_deg, response, octave, desc);
+}
+
 // Matches of the most recent frame against its predecessor, sorted by distance.
 extern "C" int rtvm_get_matches(rtvm_ctx* c, int* m_out, int32_t* qidx, int32_t* tidx, int32_t* dist) {
     if (!c) return RTVM_E_ARG;
     if (!m_out) RTVM_FAIL(c, RTVM_E_ARG, "get_matches: null argument");
+    if (c->fh <= 0) RTVM_FAIL(c, RTVM_E_STATE, "get_matches: context has no frame size");
     HIP_TRY(c, hipSetDevice(c->device));
+    const FrameSlot& S = c->h_slots[0];
     int* hc = (int*)c->h_pinned;
-    HIP_TRY(c, hipMemcpyAsync(hc, c->d_m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hc, S.m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const int m = hc[0];
     if (m < 0 || m > RTVM_MAX_MATCH) RTVM_FAIL(c, RTVM_E_HIP, "get_matches: device returned count %d", m);
     if (m) {
-        if (qidx) HIP_TRY(c, hipMemcpyAsync(qidx, c->d_m_qidx, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
-        if (tidx) HIP_TRY(c, hipMemcpyAsync(tidx, c->d_m_tidx, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
-        if (dist) HIP_TRY(c, hipMemcpyAsync(dist, c->d_m_dist, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        if (qidx) HIP_TRY(c, hipMemcpyAsync(qidx, S.m_qidx, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        if (tidx) HIP_TRY(c, hipMemcpyAsync(tidx, S.m_tidx, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        if (dist) HIP_TRY(c, hipMemcpyAsync(dist, S.m_dist, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     *m_out = m;

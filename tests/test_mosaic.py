@@ -151,3 +151,30 @@ def test_device_stream_path_matches_oracle(fixed):
         assert np.array_equal(H, om.H), "frame %s" % s
         assert np.array_equal(ctx.canvas_read(), om.canvas), "frame %s" % s
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 4, 7])
+def test_batched_stream_matches_oracle(batch):
+    """rtvm_process_batch: same canvas and homography as frame-by-frame processing, including a
+    skipped frame in the middle of a batch (later frames come back as pending and are resubmitted)."""
+    import torch
+    frames, _ = video(12, seed=6)
+    order = [1, 2, 3, 4, 5, "flat", 6, 7, 8, 9, 10, 11]
+    seq = [np.full_like(frames[0], 90) if s == "flat" else frames[s] for s in order]
+    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=500)
+    om = OracleMosaic(frames[0], nfeatures=500, glue="explicit")
+    first = torch.from_numpy(frames[0]).cuda()
+    dev = [torch.from_numpy(f).cuda() for f in seq]
+    torch.cuda.synchronize()
+    ctx.stream_begin(first.data_ptr(), om.w_offset, om.h_offset)
+    status = ctx.process_video([d.data_ptr() for d in dev], batch=batch)
+    ref = []
+    for f in seq:
+        om.process_frame(f)
+        ref.append(om.status)
+    assert status.tolist() == ref
+    st, nk, nm, H = ctx.frame_status()
+    assert np.array_equal(H, om.H)
+    assert np.array_equal(ctx.canvas_read(), om.canvas)
+    ctx.close()
