@@ -123,7 +123,8 @@ int rtvm_canvas_init(rtvm_ctx* ctx, const uint8_t* first_bgr, int row_off, int c
 int rtvm_warp_perspective(rtvm_ctx* ctx, const uint8_t* bgr, const double H[9], uint8_t* out);
 
 /* cv2.distanceTransform(mask, cv2.DIST_L2, 3)  main.py:888-889.
- * mask: h*w u8 (non-zero = inside), dist: h*w f32.  h*w <= canvas_h*canvas_w. */
+ * mask: h*w u8 (non-zero = inside), dist: h*w f32.  The image must fit the context's
+ * work planes: h*w <= canvas_h*canvas_w, h+w <= canvas_h+canvas_w, h <= canvas_h+32. */
 int rtvm_distance_transform(rtvm_ctx* ctx, const uint8_t* mask, int h, int w, float* dist);
 
 /* The whole of VideMosaic.warp(): warp, masks, distance transforms, weights,

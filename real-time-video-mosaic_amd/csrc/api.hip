@@ -150,7 +150,10 @@ int alloc_all(rtvm_ctx* c) {
     ALLOC(c, d_mask_old, n_px);
     ALLOC(c, d_dt_s, n_px * 4);
     ALLOC(c, d_dt_r, n_px * 2);
-    ALLOC(c, d_dt_f, n_px * 2);
+    c->dt_z_words = (size_t)2 * ((c->ch + 31) / 32 + 1) * (c->cw + c->ch + 64);
+    c->dt_cs_words = (size_t)4 * ((c->ch + 31) / 32 + 1) * (c->cw + c->ch + 64);
+    ALLOC(c, d_dt_z, c->dt_z_words * 2);
+    ALLOC(c, d_dt_cs, c->dt_cs_words * 2);
     ALLOC(c, d_dist, n_px * 2);
     ALLOC(c, d_wgt, n_px * 2);
     ALLOC(c, d_rb, n_px * 2);
@@ -193,7 +196,7 @@ int alloc_all(rtvm_ctx* c) {
 
 void free_all(rtvm_ctx* c) {
     void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas, c->d_warped, c->d_mask_new,
-                    c->d_mask_old, c->d_dt_s, c->d_dt_r, c->d_dt_f, c->d_dist, c->d_wgt, c->d_rb, c->d_gk, c->d_H,
+                    c->d_mask_old, c->d_dt_s, c->d_dt_r, c->d_dt_z, c->d_dt_cs, c->d_dist, c->d_wgt, c->d_rb, c->d_gk, c->d_H,
                     c->d_wp, c->d_jobs, c->d_rs_raw, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
                     c->d_skip};
     free_feat(&c->feat_prev);
@@ -424,8 +427,8 @@ extern "C" int rtvm_warp_perspective(rtvm_ctx* c, const uint8_t* bgr, const doub
 extern "C" int rtvm_distance_transform(rtvm_ctx* c, const uint8_t* mask, int h, int w, float* dist) {
     if (!c) return RTVM_E_ARG;
     if (!mask || !dist || h <= 0 || w <= 0) RTVM_FAIL(c, RTVM_E_ARG, "distance_transform: bad argument");
-    if ((size_t)h * w > (size_t)c->ch * c->cw)
-        RTVM_FAIL(c, RTVM_E_ARG, "distance_transform: %dx%d exceeds the context's canvas", h, w);
+    if ((size_t)h * w > (size_t)c->ch * c->cw || h + w > c->ch + c->cw || (h + 31) / 32 > (c->ch + 31) / 32 + 1)
+        RTVM_FAIL(c, RTVM_E_ARG, "distance_transform: %dx%d exceeds the context's canvas (%dx%d)", h, w, c->ch, c->cw);
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n_px = (size_t)c->ch * c->cw;
     DtJob* jb = (DtJob*)((char*)c->h_pinned + 1024);
@@ -434,11 +437,18 @@ extern "C" int rtvm_distance_transform(rtvm_ctx* c, const uint8_t* mask, int h, 
     jb->x0 = jb->y0 = 0;
     jb->x1 = w;
     jb->y1 = h;
+    jb->ox0 = jb->oy0 = 0;
+    jb->ox1 = w;
+    jb->oy1 = h;
     jb->sA = c->d_dt_s;
     jb->sB = c->d_dt_s + n_px;
     jb->R = c->d_dt_r;
-    jb->F = c->d_dt_f;
     jb->dist = c->d_dist;
+    jb->Z = c->d_dt_z;
+    jb->CS = c->d_dt_cs;
+    jb->znch = (h + 31) / 32;
+    jb->zpitch = w + h;
+    jb->cpitch = w;
     HIP_TRY(c, hipMemcpyAsync(c->d_jobs + 2, jb, sizeof(DtJob), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_mask_new, mask, (size_t)h * w, hipMemcpyHostToDevice, c->stream));
     int r = rtvm_launch_dt(c, c->d_jobs + 2, 1, w, h);

@@ -85,12 +85,15 @@ struct FrameSlot {
 struct DtJob {
     const uint8_t* mask;
     int pitch;
-    int x0, y0, x1, y1;
+    int x0, y0, x1, y1;      // rectangle the transform is computed on (outside = wall)
+    int ox0, oy0, ox1, oy1;  // sub-rectangle whose distances are needed
     uint16_t* sA;      // steps to the nearest zero along x - y = const
     uint16_t* sB;      // steps to the nearest zero along x + y = const
     uint32_t* R;       // row scan result
-    uint32_t* F;       // downward column scan
     float* dist;
+    uint32_t* Z;       // zero bitmaps of the diagonal lines: [2 orientations][znch][zpitch]
+    uint32_t* CS;      // column chunk summaries: [4][znch][cpitch]
+    int znch, zpitch, cpitch;
 };
 
 // Per-frame warp parameters, written on the device by k_warp_prep.
@@ -168,7 +171,9 @@ struct rtvm_ctx {
     uint8_t* d_mask_old;   // ch*cw
     uint16_t* d_dt_s;      // diagonal step planes: [2 jobs][2 orientations][ch*cw]
     uint32_t* d_dt_r;      // row-pass planes [2][ch*cw]
-    uint32_t* d_dt_f;      // downward column pass planes [2][ch*cw]
+    uint32_t* d_dt_z;      // diagonal zero bitmaps, per job
+    uint32_t* d_dt_cs;     // column chunk summaries, per job
+    size_t dt_z_words, dt_cs_words;  // per job
     float* d_dist;         // [2][ch*cw]: 0 = new, 1 = old
     float* d_wgt;          // blend weights [2][ch*cw]
     float* d_rb;           // row-blurred weights [2][ch*cw]

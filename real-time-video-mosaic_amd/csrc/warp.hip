@@ -30,7 +30,10 @@ __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restric
         wp->rx0 = wp->ry0 = wp->rx1 = wp->ry1 = 0;
         wp->wx0 = wp->wy0 = wp->wx1 = wp->wy1 = 0;
         if (jobs)
-            for (int j = 0; j < 2; j++) jobs[j].x0 = jobs[j].y0 = jobs[j].x1 = jobs[j].y1 = 0;
+            for (int j = 0; j < 2; j++) {
+                jobs[j].x0 = jobs[j].y0 = jobs[j].x1 = jobs[j].y1 = 0;
+                jobs[j].ox0 = jobs[j].oy0 = jobs[j].ox1 = jobs[j].oy1 = 0;
+            }
         return;
     }
     double S[9];
@@ -96,15 +99,20 @@ __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restric
     const int bh0 = ch < 16 ? ch : 16;
     wp->bw0 = (1024 / bh0) < cw ? (1024 / bh0) : cw;
     if (jobs) {
-        jobs[0].x0 = x0;
-        jobs[0].y0 = y0;
-        jobs[0].x1 = x1;
-        jobs[0].y1 = y1;
-        // the old-canvas distances are needed only when the frame touches the canvas
+        // new mask: transform on the ROI (its rim is zero, so nothing outside can be nearer)
+        jobs[0].x0 = jobs[0].ox0 = x0;
+        jobs[0].y0 = jobs[0].oy0 = y0;
+        jobs[0].x1 = jobs[0].ox1 = x1;
+        jobs[0].y1 = jobs[0].oy1 = y1;
+        // old mask: transform on the whole canvas, distances needed where the weights are
         jobs[1].x0 = 0;
         jobs[1].y0 = 0;
         jobs[1].x1 = empty ? 0 : cw;
         jobs[1].y1 = empty ? 0 : ch;
+        jobs[1].ox0 = wp->wx0;
+        jobs[1].oy0 = wp->wy0;
+        jobs[1].ox1 = wp->wx1;
+        jobs[1].oy1 = wp->wy1;
     }
 }
 
@@ -315,11 +323,16 @@ int rtvm_warp_setup(rtvm_ctx* c) {
         jobs[j].mask = j == 0 ? c->d_mask_new : c->d_mask_old;
         jobs[j].pitch = c->cw;
         jobs[j].x0 = jobs[j].y0 = jobs[j].x1 = jobs[j].y1 = 0;
+        jobs[j].ox0 = jobs[j].oy0 = jobs[j].ox1 = jobs[j].oy1 = 0;
         jobs[j].sA = c->d_dt_s + (size_t)(2 * j) * n_px;
         jobs[j].sB = c->d_dt_s + (size_t)(2 * j + 1) * n_px;
         jobs[j].R = c->d_dt_r + (size_t)j * n_px;
-        jobs[j].F = c->d_dt_f + (size_t)j * n_px;
         jobs[j].dist = c->d_dist + (size_t)j * n_px;
+        jobs[j].Z = c->d_dt_z + (size_t)j * c->dt_z_words;
+        jobs[j].CS = c->d_dt_cs + (size_t)j * c->dt_cs_words;
+        jobs[j].znch = (c->ch + 31) / 32;
+        jobs[j].zpitch = c->cw + c->ch;
+        jobs[j].cpitch = c->cw;
     }
     jobs[2] = jobs[0];
     HIP_TRY(c, hipMemcpy(c->d_jobs, jobs, sizeof(jobs), hipMemcpyHostToDevice));
