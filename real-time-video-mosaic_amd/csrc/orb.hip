@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void k_fast_score(OrbDev P, const FrameSlot* _
 
 // Keeps a scored pixel iff it beats its 8 neighbours strictly and lies at least
 // 31 pixels inside the level; appends (score << 24 | y << 12 | x) to the level's
-// candidate list (one atomic per wave) and counts the score in the level's histogram.
+// candidate list and counts the score in the level's histogram (aggregated per
+// workgroup in LDS: one global atomic per workgroup and per occupied bin).
 __global__ __launch_bounds__(256) void k_fast_nms(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
     const FrameSlot& SL = slots[sb + blockIdx.y];
     const uint8_t* __restrict__ score = SL.score;
@@ -189,32 +190,43 @@ __global__ __launch_bounds__(256) void k_fast_nms(OrbDev P, const FrameSlot* __r
     const int tiles_x = (W - 60 + 63) / 64;
     const int x = 30 + (local % tiles_x) * 64 + (threadIdx.x & 63);
     const uint8_t* S = score + P.off[l];
-    const int lane = threadIdx.x & 63;
+    // block-level aggregation: one counter atomic per block, histogram bins through LDS
+    __shared__ int s_hist[256];
+    __shared__ int s_cnt, s_base;
+    s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int my_pos[2] = {-1, -1}, my_s[2] = {0, 0}, my_y[2] = {0, 0};
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         const int y = 30 + (local / tiles_x) * 8 + (threadIdx.x >> 6) + 4 * half;
-        bool keep = false;
-        int s = 0;
         if (x >= EDGE && x < W - EDGE && y >= EDGE && y < H - EDGE) {
             const uint8_t* p = S + (size_t)y * pitch + x;
-            s = p[0];
-            if (s) {
-                keep = s > p[-1] && s > p[1] && s > p[-pitch - 1] && s > p[-pitch] && s > p[-pitch + 1] &&
-                       s > p[pitch - 1] && s > p[pitch] && s > p[pitch + 1];
-            }
-        }
-        const unsigned long long bal = __ballot(keep);
-        if (bal) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&cand_count[l], __popcll(bal));
-            base = __shfl(base, 0);
-            if (keep) {
-                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                if (pos < P.cand_cap[l]) cand[P.cand_off[l] + pos] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
-                atomicAdd(&hist[l * 256 + s], 1);
+            const int s = p[0];
+            if (s && s > p[-1] && s > p[1] && s > p[-pitch - 1] && s > p[-pitch] && s > p[-pitch + 1] &&
+                s > p[pitch - 1] && s > p[pitch] && s > p[pitch + 1]) {
+                my_pos[half] = atomicAdd(&s_cnt, 1);
+                my_s[half] = s;
+                my_y[half] = y;
+                atomicAdd(&s_hist[s], 1);
             }
         }
     }
+    __syncthreads();
+    const int n = s_cnt;
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&cand_count[l], n);
+    __syncthreads();
+    const int base = s_base;
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+        if (my_pos[half] >= 0) {
+            const int pos = base + my_pos[half];
+            if (pos < P.cand_cap[l])
+                cand[P.cand_off[l] + pos] = ((uint32_t)my_s[half] << 24) | ((uint32_t)my_y[half] << 12) | (uint32_t)x;
+        }
+    const int hcount = s_hist[threadIdx.x];
+    if (hcount) atomicAdd(&hist[l * 256 + threadIdx.x], hcount);
 }
 
 // ------------------------------------------------------------------ selection
