@@ -77,6 +77,27 @@ def cpu_baseline(frames_np, cfg, n_frames):
     return n_frames / dt, om
 
 
+def max_over_ranks(seconds, world, device=None):
+    """Slowest rank's time: what the whole job took (all_reduce MAX over the process group)."""
+    if world <= 1:
+        return float(seconds)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_throughput(frames_per_rank, seconds, world, device=None):
+    """Whole-job frames/s: every rank stitched frames_per_rank frames of its own stream."""
+    return world * frames_per_rank / max_over_ranks(seconds, world, device)
+
+
+def stream_seed(rank, world):
+    """Independent streams: one seeded synthetic video per rank."""
+    return 0 if world == 1 else 10 + rank
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,7 +128,7 @@ def main():
     K, W = args.steps, args.warmup
     T = 1 + W + K
     # --- synthetic video, seeded per rank (independent streams), resident in HBM
-    seed = 0 if world == 1 else 10 + rank
+    seed = stream_seed(rank, world)
     side_h = fh + 2 * T + 256
     side_w = fw + 2 * T + 256
     world_img = synth.make_world(side_h, side_w, seed=seed)
@@ -160,11 +181,7 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     dom = ctx.profile_stop()[dominant]
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(t1 - t0, world, dev)
     st, nk, nm, H = ctx.frame_status()
     last = min(B, K) if K % B == 0 else K % B
     done, bst, _, _ = ctx.batch_status(last)
