@@ -197,7 +197,7 @@ int alloc_all(rtvm_ctx* c) {
 void free_all(rtvm_ctx* c) {
     void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas, c->d_warped, c->d_mask_new,
                     c->d_mask_old, c->d_dt_s, c->d_dt_r, c->d_dt_z, c->d_dt_cs, c->d_dist, c->d_wgt, c->d_rb, c->d_gk, c->d_H,
-                    c->d_wp, c->d_jobs, c->d_rs_raw, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
+                    c->d_wp, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
                     c->d_skip};
     free_feat(&c->feat_prev);
     for (void* p : ptrs)
@@ -307,6 +307,44 @@ extern "C" int rtvm_match_hamming_xcheck_sorted(rtvm_ctx* c, const uint8_t* q, i
                                                 const uint8_t* t, int nt, int32_t* qidx,
                                                 int32_t* tidx, int32_t* dist, int* m_out) {
     return match_hamming_host(c, q, nq, t, nt, qidx, tidx, dist, m_out, 1);
+}
+
+// ---- L2 knn-2 matcher (SIFT branch) ---------------------------------------------
+extern "C" int rtvm_match_l2_knn2(rtvm_ctx* c, const float* q, int nq, const float* t, int nt, int dim,
+                                  int32_t* idx, float* dist) {
+    if (!c) return RTVM_E_ARG;
+    if (nq < 0 || nt < 2 || dim <= 0 || !t || (nq > 0 && (!q || !idx || !dist)))
+        RTVM_FAIL(c, RTVM_E_ARG, "match_l2_knn2: bad argument (needs at least 2 train descriptors)");
+    if (nq == 0) return RTVM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t need_q = (size_t)nq * dim, need_t = (size_t)nt * dim;
+    if (need_q > c->l_cap_q || need_t > c->l_cap_t) {  // grow the staging buffers
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        void* old[] = {c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag};
+        for (void* p : old)
+            if (p) (void)hipFree(p);
+        c->d_lq = c->d_lt = c->d_l_dist = c->d_l_norms = nullptr;
+        c->d_l_idx = nullptr;
+        c->d_l_flag = nullptr;
+        c->l_cap_q = c->l_cap_t = 0;
+        const size_t cq = need_q > c->l_cap_q ? need_q : c->l_cap_q, ct = need_t > c->l_cap_t ? need_t : c->l_cap_t;
+        ALLOC(c, d_lq, cq);
+        ALLOC(c, d_lt, ct);
+        ALLOC(c, d_l_idx, (size_t)2 * (cq / dim + 1));
+        ALLOC(c, d_l_dist, (size_t)2 * (cq / dim + 1));
+        ALLOC(c, d_l_norms, cq / dim + ct / dim + 2);
+        ALLOC(c, d_l_flag, 4);
+        c->l_cap_q = cq;
+        c->l_cap_t = ct;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_lq, q, need_q * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_lt, t, need_t * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    int r = rtvm_launch_l2_knn2(c, c->d_lq, nq, c->d_lt, nt, dim, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpyAsync(idx, c->d_l_idx, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dist, c->d_l_dist, (size_t)nq * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTVM_OK;
 }
 
 // ---- gray / ORB ---------------------------------------------------------------
@@ -486,4 +524,3 @@ extern "C" int rtvm_canvas_read(rtvm_ctx* c, uint8_t* out) {
 
 // ---- not yet implemented (stubs keep the ABI complete while stages land) ----
 #define RTVM_STUB(ctx) RTVM_FAIL(ctx, RTVM_E_STATE, "%s: not implemented yet", __func__)
-extern "C" int rtvm_match_l2_knn2(rtvm_ctx* c, const float*, int, const float*, int, int, int32_t*, float*) { RTVM_STUB(c); }

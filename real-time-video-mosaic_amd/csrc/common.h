@@ -158,7 +158,9 @@ struct rtvm_ctx {
     float* d_lt;
     int32_t* d_l_idx;
     float* d_l_dist;
-    size_t l_cap_q, l_cap_t;
+    float* d_l_norms;
+    int* d_l_flag;
+    size_t l_cap_q, l_cap_t;   // capacities in floats / rows
 
     // --- RANSAC ---
     uint32_t* d_rs_raw;    // raw outputs of the fixed-seed RNG
@@ -228,8 +230,8 @@ int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int with_orb);  // api.h
 size_t rtvm_ransac_state_bytes();
 void rtvm_ransac_raw_table(uint32_t* raw, int n);
 int rtvm_launch_ransac(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence);
-int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim,
-                        int32_t* d_idx, float* d_dist);
+int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim, int32_t* d_idx,
+                        float* d_dist, float* d_norms, int* d_flag);
 
 // ---- optional per-kernel timing with HIP events on the context's stream (prof.hip) ----
 int rtvm_prof_begin(rtvm_ctx* c, const char* name);

@@ -116,3 +116,52 @@ def test_hip_hamming_rejects_oversize(ctx_small):
     q = np.zeros((16385, 32), np.uint8)
     with pytest.raises(rtvm.RtvmError):
         ctx_small.match_hamming(q, q[:10])
+
+
+def sift_like(seed, nq, nt, dim=128, planted=0.7):
+    """Integer-valued float32 descriptors (0..255) with planted correspondences, as SIFT produces."""
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, 120, (nt, dim)).astype(np.float32)
+    q = rng.integers(0, 120, (nq, dim)).astype(np.float32)
+    k = int(min(nq, nt) * planted)
+    src, dst = rng.permutation(nt)[:k], rng.permutation(nq)[:k]
+    q[dst] = np.clip(t[src] + np.rint(rng.normal(0, 8, (k, dim))), 0, 255).astype(np.float32)
+    if nt > 12 and nq > 3:
+        t[9] = t[4]           # exact duplicates: the earlier index must come first
+        t[11] = t[4]
+        q[1] = t[4]
+    return q, t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nt,dim", [(1, 2, 128), (33, 31, 128), (500, 700, 128), (2000, 2000, 128),
+                                       (300, 257, 64), (100, 90, 32)])
+def test_hip_l2_knn2_integer_valued_exact(ctx_small, nq, nt, dim):
+    q, t = sift_like(nq + nt, nq, nt, dim)
+    gi, gd = ctx_small.match_l2_knn2(q, t)
+    ri, rd = orc.match_l2_knn2(q, t)
+    assert np.array_equal(gi, ri)
+    assert np.array_equal(gd, rd)
+
+
+@pytest.mark.gpu
+def test_hip_l2_knn2_generic_floats_exact(ctx_small):
+    rng = np.random.default_rng(5)
+    t = rng.normal(0, 1, (400, 128)).astype(np.float32)
+    q = (t[rng.integers(0, 400, 350)] + rng.normal(0, 0.05, (350, 128))).astype(np.float32)
+    gi, gd = ctx_small.match_l2_knn2(q, t)
+    ri, rd = orc.match_l2_knn2(q, t)
+    assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
+    q2 = q.copy()
+    q2[0, 0] = 300.0                      # integer valued but out of the 8-bit range
+    gi, gd = ctx_small.match_l2_knn2(np.rint(q2 * 50), np.rint(t * 50))
+    ri, rd = orc.match_l2_knn2(np.rint(q2 * 50), np.rint(t * 50))
+    assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
+
+
+@pytest.mark.gpu
+def test_hip_l2_knn2_needs_two_train_rows(ctx_small):
+    import rtvm
+    q, t = sift_like(1, 5, 5)
+    with pytest.raises(rtvm.RtvmError):
+        ctx_small.match_l2_knn2(q, t[:1])
