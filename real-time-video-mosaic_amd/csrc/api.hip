@@ -155,7 +155,6 @@ int alloc_all(rtvm_ctx* c) {
     ALLOC(c, d_dt_z, c->dt_z_words * 2);
     ALLOC(c, d_dt_cs, c->dt_cs_words * 2);
     ALLOC(c, d_dist, n_px * 2);
-    ALLOC(c, d_wgt, n_px * 2);
     ALLOC(c, d_rb, n_px * 2);
     ALLOC(c, d_gk, 32);
     ALLOC(c, d_H, RTVM_MAX_BATCH * 9 + 16);
@@ -196,7 +195,7 @@ int alloc_all(rtvm_ctx* c) {
 
 void free_all(rtvm_ctx* c) {
     void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas, c->d_warped, c->d_mask_new,
-                    c->d_mask_old, c->d_dt_s, c->d_dt_r, c->d_dt_z, c->d_dt_cs, c->d_dist, c->d_wgt, c->d_rb, c->d_gk, c->d_H,
+                    c->d_mask_old, c->d_dt_s, c->d_dt_r, c->d_dt_z, c->d_dt_cs, c->d_dist, c->d_rb, c->d_gk, c->d_H,
                     c->d_wp, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
                     c->d_skip};
     free_feat(&c->feat_prev);

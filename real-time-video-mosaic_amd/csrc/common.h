@@ -177,7 +177,6 @@ struct rtvm_ctx {
     uint32_t* d_dt_cs;     // column chunk summaries, per job
     size_t dt_z_words, dt_cs_words;  // per job
     float* d_dist;         // [2][ch*cw]: 0 = new, 1 = old
-    float* d_wgt;          // blend weights [2][ch*cw]
     float* d_rb;           // row-blurred weights [2][ch*cw]
     float* d_gk;           // 31 Gaussian taps
     double* d_H;           // RTVM_MAX_BATCH x 9 doubles: homographies handed to the warp

@@ -19,8 +19,8 @@
 //   k_dt_diag_b  steps to the nearest zero along the line from the bitmaps
 //   k_dt_rows    row scans (one workgroup per row), only rows of the output window
 //   k_dt_cols_a  per (column, chunk): value leaving the chunk downwards / upwards
-//   k_dt_cols_s  per column: values arriving at every chunk from above / below
-//   k_dt_cols_b  final column scan in registers, min with the row scan, distance out
+//   k_dt_cols_b  carries from the other chunks' summaries, final column scan in
+//                registers, min with the row scan, distance out
 #include "common.h"
 
 namespace {
@@ -209,28 +209,6 @@ __global__ __launch_bounds__(64) void k_dt_cols_a(const DtJob* __restrict__ jobs
     jb.CS[((size_t)1 * jb.znch + c) * jb.cpitch + x] = be;
 }
 
-// Per column: value arriving at the first row of every chunk from above (CS plane 2)
-// and at the last row of every chunk from below (plane 3).
-__global__ __launch_bounds__(64) void k_dt_cols_s(const DtJob* __restrict__ jobs) {
-    const DtJob jb = jobs[blockIdx.y];
-    const int H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
-    const int x = jb.ox0 + blockIdx.x * 64 + threadIdx.x;
-    if (H <= 0 || x >= jb.ox1) return;
-    const size_t plane = (size_t)jb.znch * jb.cpitch;
-    uint32_t arr = INF32;
-    for (int c = 0; c < nch; c++) {
-        jb.CS[2 * plane + (size_t)c * jb.cpitch + x] = arr;
-        const uint32_t fe = jb.CS[0 * plane + (size_t)c * jb.cpitch + x];
-        arr = sat_add(min(fe, sat_add(arr, DT_A * (CH - 1))), DT_A);
-    }
-    arr = INF32;
-    for (int c = nch - 1; c >= 0; c--) {
-        jb.CS[3 * plane + (size_t)c * jb.cpitch + x] = arr;
-        const uint32_t be = jb.CS[1 * plane + (size_t)c * jb.cpitch + x];
-        arr = sat_add(min(be, sat_add(arr, DT_A * (CH - 1))), DT_A);
-    }
-}
-
 // Final column scan of the chunks that intersect the output window, in registers;
 // d = min(column scan, row scan), clamped to DIST_MAX, as float / 65536.
 __global__ __launch_bounds__(64) void k_dt_cols_b(const DtJob* __restrict__ jobs) {
@@ -244,15 +222,26 @@ __global__ __launch_bounds__(64) void k_dt_cols_b(const DtJob* __restrict__ jobs
     const size_t plane = (size_t)jb.znch * jb.cpitch;
     uint32_t E[CH], F[CH];
     load_chunk_e(jb, x, ya, E);
-    uint32_t run = jb.CS[2 * plane + (size_t)c * jb.cpitch + x];
+    // values arriving from the other chunks of the column: at the first row from above,
+    // at the last row from below (chunk k's summary travels 32*|c-k| - 31 rows)
+    uint32_t cf = INF32, cb = INF32;
+    for (int k = 0; k < nch; k++) {
+        if (k < c) {
+            const uint32_t fe = jb.CS[0 * plane + (size_t)k * jb.cpitch + x];
+            cf = min(cf, sat_add(fe, DT_A * (uint32_t)(CH * (c - k) - (CH - 1))));
+        } else if (k > c) {
+            const uint32_t be = jb.CS[1 * plane + (size_t)k * jb.cpitch + x];
+            cb = min(cb, sat_add(be, DT_A * (uint32_t)(CH * (k - c) - (CH - 1))));
+        }
+    }
+    uint32_t run = cf;
 #pragma unroll
     for (int r = 0; r < CH; r++) {
         run = min(run, E[r]);
         F[r] = run;
         run = sat_add(run, DT_A);
     }
-    run = jb.CS[3 * plane + (size_t)c * jb.cpitch + x];
-    // a short last chunk: the value from below arrives at row y1-1, not at ya+31
+    run = cb;  // only chunks that are not the last have a chunk below, and those are full
 #pragma unroll
     for (int r = CH - 1; r >= 0; r--) {
         const int y = ya + r;
@@ -281,7 +270,6 @@ int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int m
     RTVM_LAUNCH(c, k_dt_diag_b, dim3((nlines + 63) / 64, nch, 2 * njobs), dim3(64), 0, d_jobs);
     RTVM_LAUNCH(c, k_dt_rows, dim3(max_h, njobs), dim3(256), 0, d_jobs);
     RTVM_LAUNCH(c, k_dt_cols_a, dim3((max_w + 63) / 64, nch, njobs), dim3(64), 0, d_jobs);
-    RTVM_LAUNCH(c, k_dt_cols_s, dim3((max_w + 63) / 64, njobs), dim3(64), 0, d_jobs);
     RTVM_LAUNCH(c, k_dt_cols_b, dim3((max_w + 63) / 64, nch + 1, njobs), dim3(64), 0, d_jobs);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;

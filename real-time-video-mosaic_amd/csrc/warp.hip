@@ -188,30 +188,13 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, c
     if (mask_new) mask_new[p] = (v[0] | v[1] | v[2]) ? 255 : 0;
 }
 
-// weight_new = dn / (dn + do + 1e-6), weight_old = do / (...)  (main.py:892-894)
-// on the ROI grown by the blur radius.  dn is zero outside the ROI.
-__global__ __launch_bounds__(256) void k_weights(const WarpParams* __restrict__ wp, const float* __restrict__ dn,
-                                                 const float* __restrict__ dold, float* __restrict__ wn,
-                                                 float* __restrict__ wo, int cw) {
-    const int wx0 = wp->wx0, wy0 = wp->wy0, wx1 = wp->wx1, wy1 = wp->wy1;
-    const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
-    if (bx >= wx1 || bx + 64 <= wx0 || by >= wy1 || by + 4 <= wy0) return;
-    const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
-    if (x < wx0 || x >= wx1 || y < wy0 || y >= wy1) return;
-    const size_t p = (size_t)y * cw + x;
-    const bool in_roi = x >= wp->rx0 && x < wp->rx1 && y >= wp->ry0 && y < wp->ry1;
-    const float a = in_roi ? dn[p] : 0.f;
-    const float b = dold[p];
-    const float sum = (a + b) + 1e-6f;
-    wn[p] = a / sum;
-    wo[p] = b / sum;
-}
-
-// Row pass of cv2.GaussianBlur(w, (31,31), 0) (main.py:897-898) for both weight
-// planes: 31 taps added left to right in float32, BORDER_REFLECT_101 at the canvas
-// edge.  One workgroup = 256 consecutive pixels of one row, staged through LDS.
+// weight_new = dn / (dn + do + 1e-6), weight_old = do / (...)  (main.py:892-894),
+// evaluated while staging, then the row pass of cv2.GaussianBlur(w, (31,31), 0)
+// (main.py:897-898) for both weights: 31 taps added left to right in float32,
+// BORDER_REFLECT_101 at the canvas edge.  dn is zero outside the ROI.  One
+// workgroup = 256 consecutive pixels of one row, staged through LDS.
 __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
-                                                   const float* __restrict__ wn, const float* __restrict__ wo,
+                                                   const float* __restrict__ dn, const float* __restrict__ dold,
                                                    float* __restrict__ rbn, float* __restrict__ rbo, int cw) {
     const int rx0 = wp->rx0, rx1 = wp->rx1, wy0 = wp->wy0, wy1 = wp->wy1;
     const int bx = blockIdx.x * 256, y = blockIdx.y;
@@ -219,12 +202,20 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
     __shared__ float s_n[256 + 30], s_o[256 + 30];
     __shared__ float s_k[31];
     const size_t row = (size_t)y * cw;
+    const bool row_in_roi = y >= wp->ry0 && y < wp->ry1;
     for (int i = threadIdx.x; i < 256 + 30; i += 256) {
         const int xs = reflect101(bx - 15 + i, cw);
-        // weights exist on [wx0, wx1); columns this row pass never needs may lie outside
-        const bool ok = xs >= wp->wx0 && xs < wp->wx1;
-        s_n[i] = ok ? wn[row + xs] : 0.f;
-        s_o[i] = ok ? wo[row + xs] : 0.f;
+        // distances exist on [wx0, wx1); columns this row pass never needs may lie outside
+        float wn = 0.f, wo = 0.f;
+        if (xs >= wp->wx0 && xs < wp->wx1) {
+            const float a = (row_in_roi && xs >= rx0 && xs < rx1) ? dn[row + xs] : 0.f;
+            const float b = dold[row + xs];
+            const float sum = (a + b) + 1e-6f;
+            wn = a / sum;
+            wo = b / sum;
+        }
+        s_n[i] = wn;
+        s_o[i] = wo;
     }
     if (threadIdx.x < 31) s_k[threadIdx.x] = gk[threadIdx.x];
     __syncthreads();
@@ -379,13 +370,10 @@ int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H,
                            c->fh, c->fw, c->ch, c->cw);
     int r = rtvm_launch_dt(c, c->d_jobs, 2, c->cw, c->ch);
     if (r != RTVM_OK) return r;
-    float* wn = c->d_wgt;
-    float* wo = c->d_wgt + n_px;
     float* rbn = c->d_rb;
     float* rbo = c->d_rb + n_px;
-    RTVM_LAUNCH(c, k_weights, grid, dim3(256), 0, c->d_wp, c->d_dist, c->d_dist + n_px, wn, wo, c->cw);
-    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, c->ch), dim3(256), 0, c->d_wp, c->d_gk, wn,
-                       wo, rbn, rbo, c->cw);
+    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, c->ch), dim3(256), 0, c->d_wp, c->d_gk, c->d_dist,
+                c->d_dist + n_px, rbn, rbo, c->cw);
     RTVM_LAUNCH(c, k_blur_cols_commit, grid, dim3(256), 0, c->d_wp, c->d_gk, rbn, rbo, c->d_warped,
                        c->d_mask_new, c->d_mask_old, c->d_canvas, c->ch, c->cw);
     HIP_TRY(c, hipGetLastError());
