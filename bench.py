@@ -43,8 +43,18 @@ def pyramid_pixels(fh, fw):
 
 
 def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px):
-    """Compulsory HBM bytes of one launch: every input read once, every output written once."""
+    """Compulsory HBM bytes of one launch: every input read once, every output written once.
+
+    The distance transform runs two jobs per frame: the new mask on the frame's region of the
+    canvas (roi_px pixels) and the old mask on the whole canvas, whose distances are only needed
+    on the blend window (the region plus the 15-pixel blur margin)."""
     P, C, S = fh * fw, ch * cw, pyramid_pixels(fh, fw)
+    win_h, win_w = min(ch, fh + 38), min(cw, fw + 38)
+    win = win_h * win_w
+    A = C + roi_px                      # pixels the diagonal scans cover (both jobs)
+    rows_px = roi_px + win_h * cw       # rows of the output windows, full rectangle width
+    cols_px = roi_px + win_w * ch       # columns of the output windows, full rectangle height
+    win2 = roi_px + win                 # output windows of both jobs
     table = {
         "k_gray": 3 * P + P,
         "k_fast_score": S + S,                 # level pixels in, score map out
@@ -53,13 +63,15 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px):
         "k_resize": (S - P) / 7 * (1.44 + 1),  # per launch: previous level in, level out (mean over 7 launches)
         "k_warp<false>": 3 * P + 4 * roi_px,   # frame in, warped u8x3 + mask out
         "k_warp<true>": 3 * P + 4 * roi_px,
-        "k_dt_diag": 1 * (C + roi_px) + 4 * (C + roi_px),      # mask in, two u16 step planes out (both jobs)
-        "k_dt_rows": 4 * (C + roi_px) + 4 * (C + roi_px),      # step planes in, row scan out
-        "k_dt_cols": 8 * (C + roi_px) + 4 * (C + roi_px),      # step planes + row scan in, distance out
-        "k_weights": 8 * roi_px + 8 * roi_px,
-        "k_blur_rows": 8 * roi_px + 8 * roi_px,
-        "k_blur_cols_commit": 8 * roi_px + 3 * roi_px + 2 * roi_px + 6 * roi_px,
+        "k_dt_diag_a": A + A / 4,              # mask in, one zero bit per pixel and orientation out
+        "k_dt_diag_b": A / 4 + 4 * A,          # bitmaps in, two u16 step planes out
+        "k_dt_rows": 4 * rows_px + 4 * rows_px,              # step planes in, u32 row scan out
+        "k_dt_cols_a": 4 * cols_px + cols_px / 4,            # step planes in, two u32 per 32-row chunk out
+        "k_dt_cols_b": 4 * win2 + 4 * win2 + 4 * win2 + cols_px / 4,  # steps + row scan + summaries in, f32 out
+        "k_blur_rows": 4 * roi_px + 4 * win + 8 * win,       # two distance planes in, two row-blurred weights out
+        "k_blur_cols_commit": 8 * win + 4 * roi_px + 6 * roi_px + roi_px,  # weights, warped+mask, canvas r/w, mask out
         "k_hamming_argmin": 2 * nkp * 32 * 2,
+        "k_rs_refine": nkp * 16,               # matched point pairs in (latency bound: fp64 solver chains)
     }
     return table.get(name)
 
@@ -106,6 +118,7 @@ def main():
     ap.add_argument("--config", default="720p_orb1000", choices=sorted(CONFIGS))
     ap.add_argument("--warp-mode", default="float", choices=["float", "fixed"])
     ap.add_argument("--batch", type=int, default=16, help="frames per rtvm_process_batch call (1..32)")
+    ap.add_argument("--single-stream", action="store_true", help="queue every batch on one HIP stream")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel timing table to this JSON file")
     args = ap.parse_args()
@@ -137,6 +150,8 @@ def main():
     torch.cuda.synchronize()
 
     flags = rtvm._ffi.FLAG_WARP_FIXED if args.warp_mode == "fixed" else 0
+    if args.single_stream:
+        flags |= rtvm._ffi.FLAG_SINGLE_STREAM
     ctx = rtvm.Context(fh, fw, ch, cw, nfeatures=nf, flags=flags, device=local_rank)
     row_off, col_off = ch - fh, int(cw / 2 - fw / 2)
     stride = fh * fw * 3
@@ -211,7 +226,8 @@ def main():
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.config, "frame": [fh, fw], "canvas": [ch, cw], "nfeatures": nf,
-                       "warp_mode": args.warp_mode, "batch": B, "streams": world, "parallelism": "one stream per GPU",
+                       "warp_mode": args.warp_mode, "batch": B, "hip_streams": 1 if args.single_stream else 2,
+                       "streams": world, "parallelism": "one stream per GPU",
                        "last_frame": {"status": st, "keypoints": nk, "matches": nm}},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -48,7 +48,9 @@ enum {
     RTVM_FLAG_WARP_FIXED = 1 << 0, /* warpPerspective arithmetic of OpenCV <= 4.10
                                       (1/32-pixel fixed point); default is the
                                       fp32 arithmetic of OpenCV >= 4.11 */
-    RTVM_FLAG_MATCH_LEGACY = 1 << 1 /* reserved: one-sided cross-check of OpenCV < 4.2 */
+    RTVM_FLAG_MATCH_LEGACY = 1 << 1, /* reserved: one-sided cross-check of OpenCV < 4.2 */
+    RTVM_FLAG_SINGLE_STREAM = 1 << 2 /* rtvm_process_batch queues everything on one HIP
+                                        stream (no overlap of consecutive batches) */
 };
 
 /* per-frame status bits reported by rtvm_process_frame / rtvm_frame_status */
@@ -144,18 +146,34 @@ int rtvm_stream_begin(rtvm_ctx* ctx, const uint8_t* bgr_dev, int row_off, int co
  * match, RANSAC, validate, smooth, chain, warp+blend, state advance, all queued on
  * the context's stream without a host round trip.  Asynchronous. */
 int rtvm_process_frame(rtvm_ctx* ctx, const uint8_t* bgr_dev);
-/* Room for batches of up to n frames (1..32) in rtvm_process_batch.  Allocates. */
+/* Room for batches of up to n frames (1..32) in rtvm_process_batch: two sets of n
+ * frame slots, so that two consecutive batches can be in flight.  Allocates. */
 int rtvm_reserve_batch(rtvm_ctx* ctx, int n);
 /* process_frame for n consecutive device-resident frames (bgr_dev: n device pointers
  * in a host array).  Detection, matching and RANSAC run for the whole batch at once,
  * the warp + blend frame by frame.  When a frame in the middle of the batch is
  * skipped (main.py:722-731) the later frames are left unprocessed with status
  * RTVM_FRAME_PENDING; rtvm_batch_status reports how many frames were consumed and
- * the caller resubmits the rest.  Asynchronous. */
+ * the caller resubmits the rest.  Asynchronous.
+ * Consecutive calls overlap on the device: detection, matching and RANSAC of a batch
+ * run on a second HIP stream while the previous batch is still being warped and
+ * blended.  The first frame of such a batch is matched against the last frame of the
+ * batch before it; when that frame turns out to be skipped, the whole later batch is
+ * left RTVM_FRAME_PENDING (0 frames consumed).  Reading a batch's status ends the
+ * overlap when it reports pending frames or a skipped last frame, so whatever is
+ * submitted next is matched against the last accepted frame (kp_prev/des_prev of
+ * main.py:757-758) and always consumes at least one frame. */
 int rtvm_process_batch(rtvm_ctx* ctx, const uint8_t* const* bgr_dev, int n);
 /* Of the most recent batch: frames consumed and, per frame (arrays of cap entries,
  * any may be NULL), status bits, match count, keypoint count.  Syncs the stream. */
 int rtvm_batch_status(rtvm_ctx* ctx, int* n_done, int* status, int* n_matches, int* n_keypoints, int cap);
+/* Same for the most recent batch (back = 0) or the one queued before it (back = 1),
+ * waiting for that batch only: a caller can keep one batch in flight while it reads
+ * the outcome of the other.  When the batch read left frames pending or skipped its
+ * last frame, the batch queued after it (if any) is pending as a whole; the call then
+ * waits for it too. */
+int rtvm_batch_status_at(rtvm_ctx* ctx, int back, int* n_done, int* status, int* n_matches,
+                         int* n_keypoints, int cap);
 /* Status bits, match count and the absolute homography of the most recent
  * rtvm_process_frame (any may be NULL).  Syncs the stream. */
 int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_matches, double H_abs[9]);

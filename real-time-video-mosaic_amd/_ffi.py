@@ -15,6 +15,7 @@ OK = 0
 E_ARG, E_HIP, E_NOMEM, E_DEGENERATE, E_STATE = -1, -2, -3, -4, -5
 DET_ORB, DET_SIFT_MATCH_ONLY = 0, 1
 FLAG_WARP_FIXED = 1
+FLAG_SINGLE_STREAM = 4
 FRAME_FEW_MATCHES, FRAME_NO_HOMOGRAPHY, FRAME_INVALID_H = 1, 2, 4
 
 # name -> (restype, argtypes); also the list the symbol-export test walks
@@ -48,6 +49,7 @@ SIGNATURES = {
     "rtvm_reserve_batch": (C.c_int, [_vp, C.c_int]),
     "rtvm_process_batch": (C.c_int, [_vp, _vp, C.c_int]),
     "rtvm_batch_status": (C.c_int, [_vp, _intp, _vp, _vp, _vp, C.c_int]),
+    "rtvm_batch_status_at": (C.c_int, [_vp, C.c_int, _intp, _vp, _vp, _vp, C.c_int]),
     "rtvm_first_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_frame_register": (C.c_int, [_vp, _vp, _intp, _intp, _vp]),
     "rtvm_frame_commit": (C.c_int, [_vp, _vp]),
@@ -319,27 +321,47 @@ class Context:
         arr = (C.c_void_p * n)(*bgr_dev_ptrs)
         self._check(lib().rtvm_process_batch(self._h, arr, n))
 
-    def batch_status(self, n):
-        """(frames consumed, status[n], matches[n], keypoints[n]) of the most recent batch.  Syncs."""
+    def batch_status(self, n, back=0):
+        """(frames consumed, status[n], matches[n], keypoints[n]) of the most recent batch
+        (back=0) or of the one queued before it (back=1).  Waits for that batch."""
         done = C.c_int(0)
         st = np.zeros(n, np.int32)
         nm = np.zeros(n, np.int32)
         nk = np.zeros(n, np.int32)
-        self._check(lib().rtvm_batch_status(self._h, C.byref(done), ptr(st), ptr(nm), ptr(nk), n))
+        self._check(lib().rtvm_batch_status_at(self._h, back, C.byref(done), ptr(st), ptr(nm), ptr(nk), n))
         return done.value, st, nm, nk
 
     def process_video(self, bgr_dev_ptrs, batch=16):
-        """process_frame over a whole list of device-resident frames in batches, resubmitting the
-        frames a skipped frame left pending.  Returns the per-frame status codes."""
+        """process_frame over a whole list of device-resident frames in batches, two batches
+        in flight, resubmitting the frames a skipped frame left pending.  Returns the
+        per-frame status codes."""
         self.reserve_batch(batch)
-        n, i = len(bgr_dev_ptrs), 0
+        n = len(bgr_dev_ptrs)
         status = np.zeros(n, np.int32)
-        while i < n:
-            k = min(batch, n - i)
-            self.process_batch(bgr_dev_ptrs[i:i + k])
-            done, st, _, _ = self.batch_status(k)
-            status[i:i + done] = st[:done]
-            i += max(done, 1)
+        inflight = []   # (first frame, length) of the queued batches, oldest first
+        nxt = 0         # next frame to queue
+        while nxt < n or inflight:
+            while len(inflight) < 2 and nxt < n:
+                k = min(batch, n - nxt)
+                self.process_batch(bgr_dev_ptrs[nxt:nxt + k])
+                inflight.append((nxt, k))
+                nxt += k
+            start, k = inflight.pop(0)
+            done, st, _, _ = self.batch_status(k, back=len(inflight))
+            status[start:start + done] = st[:done]
+            if done < k:
+                # a skipped frame left the rest of this batch pending, and with it whatever was
+                # queued behind: queue again from the first pending frame
+                inflight.clear()
+                nxt = start + done
+            elif inflight and st[k - 1] & (FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY):
+                # the last frame was skipped: a batch matched against it ahead of time comes
+                # back pending as a whole (0 frames consumed)
+                s2, k2 = inflight[0]
+                done2, _, _, _ = self.batch_status(k2, back=0)
+                if done2 == 0:
+                    inflight.clear()
+                    nxt = s2
         return status
 
     def frame_status(self):

@@ -117,7 +117,7 @@ int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int with_orb) {
         S.feat.count = c->d_mcount;
         S.prev.desc = c->d_mt;
         S.prev.count = c->d_mcount + 1;
-    } else if (slot == 0) {
+    } else if (slot % RTVM_MAX_BATCH == 0) {  // first of a set: bound again whenever a batch is queued
         S.prev = c->feat_prev;
     } else {
         S.prev = c->h_slots[slot - 1].feat;
@@ -132,9 +132,19 @@ int alloc_all(rtvm_ctx* c) {
     const int mk = RTVM_MAX_MATCH;
     int r;
     HIP_TRY(c, hipHostMalloc(&c->h_pinned, 1 << 16, hipHostMallocDefault));
-    c->h_slots = (FrameSlot*)calloc(RTVM_MAX_BATCH + 1, sizeof(FrameSlot));
+    memset(c->h_pinned, 0, 1 << 16);
+    c->h_rep = (BatchReport*)((char*)c->h_pinned + 16384);
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_rep, c->h_rep, 0));
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_front[k], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_back[k], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
+    }
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    c->spec_tail = -1;
+    c->h_slots = (FrameSlot*)calloc(RTVM_MAX_SLOTS + 1, sizeof(FrameSlot));
     if (!c->h_slots) RTVM_FAIL(c, RTVM_E_NOMEM, "host allocation failed");
-    ALLOC(c, d_slots, RTVM_MAX_BATCH + 1);
+    ALLOC(c, d_slots, RTVM_MAX_SLOTS + 1);
     // matcher staging
     ALLOC(c, d_mq, (size_t)mk * 32);
     ALLOC(c, d_mt, (size_t)mk * 32);
@@ -201,10 +211,16 @@ void free_all(rtvm_ctx* c) {
     free_feat(&c->feat_prev);
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    for (int i = 0; i <= RTVM_MAX_BATCH; i++)
+    for (int i = 0; i <= RTVM_MAX_SLOTS; i++)
         if (c->slot_arena[i]) (void)hipFree(c->slot_arena[i]);
     free(c->h_slots);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (int k = 0; k < 2; k++) {
+        if (c->ev_front[k]) (void)hipEventDestroy(c->ev_front[k]);
+        if (c->ev_back[k]) (void)hipEventDestroy(c->ev_back[k]);
+        if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+    }
+    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
 }
 
 }  // namespace
@@ -230,15 +246,22 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
     c->detector = detector;
     c->nfeatures = nfeatures;
     c->flags = flags;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream_main) != hipSuccess) {
         delete c;
         return RTVM_E_HIP;
     }
+    if (hipStreamCreate(&c->stream_front) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream_main);
+        delete c;
+        return RTVM_E_HIP;
+    }
+    c->stream = c->stream_main;
     int r = alloc_all(c);
     if (r != RTVM_OK) {
         fprintf(stderr, "rtvm_create: %s\n", c->err);
         free_all(c);
-        (void)hipStreamDestroy(c->stream);
+        (void)hipStreamDestroy(c->stream_front);
+        (void)hipStreamDestroy(c->stream_main);
         delete c;
         return r;
     }
@@ -249,10 +272,12 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
 extern "C" void rtvm_destroy(rtvm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream_front);
+    (void)hipStreamSynchronize(c->stream_main);
     rtvm_prof_free(c);
     free_all(c);
-    (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->stream_front);
+    (void)hipStreamDestroy(c->stream_main);
     delete c;
 }
 
@@ -260,7 +285,8 @@ extern "C" const char* rtvm_last_error(const rtvm_ctx* c) { return c ? c->err : 
 
 extern "C" int rtvm_sync(rtvm_ctx* c) {
     if (!c) return RTVM_E_ARG;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // every front half is followed by a canvas half on the main stream that waits for it
+    HIP_TRY(c, hipStreamSynchronize(c->stream_main));
     return RTVM_OK;
 }
 
@@ -386,6 +412,10 @@ extern "C" int rtvm_reserve_batch(rtvm_ctx* c, int n) {
     for (int s = c->n_batch; s < n; s++) {
         if ((r = rtvm_slots_alloc(c, s, c->orb.max_kp, 1))) return r;
         c->n_batch = s + 1;
+    }
+    for (int s = c->n_set1; s < n; s++) {
+        if ((r = rtvm_slots_alloc(c, RTVM_MAX_BATCH + s, c->orb.max_kp, 1))) return r;
+        c->n_set1 = s + 1;
     }
     return RTVM_OK;
 }
@@ -520,6 +550,3 @@ extern "C" int rtvm_canvas_read(rtvm_ctx* c, uint8_t* out) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RTVM_OK;
 }
-
-// ---- not yet implemented (stubs keep the ABI complete while stages land) ----
-#define RTVM_STUB(ctx) RTVM_FAIL(ctx, RTVM_E_STATE, "%s: not implemented yet", __func__)

@@ -78,7 +78,10 @@ struct FrameSlot {
 };
 
 #define RTVM_MAX_BATCH 32
-#define RTVM_STAGE_SLOT RTVM_MAX_BATCH   // slot used by the host-buffer matcher / RANSAC entry points
+// Two sets of batch slots (set k = slots k*RTVM_MAX_BATCH ...): while the canvas half of
+// one batch runs, the front half of the next batch fills the other set.
+#define RTVM_MAX_SLOTS (2 * RTVM_MAX_BATCH)
+#define RTVM_STAGE_SLOT RTVM_MAX_SLOTS   // slot used by the host-buffer matcher / RANSAC entry points
 
 // One distance-transform job: a rectangle of a mask plane and the planes the
 // scans write (all indexed y*pitch + x like the mask).
@@ -120,15 +123,43 @@ struct StreamState {
     int abort;         // a frame in the middle of a batch was skipped: later frames stay pending
     int n_done;        // frames of the last batch that were consumed (stitched or skipped)
     int last_good;     // batch index of the last frame that advanced the state, -1 if none
+    int tail_ok;       // the last frame of the last batch advanced the state (a batch whose front
+                       // half was matched against that frame ahead of time is valid)
     int b_status[RTVM_MAX_BATCH];
     int b_matches[RTVM_MAX_BATCH];
     int b_kp[RTVM_MAX_BATCH];
 };
 
+// What the caller reads back about one batch; written by the device into pinned host memory.
+struct BatchReport {
+    int n_done, abort, tail_ok, pad;
+    int status[RTVM_MAX_BATCH];
+    int matches[RTVM_MAX_BATCH];
+    int kp[RTVM_MAX_BATCH];
+};
+
+// frame pointers of a batch, passed to the binding kernel by value
+struct BatchPtrs {
+    const uint8_t* p[RTVM_MAX_BATCH];
+};
 
 struct rtvm_ctx {
     int device;
-    hipStream_t stream;
+    hipStream_t stream;        // stream the launch macros use right now (main or front)
+    hipStream_t stream_main;   // canvas half, host-buffer entry points, read-backs
+    hipStream_t stream_front;  // detect / match / RANSAC of a batch queued ahead of the canvas half
+    hipEvent_t ev_front[2];    // front half of the batch in slot set k is complete
+    hipEvent_t ev_back[2];     // canvas half of the batch that used slot set k is complete
+    hipEvent_t ev_done[2];     // batch number (seq & 1) is complete
+    hipEvent_t ev_main;
+    int back_rec[2];           // ev_back[k] has been recorded
+    int set_next;              // slot set of the next pipelined batch
+    int spec_tail;             // slot of the last frame of the batch queued before, -1 = none:
+                               // the next batch is matched against feat_prev after a full wait
+    long seq;                  // batches queued since the stream began
+    int n_set1;                // allocated slots of set 1
+    BatchReport* h_rep;        // [2] pinned, indexed by seq & 1
+    BatchReport* d_rep;        // device view of h_rep
     int fh, fw, ch, cw;
     int detector, nfeatures, flags;
     char err[512];
@@ -142,12 +173,11 @@ struct rtvm_ctx {
     uint16_t* d_xw;
     uint16_t* d_yofs;
     uint16_t* d_yw;
-    FrameSlot* h_slots;    // host mirror of d_slots (RTVM_MAX_BATCH + 1 entries)
+    FrameSlot* h_slots;    // host mirror of d_slots (RTVM_MAX_SLOTS + 1 entries)
     FrameSlot* d_slots;
-    void* slot_arena[RTVM_MAX_BATCH + 1];  // one device allocation per slot
-    int n_batch;           // slots 0..n_batch-1 are allocated
+    void* slot_arena[RTVM_MAX_SLOTS + 1];  // one device allocation per slot
+    int n_batch;           // slots 0..n_batch-1 of set 0 are allocated
     FeatSet feat_prev;     // features of the previous (last accepted) frame
-    const uint8_t** h_bgr_ptrs;  // frame pointers of the batch being queued
 
     // --- matcher staging for the host-buffer entry points ---
     uint8_t* d_mq;

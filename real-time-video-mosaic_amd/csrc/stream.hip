@@ -14,6 +14,13 @@
 // assumption that t would be accepted; when t is skipped in the middle of a batch,
 // the later frames of the batch are left untouched (RTVM_FRAME_PENDING) for the
 // caller to resubmit, so the result is the reference's for any batch size.
+//
+// Two streams: rtvm_process_batch queues the front half of a batch on the front stream
+// and the back half on the main stream, in two alternating sets of frame slots, so the
+// front half of batch k+1 (small grids, latency bound) overlaps the back half of batch
+// k (bandwidth bound).  Its first frame is then matched against the last frame of batch
+// k before that frame is known to be accepted; when it was not, batch k+1 is left
+// pending as a whole, exactly like the rest of a batch after a skipped frame.
 #include "common.h"
 
 #include <cmath>
@@ -65,10 +72,12 @@ __device__ bool validate_h(const double* H, double trans_thr, double scale_thr) 
 // "do not stitch" flag of every frame.
 __global__ void k_batch_glue(const FrameSlot* __restrict__ slots, int sb, int n, StreamState* __restrict__ st,
                              const double* __restrict__ wtab, double* __restrict__ H_out, int* __restrict__ skip,
-                             double trans_thr, double scale_thr) {
+                             double trans_thr, double scale_thr, int ahead, BatchReport* __restrict__ rep) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int n_done = 0, last_good = -1;
     bool abort = st->abort != 0;
+    // matched ahead of time against a frame that did not advance the state
+    if (ahead && !st->tail_ok) abort = true;
     for (int j = 0; j < n; j++) {
         const FrameSlot& S = slots[sb + j];
         skip[j] = 1;
@@ -139,6 +148,23 @@ __global__ void k_batch_glue(const FrameSlot* __restrict__ slots, int sb, int n,
     st->abort = abort ? 1 : 0;
     st->n_done = n_done;
     st->last_good = last_good;
+    st->tail_ok = (!abort && last_good == n - 1) ? 1 : 0;
+    rep->n_done = n_done;
+    rep->abort = st->abort;
+    rep->tail_ok = st->tail_ok;
+    for (int j = 0; j < n; j++) {
+        rep->status[j] = st->b_status[j];
+        rep->matches[j] = st->b_matches[j];
+        rep->kp[j] = st->b_kp[j];
+    }
+}
+
+// Publishes the frame pointers of a batch and the feature set its first frame is matched
+// against to the device copies of the slots.
+__global__ void k_batch_bind(FrameSlot* __restrict__ slots, int sb, int n, BatchPtrs ptrs, FeatSet prev) {
+    const int j = threadIdx.x;
+    if (j < n) slots[sb + j].bgr = ptrs.p[j];
+    if (j == 0) slots[sb].prev = prev;
 }
 
 __device__ __forceinline__ void copy_feat(const FeatSet& cur, const FeatSet& prev, int i, int n) {
@@ -191,6 +217,7 @@ __global__ void k_state_init(StreamState* st, int row_off, int col_off, int* ski
     st->abort = 0;
     st->n_done = 0;
     st->last_good = -1;
+    st->tail_ok = 1;
     for (int j = 0; j < RTVM_MAX_BATCH; j++) skip[j] = 0;
 }
 
@@ -201,32 +228,35 @@ int need_stream_ctx(rtvm_ctx* c, const char* who) {
     return RTVM_OK;
 }
 
-// Publishes the frame pointers of a batch to the device copies of the slots.
-int set_frame_ptrs(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
+// Binds the frames of a batch (and the train side of its first frame) to slots sb .. sb+n-1
+// on the current stream.
+int bind_batch(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, const FeatSet& prev) {
+    BatchPtrs bp;
+    memset(&bp, 0, sizeof(bp));
     for (int j = 0; j < n; j++) {
         if (!ptrs[j]) RTVM_FAIL(c, RTVM_E_ARG, "null frame pointer at batch index %d", j);
-        if (c->h_slots[j].bgr != ptrs[j]) {
-            c->h_slots[j].bgr = ptrs[j];
-            HIP_TRY(c, hipMemcpyAsync(&c->d_slots[j].bgr, &c->h_slots[j].bgr, sizeof(uint8_t*), hipMemcpyHostToDevice,
-                                      c->stream));
-        }
+        bp.p[j] = ptrs[j];
+        c->h_slots[sb + j].bgr = ptrs[j];
     }
+    RTVM_LAUNCH(c, k_batch_bind, dim3(1), dim3(64), 0, c->d_slots, sb, n, bp, prev);
     return RTVM_OK;
 }
 
-// detect + match against the previous frame + gather points + RANSAC for slots 0..n-1
-int queue_front_half(rtvm_ctx* c, int n) {
+// detect + match against the previous frame + gather points + RANSAC for slots sb..sb+n-1
+int queue_front_half(rtvm_ctx* c, int sb, int n) {
     int r;
-    if ((r = rtvm_launch_orb(c, 0, n))) return r;
+    if ((r = rtvm_launch_orb(c, sb, n))) return r;
     const int cap = c->orb.max_kp;
-    if ((r = rtvm_launch_hamming(c, 0, n, cap, cap, 1))) return r;
-    RTVM_LAUNCH(c, k_gather_pts, dim3((cap + 255) / 256, n), dim3(256), 0, c->d_slots, 0);
-    return rtvm_launch_ransac(c, 0, n, 2.0, 2000, 0.995);
+    if ((r = rtvm_launch_hamming(c, sb, n, cap, cap, 1))) return r;
+    RTVM_LAUNCH(c, k_gather_pts, dim3((cap + 255) / 256, n), dim3(256), 0, c->d_slots, sb);
+    return rtvm_launch_ransac(c, sb, n, 2.0, 2000, 0.995);
 }
 
 int queue_first_frame(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_off) {
     int r;
-    if ((r = set_frame_ptrs(c, &d_bgr, 1))) return r;
+    c->spec_tail = -1;
+    c->seq = 0;
+    if ((r = bind_batch(c, 0, &d_bgr, 1, c->feat_prev))) return r;
     if ((r = rtvm_launch_orb(c, 0, 1))) return r;
     RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
                 c->feat_prev, c->orb.max_kp);
@@ -237,20 +267,69 @@ int queue_first_frame(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_of
     return RTVM_OK;
 }
 
-int queue_batch(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
+// glue + warp/blend of every frame + kp_prev/des_prev update, on the main stream
+int queue_back_half(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, int ahead) {
+    int r;
+    c->seq += 1;
+    const int slot = (int)(c->seq & 1);
+    RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
+                50.0, 0.3, ahead, c->d_rep + slot);
+    for (int j = 0; j < n; j++)
+        if ((r = rtvm_launch_warp_blend(c, ptrs[j], c->d_H + 9 * j, c->d_skip + j))) return r;
+    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, sb, c->d_state, -1,
+                c->feat_prev, c->orb.max_kp);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->stream_main));
+    return RTVM_OK;
+}
+
+// The launch macros use c->stream; this points it at the front stream for a scope.
+struct FrontScope {
+    rtvm_ctx* c;
+    explicit FrontScope(rtvm_ctx* ctx) : c(ctx) { c->stream = c->stream_front; }
+    ~FrontScope() { c->stream = c->stream_main; }
+};
+
+// One batch on the main stream only, in slot set 0, matched against feat_prev.
+int queue_batch_serial(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
     int r;
     if (n < 1 || n > c->n_batch)
         RTVM_FAIL(c, RTVM_E_ARG, "batch of %d frames: reserve it first (rtvm_reserve_batch), at most %d", n,
                   RTVM_MAX_BATCH);
-    if ((r = set_frame_ptrs(c, ptrs, n))) return r;
-    if ((r = queue_front_half(c, n))) return r;
-    RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, 0, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
-                50.0, 0.3);
-    for (int j = 0; j < n; j++)
-        if ((r = rtvm_launch_warp_blend(c, ptrs[j], c->d_H + 9 * j, c->d_skip + j))) return r;
-    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, -1,
-                c->feat_prev, c->orb.max_kp);
-    HIP_TRY(c, hipGetLastError());
+    c->spec_tail = -1;
+    if ((r = bind_batch(c, 0, ptrs, n, c->feat_prev))) return r;
+    if ((r = queue_front_half(c, 0, n))) return r;
+    return queue_back_half(c, 0, ptrs, n, 0);
+}
+
+// One batch with its front half on the front stream.
+int queue_batch_overlapped(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
+    int r;
+    if (n < 1 || n > c->n_batch || n > c->n_set1)
+        RTVM_FAIL(c, RTVM_E_ARG, "batch of %d frames: reserve it first (rtvm_reserve_batch), at most %d", n,
+                  RTVM_MAX_BATCH);
+    const int set = c->set_next, sb = set * RTVM_MAX_BATCH;
+    const int ahead = c->spec_tail >= 0 ? 1 : 0;
+    if (ahead) {
+        // the batch that used this slot set before must have left it
+        if (c->back_rec[set]) HIP_TRY(c, hipStreamWaitEvent(c->stream_front, c->ev_back[set], 0));
+    } else {
+        // feat_prev is written on the main stream: wait for everything queued there
+        HIP_TRY(c, hipEventRecord(c->ev_main, c->stream_main));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream_front, c->ev_main, 0));
+    }
+    {
+        FrontScope fs(c);
+        if ((r = bind_batch(c, sb, ptrs, n, ahead ? c->h_slots[c->spec_tail].feat : c->feat_prev))) return r;
+        if ((r = queue_front_half(c, sb, n))) return r;
+        HIP_TRY(c, hipEventRecord(c->ev_front[set], c->stream_front));
+    }
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_main, c->ev_front[set], 0));
+    if ((r = queue_back_half(c, sb, ptrs, n, ahead))) return r;
+    HIP_TRY(c, hipEventRecord(c->ev_back[set], c->stream_main));
+    c->back_rec[set] = 1;
+    c->spec_tail = sb + n - 1;
+    c->set_next = set ^ 1;
     return RTVM_OK;
 }
 
@@ -299,7 +378,7 @@ extern "C" int rtvm_process_frame(rtvm_ctx* c, const uint8_t* bgr_dev) {
     if (r) return r;
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "process_frame: call rtvm_stream_begin first");
     HIP_TRY(c, hipSetDevice(c->device));
-    return queue_batch(c, &bgr_dev, 1);
+    return queue_batch_serial(c, &bgr_dev, 1);
 }
 
 extern "C" int rtvm_process_batch(rtvm_ctx* c, const uint8_t* const* bgr_dev, int n) {
@@ -309,7 +388,8 @@ extern "C" int rtvm_process_batch(rtvm_ctx* c, const uint8_t* const* bgr_dev, in
     if (r) return r;
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "process_batch: call rtvm_stream_begin first");
     HIP_TRY(c, hipSetDevice(c->device));
-    return queue_batch(c, bgr_dev, n);
+    if (n >= 1 && n <= c->n_set1 && !(c->flags & RTVM_FLAG_SINGLE_STREAM)) return queue_batch_overlapped(c, bgr_dev, n);
+    return queue_batch_serial(c, bgr_dev, n);
 }
 
 static int read_state(rtvm_ctx* c, StreamState** hs_out) {
@@ -320,23 +400,37 @@ static int read_state(rtvm_ctx* c, StreamState** hs_out) {
     return RTVM_OK;
 }
 
-extern "C" int rtvm_batch_status(rtvm_ctx* c, int* n_done, int* status, int* n_matches, int* n_keypoints, int cap) {
+// back = 0: the batch queued last; back = 1: the one before it (waits for that batch only,
+// so the caller can keep one batch in flight while it reads the other's outcome).
+extern "C" int rtvm_batch_status_at(rtvm_ctx* c, int back, int* n_done, int* status, int* n_matches,
+                                    int* n_keypoints, int cap) {
     if (!c) return RTVM_E_ARG;
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "batch_status: no stream");
+    if (back < 0 || back > 1 || c->seq - back < 1)
+        RTVM_FAIL(c, RTVM_E_STATE, "batch_status: no batch %d before the last one (%ld queued)", back, c->seq);
     HIP_TRY(c, hipSetDevice(c->device));
-    StreamState* hs;
-    int r = read_state(c, &hs);
-    if (r) return r;
-    if (n_done) *n_done = hs->n_done;
+    const int slot = (int)((c->seq - back) & 1);
+    HIP_TRY(c, hipEventSynchronize(c->ev_done[slot]));
+    const BatchReport* rep = c->h_rep + slot;
+    if (n_done) *n_done = rep->n_done;
     for (int j = 0; j < cap && j < RTVM_MAX_BATCH; j++) {
-        if (status) status[j] = hs->b_status[j];
-        if (n_matches) n_matches[j] = hs->b_matches[j];
-        if (n_keypoints) n_keypoints[j] = hs->b_kp[j];
+        if (status) status[j] = rep->status[j];
+        if (n_matches) n_matches[j] = rep->matches[j];
+        if (n_keypoints) n_keypoints[j] = rep->kp[j];
     }
-    if (hs->abort) {  // the caller now knows; frames resubmitted from here on are processed again
-        HIP_TRY(c, hipMemsetAsync(&c->d_state->abort, 0, sizeof(int), c->stream));
+    if (rep->abort || !rep->tail_ok) {
+        // Frames were left pending, or the last frame did not advance the state: whatever
+        // was queued after this batch is pending as a whole.  Drain it; the caller now
+        // knows, and what it submits next is matched against the last accepted frame.
+        HIP_TRY(c, hipStreamSynchronize(c->stream_main));
+        HIP_TRY(c, hipMemsetAsync(&c->d_state->abort, 0, sizeof(int), c->stream_main));
+        c->spec_tail = -1;
     }
     return RTVM_OK;
+}
+
+extern "C" int rtvm_batch_status(rtvm_ctx* c, int* n_done, int* status, int* n_matches, int* n_keypoints, int cap) {
+    return rtvm_batch_status_at(c, 0, n_done, status, n_matches, n_keypoints, cap);
 }
 
 extern "C" int rtvm_frame_status(rtvm_ctx* c, int* status, int* n_keypoints, int* n_matches, double H_abs[9]) {
@@ -365,8 +459,9 @@ extern "C" int rtvm_frame_register(rtvm_ctx* c, const uint8_t* bgr, int* n_match
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
     const uint8_t* p = c->d_bgr;
-    if ((r = set_frame_ptrs(c, &p, 1))) return r;
-    if ((r = queue_front_half(c, 1))) return r;
+    c->spec_tail = -1;
+    if ((r = bind_batch(c, 0, &p, 1, c->feat_prev))) return r;
+    if ((r = queue_front_half(c, 0, 1))) return r;
     const FrameSlot& S = c->h_slots[0];
     int* hc = (int*)c->h_pinned;
     double* hH = (double*)c->h_pinned + 8;
@@ -435,7 +530,8 @@ int rtvm_orb_host(rtvm_ctx* c, const uint8_t* bgr, int* n_out, float* xy, float*
     HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
     const uint8_t* p = c->d_bgr;
     int r;
-    if ((r = set_frame_ptrs(c, &p, 1))) return r;
+    c->spec_tail = -1;
+    if ((r = bind_batch(c, 0, &p, 1, c->feat_prev))) return r;
     if ((r = rtvm_launch_orb(c, 0, 1))) return r;
     if (gray) {
         HIP_TRY(c, hipMemcpy2DAsync(gray, c->fw, c->h_slots[0].pyr + c->orb.off[0], c->orb.pitch[0], c->fw, c->fh,

@@ -154,15 +154,17 @@ def test_device_stream_path_matches_oracle(fixed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch", [1, 4, 7])
-def test_batched_stream_matches_oracle(batch):
+@pytest.mark.parametrize("batch,flags", [(1, 0), (3, 0), (4, 0), (6, 0), (7, 0), (4, 4), (6, 4)])
+def test_batched_stream_matches_oracle(batch, flags):
     """rtvm_process_batch: same canvas and homography as frame-by-frame processing, including a
-    skipped frame in the middle of a batch (later frames come back as pending and are resubmitted)."""
+    skipped frame in the middle of a batch (later frames come back as pending and are resubmitted)
+    and at the end of a batch (the batch queued ahead of it comes back pending as a whole).
+    flags 4 = everything on one stream."""
     import torch
     frames, _ = video(12, seed=6)
     order = [1, 2, 3, 4, 5, "flat", 6, 7, 8, 9, 10, 11]
     seq = [np.full_like(frames[0], 90) if s == "flat" else frames[s] for s in order]
-    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=500)
+    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=500, flags=flags)
     om = OracleMosaic(frames[0], nfeatures=500, glue="explicit")
     first = torch.from_numpy(frames[0]).cuda()
     dev = [torch.from_numpy(f).cuda() for f in seq]
@@ -177,4 +179,47 @@ def test_batched_stream_matches_oracle(batch):
     st, nk, nm, H = ctx.frame_status()
     assert np.array_equal(H, om.H)
     assert np.array_equal(ctx.canvas_read(), om.canvas)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_batches_queued_back_to_back():
+    """Batches queued without reading any status in between (two in flight on two streams):
+    same canvas as frame-by-frame processing; after a skipped frame everything later is pending."""
+    import torch
+    frames, _ = video(13, seed=8)
+    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=500)
+    om = OracleMosaic(frames[0], nfeatures=500, glue="explicit")
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    flat = torch.full_like(dev[0], 90)
+    torch.cuda.synchronize()
+    ctx.reserve_batch(4)
+    ctx.stream_begin(dev[0].data_ptr(), om.w_offset, om.h_offset)
+    for b in range(3):
+        ctx.process_batch([dev[1 + 4 * b + j].data_ptr() for j in range(4)])
+    done1, st1, _, _ = ctx.batch_status(4, back=1)
+    done0, st0, _, _ = ctx.batch_status(4, back=0)
+    assert done1 == 4 and done0 == 4 and not st1.any() and not st0.any()
+    for f in frames[1:13]:
+        om.process_frame(f)
+    st, nk, nm, H = ctx.frame_status()
+    assert np.array_equal(H, om.H)
+    assert np.array_equal(ctx.canvas_read(), om.canvas)
+    # a skipped frame at the end of a batch voids the two batches queued behind it
+    ctx.stream_begin(dev[0].data_ptr(), om.w_offset, om.h_offset)
+    ctx.process_batch([dev[1].data_ptr(), dev[2].data_ptr(), flat.data_ptr()])
+    ctx.process_batch([dev[3].data_ptr(), dev[4].data_ptr()])
+    ctx.process_batch([dev[5].data_ptr(), dev[6].data_ptr()])
+    done, stl, _, _ = ctx.batch_status(2, back=0)
+    assert done == 0 and stl.tolist() == [8, 8]
+    # the status read ended the overlap: the next batch is matched against frame 2
+    ctx.process_batch([dev[3].data_ptr(), dev[4].data_ptr()])
+    done, stl, _, _ = ctx.batch_status(2)
+    assert done == 2 and stl.tolist() == [0, 0]
+    om2 = OracleMosaic(frames[0], nfeatures=500, glue="explicit")
+    for f in (frames[1], frames[2], np.full_like(frames[0], 90), frames[3], frames[4]):
+        om2.process_frame(f)
+    st, nk, nm, H = ctx.frame_status()
+    assert np.array_equal(H, om2.H)
+    assert np.array_equal(ctx.canvas_read(), om2.canvas)
     ctx.close()
