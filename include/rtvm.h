@@ -146,8 +146,8 @@ int rtvm_stream_begin(rtvm_ctx* ctx, const uint8_t* bgr_dev, int row_off, int co
  * match, RANSAC, validate, smooth, chain, warp+blend, state advance, all queued on
  * the context's stream without a host round trip.  Asynchronous. */
 int rtvm_process_frame(rtvm_ctx* ctx, const uint8_t* bgr_dev);
-/* Room for batches of up to n frames (1..32) in rtvm_process_batch: two sets of n
- * frame slots, so that two consecutive batches can be in flight.  Allocates. */
+/* Room for batches of up to n frames (1..32) in rtvm_process_batch: three sets of n
+ * frame slots, so that three consecutive batches can be in flight.  Allocates. */
 int rtvm_reserve_batch(rtvm_ctx* ctx, int n);
 /* process_frame for n consecutive device-resident frames (bgr_dev: n device pointers
  * in a host array).  Detection, matching and RANSAC run for the whole batch at once,
@@ -155,9 +155,9 @@ int rtvm_reserve_batch(rtvm_ctx* ctx, int n);
  * skipped (main.py:722-731) the later frames are left unprocessed with status
  * RTVM_FRAME_PENDING; rtvm_batch_status reports how many frames were consumed and
  * the caller resubmits the rest.  Asynchronous.
- * Consecutive calls overlap on the device: detection, matching and RANSAC of a batch
- * run on a second HIP stream while the previous batch is still being warped and
- * blended.  The first frame of such a batch is matched against the last frame of the
+ * Consecutive calls overlap on the device: detection + matching and RANSAC of later
+ * batches run on HIP streams of their own while an earlier batch is still being warped
+ * and blended (up to three batches in flight).  The first frame of such a batch is matched against the last frame of the
  * batch before it; when that frame turns out to be skipped, the whole later batch is
  * left RTVM_FRAME_PENDING (0 frames consumed).  Reading a batch's status ends the
  * overlap when it reports pending frames or a skipped last frame, so whatever is
@@ -167,11 +167,11 @@ int rtvm_process_batch(rtvm_ctx* ctx, const uint8_t* const* bgr_dev, int n);
 /* Of the most recent batch: frames consumed and, per frame (arrays of cap entries,
  * any may be NULL), status bits, match count, keypoint count.  Syncs the stream. */
 int rtvm_batch_status(rtvm_ctx* ctx, int* n_done, int* status, int* n_matches, int* n_keypoints, int cap);
-/* Same for the most recent batch (back = 0) or the one queued before it (back = 1),
- * waiting for that batch only: a caller can keep one batch in flight while it reads
- * the outcome of the other.  When the batch read left frames pending or skipped its
- * last frame, the batch queued after it (if any) is pending as a whole; the call then
- * waits for it too. */
+/* Same for the most recent batch (back = 0) or the ones queued before it (back = 1, 2),
+ * waiting for that batch only: a caller can keep two batches in flight while it reads
+ * the outcome of a third.  When the batch read left frames pending or skipped its
+ * last frame, the batches queued after it (if any) are pending as a whole; the call
+ * then waits for them too. */
 int rtvm_batch_status_at(rtvm_ctx* ctx, int back, int* n_done, int* status, int* n_matches,
                          int* n_keypoints, int cap);
 /* Status bits, match count and the absolute homography of the most recent

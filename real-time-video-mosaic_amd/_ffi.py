@@ -294,15 +294,16 @@ class Context:
         self._check(lib().rtvm_profile_start(self._h, name_filter.encode() if name_filter else None))
 
     def profile_stop(self):
-        """Returns {kernel name: (launches, total_ms)}."""
+        """Returns {kernel name: (launches, total_ms, stream)}; stream 0 = main (canvas half),
+        1 = detection + matching, 2 = RANSAC."""
         self._check(lib().rtvm_profile_stop(self._h))
         n = lib().rtvm_profile_report(self._h, None, 0)
         buf = C.create_string_buffer(n + 16)
         lib().rtvm_profile_report(self._h, buf, n + 16)
         out = {}
         for line in buf.value.decode().splitlines():
-            name, cnt, ms = line.rsplit(" ", 2)
-            out[name] = (int(cnt), float(ms))
+            name, cnt, ms, stream = line.rsplit(" ", 3)
+            out[name] = (int(cnt), float(ms), int(stream))
         return out
 
     # ---- device-resident stream path -------------------------------------
@@ -323,7 +324,7 @@ class Context:
 
     def batch_status(self, n, back=0):
         """(frames consumed, status[n], matches[n], keypoints[n]) of the most recent batch
-        (back=0) or of the one queued before it (back=1).  Waits for that batch."""
+        (back=0) or of the ones queued before it (back=1, 2).  Waits for that batch."""
         done = C.c_int(0)
         st = np.zeros(n, np.int32)
         nm = np.zeros(n, np.int32)
@@ -332,7 +333,7 @@ class Context:
         return done.value, st, nm, nk
 
     def process_video(self, bgr_dev_ptrs, batch=16):
-        """process_frame over a whole list of device-resident frames in batches, two batches
+        """process_frame over a whole list of device-resident frames in batches, three batches
         in flight, resubmitting the frames a skipped frame left pending.  Returns the
         per-frame status codes."""
         self.reserve_batch(batch)
@@ -341,7 +342,7 @@ class Context:
         inflight = []   # (first frame, length) of the queued batches, oldest first
         nxt = 0         # next frame to queue
         while nxt < n or inflight:
-            while len(inflight) < 2 and nxt < n:
+            while len(inflight) < 3 and nxt < n:
                 k = min(batch, n - nxt)
                 self.process_batch(bgr_dev_ptrs[nxt:nxt + k])
                 inflight.append((nxt, k))
@@ -358,7 +359,7 @@ class Context:
                 # the last frame was skipped: a batch matched against it ahead of time comes
                 # back pending as a whole (0 frames consumed)
                 s2, k2 = inflight[0]
-                done2, _, _, _ = self.batch_status(k2, back=0)
+                done2, _, _, _ = self.batch_status(k2, back=len(inflight) - 1)
                 if done2 == 0:
                     inflight.clear()
                     nxt = s2

@@ -135,11 +135,12 @@ int alloc_all(rtvm_ctx* c) {
     memset(c->h_pinned, 0, 1 << 16);
     c->h_rep = (BatchReport*)((char*)c->h_pinned + 16384);
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_rep, c->h_rep, 0));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < RTVM_NSETS; k++) {
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_feat[k], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_front[k], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_back[k], hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
     }
+    for (int k = 0; k < 4; k++) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     c->spec_tail = -1;
     c->h_slots = (FrameSlot*)calloc(RTVM_MAX_SLOTS + 1, sizeof(FrameSlot));
@@ -215,11 +216,13 @@ void free_all(rtvm_ctx* c) {
         if (c->slot_arena[i]) (void)hipFree(c->slot_arena[i]);
     free(c->h_slots);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < RTVM_NSETS; k++) {
+        if (c->ev_feat[k]) (void)hipEventDestroy(c->ev_feat[k]);
         if (c->ev_front[k]) (void)hipEventDestroy(c->ev_front[k]);
         if (c->ev_back[k]) (void)hipEventDestroy(c->ev_back[k]);
-        if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
     }
+    for (int k = 0; k < 4; k++)
+        if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
 }
 
@@ -255,11 +258,18 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
         delete c;
         return RTVM_E_HIP;
     }
+    if (hipStreamCreate(&c->stream_rs) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream_front);
+        (void)hipStreamDestroy(c->stream_main);
+        delete c;
+        return RTVM_E_HIP;
+    }
     c->stream = c->stream_main;
     int r = alloc_all(c);
     if (r != RTVM_OK) {
         fprintf(stderr, "rtvm_create: %s\n", c->err);
         free_all(c);
+        (void)hipStreamDestroy(c->stream_rs);
         (void)hipStreamDestroy(c->stream_front);
         (void)hipStreamDestroy(c->stream_main);
         delete c;
@@ -273,9 +283,11 @@ extern "C" void rtvm_destroy(rtvm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream_front);
+    (void)hipStreamSynchronize(c->stream_rs);
     (void)hipStreamSynchronize(c->stream_main);
     rtvm_prof_free(c);
     free_all(c);
+    (void)hipStreamDestroy(c->stream_rs);
     (void)hipStreamDestroy(c->stream_front);
     (void)hipStreamDestroy(c->stream_main);
     delete c;
@@ -414,7 +426,8 @@ extern "C" int rtvm_reserve_batch(rtvm_ctx* c, int n) {
         c->n_batch = s + 1;
     }
     for (int s = c->n_set1; s < n; s++) {
-        if ((r = rtvm_slots_alloc(c, RTVM_MAX_BATCH + s, c->orb.max_kp, 1))) return r;
+        for (int k = 1; k < RTVM_NSETS; k++)
+            if ((r = rtvm_slots_alloc(c, k * RTVM_MAX_BATCH + s, c->orb.max_kp, 1))) return r;
         c->n_set1 = s + 1;
     }
     return RTVM_OK;

@@ -78,9 +78,11 @@ struct FrameSlot {
 };
 
 #define RTVM_MAX_BATCH 32
-// Two sets of batch slots (set k = slots k*RTVM_MAX_BATCH ...): while the canvas half of
-// one batch runs, the front half of the next batch fills the other set.
-#define RTVM_MAX_SLOTS (2 * RTVM_MAX_BATCH)
+// Three sets of batch slots (set k = slots k*RTVM_MAX_BATCH ...): while the canvas half of
+// one batch runs, RANSAC of the next batch and detection + matching of the one after it
+// work in the other two sets.
+#define RTVM_NSETS 3
+#define RTVM_MAX_SLOTS (RTVM_NSETS * RTVM_MAX_BATCH)
 #define RTVM_STAGE_SLOT RTVM_MAX_SLOTS   // slot used by the host-buffer matcher / RANSAC entry points
 
 // One distance-transform job: a rectangle of a mask plane and the planes the
@@ -145,20 +147,22 @@ struct BatchPtrs {
 
 struct rtvm_ctx {
     int device;
-    hipStream_t stream;        // stream the launch macros use right now (main or front)
+    hipStream_t stream;        // stream the launch macros use right now
     hipStream_t stream_main;   // canvas half, host-buffer entry points, read-backs
-    hipStream_t stream_front;  // detect / match / RANSAC of a batch queued ahead of the canvas half
-    hipEvent_t ev_front[2];    // front half of the batch in slot set k is complete
-    hipEvent_t ev_back[2];     // canvas half of the batch that used slot set k is complete
-    hipEvent_t ev_done[2];     // batch number (seq & 1) is complete
+    hipStream_t stream_front;  // detection + matching of a batch queued ahead of the canvas half
+    hipStream_t stream_rs;     // RANSAC of a batch queued ahead of the canvas half
+    hipEvent_t ev_feat[RTVM_NSETS];   // detection + matching of the batch in slot set k is complete
+    hipEvent_t ev_front[RTVM_NSETS];  // RANSAC of the batch in slot set k is complete
+    hipEvent_t ev_back[RTVM_NSETS];   // canvas half of the batch that used slot set k is complete
+    hipEvent_t ev_done[4];     // batch number (seq & 3) is complete
     hipEvent_t ev_main;
-    int back_rec[2];           // ev_back[k] has been recorded
+    int back_rec[RTVM_NSETS];  // ev_back[k] has been recorded
     int set_next;              // slot set of the next pipelined batch
     int spec_tail;             // slot of the last frame of the batch queued before, -1 = none:
                                // the next batch is matched against feat_prev after a full wait
     long seq;                  // batches queued since the stream began
-    int n_set1;                // allocated slots of set 1
-    BatchReport* h_rep;        // [2] pinned, indexed by seq & 1
+    int n_set1;                // allocated slots of each of the sets 1 .. RTVM_NSETS-1
+    BatchReport* h_rep;        // [4] pinned, indexed by seq & 3
     BatchReport* d_rep;        // device view of h_rep
     int fh, fw, ch, cw;
     int detector, nfeatures, flags;

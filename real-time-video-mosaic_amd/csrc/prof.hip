@@ -15,6 +15,7 @@ struct Prof {
     std::vector<std::string> names;
     std::vector<double> sum_ms;
     std::vector<long> count;
+    std::vector<int> stream;   // 0 main, 1 detection + matching, 2 RANSAC
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
 };
@@ -45,7 +46,9 @@ int rtvm_prof_begin(rtvm_ctx* c, const char* name) {
         p->names.push_back(name);
         p->sum_ms.push_back(0);
         p->count.push_back(0);
+        p->stream.push_back(0);
     }
+    p->stream[idx] = c->stream == c->stream_front ? 1 : c->stream == c->stream_rs ? 2 : 0;
     Rec r{idx, take_event(p), take_event(p)};
     if (!r.e0 || !r.e1) return -1;
     (void)hipEventRecord(r.e0, c->stream);
@@ -89,7 +92,9 @@ extern "C" int rtvm_profile_start(rtvm_ctx* c, const char* filter) {
 extern "C" int rtvm_profile_stop(rtvm_ctx* c) {
     if (!c) return RTVM_E_ARG;
     c->prof_mode = 0;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream_front));
+    HIP_TRY(c, hipStreamSynchronize(c->stream_rs));
+    HIP_TRY(c, hipStreamSynchronize(c->stream_main));
     Prof* p = get(c);
     for (auto& r : p->recs) {
         float ms = 0;
@@ -104,7 +109,9 @@ extern "C" int rtvm_profile_stop(rtvm_ctx* c) {
     return RTVM_OK;
 }
 
-// One line per kernel: "name count total_ms".  Returns the number of bytes needed.
+// One line per kernel: "name count total_ms stream" (stream: 0 = main, 1 = detection +
+// matching, 2 = RANSAC; the stream of the kernel's last launch).  Returns the number of
+// bytes needed.
 extern "C" int rtvm_profile_report(rtvm_ctx* c, char* buf, int buflen) {
     if (!c) return RTVM_E_ARG;
     Prof* p = get(c);
@@ -112,7 +119,7 @@ extern "C" int rtvm_profile_report(rtvm_ctx* c, char* buf, int buflen) {
     char line[256];
     for (size_t i = 0; i < p->names.size(); i++) {
         if (!p->count[i]) continue;
-        snprintf(line, sizeof(line), "%s %ld %.6f\n", p->names[i].c_str(), p->count[i], p->sum_ms[i]);
+        snprintf(line, sizeof(line), "%s %ld %.6f %d\n", p->names[i].c_str(), p->count[i], p->sum_ms[i], p->stream[i]);
         out += line;
     }
     if (buf && buflen > 0) {

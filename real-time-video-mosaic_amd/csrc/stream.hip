@@ -15,11 +15,12 @@
 // the later frames of the batch are left untouched (RTVM_FRAME_PENDING) for the
 // caller to resubmit, so the result is the reference's for any batch size.
 //
-// Two streams: rtvm_process_batch queues the front half of a batch on the front stream
-// and the back half on the main stream, in two alternating sets of frame slots, so the
-// front half of batch k+1 (small grids, latency bound) overlaps the back half of batch
-// k (bandwidth bound).  Its first frame is then matched against the last frame of batch
-// k before that frame is known to be accepted; when it was not, batch k+1 is left
+// Three streams: rtvm_process_batch queues detection + matching of a batch on the front
+// stream, its RANSAC on a second stream and the back half on the main stream, cycling
+// through three sets of frame slots, so detection of batch k+2 and RANSAC of batch k+1
+// (small grids, latency bound) overlap the back half of batch k (bandwidth bound).  The
+// first frame of a batch is then matched against the last frame of the batch before it
+// before that frame is known to be accepted; when it was not, the later batch is left
 // pending as a whole, exactly like the rest of a batch after a skipped frame.
 #include "common.h"
 
@@ -242,13 +243,20 @@ int bind_batch(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, const Fea
     return RTVM_OK;
 }
 
-// detect + match against the previous frame + gather points + RANSAC for slots sb..sb+n-1
-int queue_front_half(rtvm_ctx* c, int sb, int n) {
+// detect + match against the previous frame + gather points for slots sb..sb+n-1
+int queue_features(rtvm_ctx* c, int sb, int n) {
     int r;
     if ((r = rtvm_launch_orb(c, sb, n))) return r;
     const int cap = c->orb.max_kp;
     if ((r = rtvm_launch_hamming(c, sb, n, cap, cap, 1))) return r;
     RTVM_LAUNCH(c, k_gather_pts, dim3((cap + 255) / 256, n), dim3(256), 0, c->d_slots, sb);
+    return RTVM_OK;
+}
+
+// ... + RANSAC: the whole front half on the current stream
+int queue_front_half(rtvm_ctx* c, int sb, int n) {
+    int r;
+    if ((r = queue_features(c, sb, n))) return r;
     return rtvm_launch_ransac(c, sb, n, 2.0, 2000, 0.995);
 }
 
@@ -271,7 +279,7 @@ int queue_first_frame(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_of
 int queue_back_half(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, int ahead) {
     int r;
     c->seq += 1;
-    const int slot = (int)(c->seq & 1);
+    const int slot = (int)(c->seq & 3);
     RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
                 50.0, 0.3, ahead, c->d_rep + slot);
     for (int j = 0; j < n; j++)
@@ -283,11 +291,11 @@ int queue_back_half(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, int 
     return RTVM_OK;
 }
 
-// The launch macros use c->stream; this points it at the front stream for a scope.
-struct FrontScope {
+// The launch macros use c->stream; this points it at another stream for a scope.
+struct StreamScope {
     rtvm_ctx* c;
-    explicit FrontScope(rtvm_ctx* ctx) : c(ctx) { c->stream = c->stream_front; }
-    ~FrontScope() { c->stream = c->stream_main; }
+    StreamScope(rtvm_ctx* ctx, hipStream_t s) : c(ctx) { c->stream = s; }
+    ~StreamScope() { c->stream = c->stream_main; }
 };
 
 // One batch on the main stream only, in slot set 0, matched against feat_prev.
@@ -302,7 +310,7 @@ int queue_batch_serial(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
     return queue_back_half(c, 0, ptrs, n, 0);
 }
 
-// One batch with its front half on the front stream.
+// One batch with detection + matching on the front stream and RANSAC on the RANSAC stream.
 int queue_batch_overlapped(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
     int r;
     if (n < 1 || n > c->n_batch || n > c->n_set1)
@@ -319,17 +327,23 @@ int queue_batch_overlapped(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream_front, c->ev_main, 0));
     }
     {
-        FrontScope fs(c);
+        StreamScope fs(c, c->stream_front);
         if ((r = bind_batch(c, sb, ptrs, n, ahead ? c->h_slots[c->spec_tail].feat : c->feat_prev))) return r;
-        if ((r = queue_front_half(c, sb, n))) return r;
-        HIP_TRY(c, hipEventRecord(c->ev_front[set], c->stream_front));
+        if ((r = queue_features(c, sb, n))) return r;
+        HIP_TRY(c, hipEventRecord(c->ev_feat[set], c->stream_front));
+    }
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_rs, c->ev_feat[set], 0));
+    {
+        StreamScope fs(c, c->stream_rs);
+        if ((r = rtvm_launch_ransac(c, sb, n, 2.0, 2000, 0.995))) return r;
+        HIP_TRY(c, hipEventRecord(c->ev_front[set], c->stream_rs));
     }
     HIP_TRY(c, hipStreamWaitEvent(c->stream_main, c->ev_front[set], 0));
     if ((r = queue_back_half(c, sb, ptrs, n, ahead))) return r;
     HIP_TRY(c, hipEventRecord(c->ev_back[set], c->stream_main));
     c->back_rec[set] = 1;
     c->spec_tail = sb + n - 1;
-    c->set_next = set ^ 1;
+    c->set_next = (set + 1) % RTVM_NSETS;
     return RTVM_OK;
 }
 
@@ -400,16 +414,16 @@ static int read_state(rtvm_ctx* c, StreamState** hs_out) {
     return RTVM_OK;
 }
 
-// back = 0: the batch queued last; back = 1: the one before it (waits for that batch only,
-// so the caller can keep one batch in flight while it reads the other's outcome).
+// back = 0: the batch queued last; back = 1, 2: the ones before it (waits for that batch
+// only, so the caller can keep two batches in flight while it reads the outcome of a third).
 extern "C" int rtvm_batch_status_at(rtvm_ctx* c, int back, int* n_done, int* status, int* n_matches,
                                     int* n_keypoints, int cap) {
     if (!c) return RTVM_E_ARG;
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "batch_status: no stream");
-    if (back < 0 || back > 1 || c->seq - back < 1)
+    if (back < 0 || back > 2 || c->seq - back < 1)
         RTVM_FAIL(c, RTVM_E_STATE, "batch_status: no batch %d before the last one (%ld queued)", back, c->seq);
     HIP_TRY(c, hipSetDevice(c->device));
-    const int slot = (int)((c->seq - back) & 1);
+    const int slot = (int)((c->seq - back) & 3);
     HIP_TRY(c, hipEventSynchronize(c->ev_done[slot]));
     const BatchReport* rep = c->h_rep + slot;
     if (n_done) *n_done = rep->n_done;
