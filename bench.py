@@ -195,6 +195,7 @@ def main():
     ctx.sync()
     t0 = time.perf_counter()
     run(1 + W, K)
+    t_enq = time.perf_counter()
     ctx.sync()
     torch.cuda.synchronize()
     if world > 1:
@@ -236,7 +237,8 @@ def main():
             "config": {"workload": args.config, "frame": [fh, fw], "canvas": [ch, cw], "nfeatures": nf,
                        "warp_mode": args.warp_mode, "batch": B, "hip_streams": 1 if args.single_stream else 3,
                        "streams": world, "parallelism": "one stream per GPU",
-                       "last_frame": {"status": st, "keypoints": nk, "matches": nm}},
+                       "last_frame": {"status": st, "keypoints": nk, "matches": nm},
+                       "host_enqueue_ms_per_step": (t_enq - t0) / K * 1e3},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if args.kernel_table:

@@ -126,6 +126,24 @@ int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int with_orb) {
     return RTVM_OK;
 }
 
+// Work planes of distance-transform job `slot` (0 or 1) for an image of h x w pixels with
+// the given pitch.
+void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int slot, int pitch, int h, int w) {
+    const size_t n_px = (size_t)c->ch * c->cw;
+    jb->S = c->d_dt_s + (size_t)slot * n_px;
+    jb->R = c->d_dt_r + (size_t)slot * n_px;
+    jb->dist = c->d_dist + (size_t)slot * n_px;
+    jb->B = c->d_dt_b + (size_t)slot * c->dt_b_words;
+    jb->Z = c->d_dt_z + (size_t)slot * c->dt_z_words;
+    jb->Z16 = c->d_dt_z16 + (size_t)slot * c->dt_z16_words;
+    jb->CS = c->d_dt_cs + (size_t)slot * c->dt_cs_words;
+    jb->wpitch = (pitch + 31) / 32 + 2;
+    jb->znch = (h + 31) / 32;
+    jb->zg = (jb->znch + 15) / 16;
+    jb->zpitch = w + h;
+    jb->cpitch = w;
+}
+
 namespace {
 
 int alloc_all(rtvm_ctx* c) {
@@ -159,18 +177,26 @@ int alloc_all(rtvm_ctx* c) {
     ALLOC(c, d_warped, n_px * 3);
     ALLOC(c, d_mask_new, n_px);
     ALLOC(c, d_mask_old, n_px);
-    ALLOC(c, d_dt_s, n_px * 4);
-    ALLOC(c, d_dt_r, n_px * 2);
-    c->dt_z_words = (size_t)2 * ((c->ch + 31) / 32 + 1) * (c->cw + c->ch + 64);
-    c->dt_cs_words = (size_t)4 * ((c->ch + 31) / 32 + 1) * (c->cw + c->ch + 64);
+    ALLOC(c, d_dt_s, n_px * 2 + 64);
+    ALLOC(c, d_dt_r, n_px * 2 + 64);
+    {
+        // sized for any image rtvm_distance_transform accepts: h < ch + 64, h + w <= ch + cw
+        const size_t nch = (size_t)(c->ch + 31) / 32 + 1, lines = (size_t)c->cw + c->ch + 64;
+        c->dt_b_words = (size_t)(c->ch + 64) * ((c->cw + c->ch + 31) / 32 + 3);
+        c->dt_z_words = 2 * nch * lines;
+        c->dt_z16_words = 2 * ((nch + 15) / 16 + 1) * lines;
+        c->dt_cs_words = 2 * nch * lines;
+    }
+    ALLOC(c, d_dt_b, c->dt_b_words * 2);
     ALLOC(c, d_dt_z, c->dt_z_words * 2);
+    ALLOC(c, d_dt_z16, c->dt_z16_words * 2);
     ALLOC(c, d_dt_cs, c->dt_cs_words * 2);
     ALLOC(c, d_dist, n_px * 2);
     ALLOC(c, d_rb, n_px * 2);
     ALLOC(c, d_gk, 32);
     ALLOC(c, d_H, RTVM_MAX_BATCH * 9 + 16);
-    ALLOC(c, d_wp, 1);
-    ALLOC(c, d_jobs, 3);
+    ALLOC(c, d_wp, RTVM_MAX_BATCH);
+    ALLOC(c, d_jobs, 2 * RTVM_MAX_BATCH + 2);
     if ((r = rtvm_warp_setup(c))) return r;
     // RANSAC constant table
     c->rs_raw_n = 32768;
@@ -206,7 +232,7 @@ int alloc_all(rtvm_ctx* c) {
 
 void free_all(rtvm_ctx* c) {
     void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas, c->d_warped, c->d_mask_new,
-                    c->d_mask_old, c->d_dt_s, c->d_dt_r, c->d_dt_z, c->d_dt_cs, c->d_dist, c->d_rb, c->d_gk, c->d_H,
+                    c->d_mask_old, c->d_dt_s, c->d_dt_r, c->d_dt_b, c->d_dt_z, c->d_dt_z16, c->d_dt_cs, c->d_dist, c->d_rb, c->d_gk, c->d_H,
                     c->d_wp, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
                     c->d_skip};
     free_feat(&c->feat_prev);
@@ -510,7 +536,6 @@ extern "C" int rtvm_distance_transform(rtvm_ctx* c, const uint8_t* mask, int h, 
     if ((size_t)h * w > (size_t)c->ch * c->cw || h + w > c->ch + c->cw || (h + 31) / 32 > (c->ch + 31) / 32 + 1)
         RTVM_FAIL(c, RTVM_E_ARG, "distance_transform: %dx%d exceeds the context's canvas (%dx%d)", h, w, c->ch, c->cw);
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t n_px = (size_t)c->ch * c->cw;
     DtJob* jb = (DtJob*)((char*)c->h_pinned + 1024);
     jb->mask = c->d_mask_new;
     jb->pitch = w;
@@ -520,18 +545,10 @@ extern "C" int rtvm_distance_transform(rtvm_ctx* c, const uint8_t* mask, int h, 
     jb->ox0 = jb->oy0 = 0;
     jb->ox1 = w;
     jb->oy1 = h;
-    jb->sA = c->d_dt_s;
-    jb->sB = c->d_dt_s + n_px;
-    jb->R = c->d_dt_r;
-    jb->dist = c->d_dist;
-    jb->Z = c->d_dt_z;
-    jb->CS = c->d_dt_cs;
-    jb->znch = (h + 31) / 32;
-    jb->zpitch = w + h;
-    jb->cpitch = w;
-    HIP_TRY(c, hipMemcpyAsync(c->d_jobs + 2, jb, sizeof(DtJob), hipMemcpyHostToDevice, c->stream));
+    rtvm_dt_job_planes(c, jb, 0, w, h, w);
+    HIP_TRY(c, hipMemcpyAsync(c->d_jobs + RTVM_JOB_STAGE, jb, sizeof(DtJob), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_mask_new, mask, (size_t)h * w, hipMemcpyHostToDevice, c->stream));
-    int r = rtvm_launch_dt(c, c->d_jobs + 2, 1, w, h);
+    int r = rtvm_launch_dt(c, c->d_jobs + RTVM_JOB_STAGE, 1, w, h, 1);
     if (r) return r;
     HIP_TRY(c, hipMemcpyAsync(dist, c->d_dist, (size_t)h * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -547,7 +564,8 @@ extern "C" int rtvm_warp_blend(rtvm_ctx* c, const uint8_t* bgr, const double H[9
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
     if ((r = upload_H(c, H))) return r;
-    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H, nullptr))) return r;
+    if ((r = rtvm_launch_warp_prep(c, c->d_H, nullptr, 1))) return r;
+    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, 0))) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RTVM_OK;
 }

@@ -86,19 +86,20 @@ struct FrameSlot {
 #define RTVM_STAGE_SLOT RTVM_MAX_SLOTS   // slot used by the host-buffer matcher / RANSAC entry points
 
 // One distance-transform job: a rectangle of a mask plane and the planes the
-// scans write (all indexed y*pitch + x like the mask).
+// scans write (S, R and dist are indexed y*pitch + x like the mask).
 struct DtJob {
     const uint8_t* mask;
     int pitch;
     int x0, y0, x1, y1;      // rectangle the transform is computed on (outside = wall)
     int ox0, oy0, ox1, oy1;  // sub-rectangle whose distances are needed
-    uint16_t* sA;      // steps to the nearest zero along x - y = const
-    uint16_t* sB;      // steps to the nearest zero along x + y = const
+    uint16_t* S;       // steps to the nearest zero along the two diagonals through the pixel
     uint32_t* R;       // row scan result
     float* dist;
-    uint32_t* Z;       // zero bitmaps of the diagonal lines: [2 orientations][znch][zpitch]
-    uint32_t* CS;      // column chunk summaries: [4][znch][cpitch]
-    int znch, zpitch, cpitch;
+    uint32_t* B;       // one zero bit per pixel: [rows][wpitch] words
+    uint32_t* Z;       // zero bits of the diagonal lines per 32-row chunk: [2 orientations][znch][zpitch]
+    uint32_t* Z16;     // which chunks of a group of 16 hold a zero: [2][zg][zpitch]
+    uint32_t* CS;      // column chunk summaries: [2][znch][cpitch]
+    int wpitch, znch, zg, zpitch, cpitch;
 };
 
 // Per-frame warp parameters, written on the device by k_warp_prep.
@@ -205,17 +206,20 @@ struct rtvm_ctx {
     uint8_t* d_warped;     // ch*cw*3
     uint8_t* d_mask_new;   // ch*cw
     uint8_t* d_mask_old;   // ch*cw
-    uint16_t* d_dt_s;      // diagonal step planes: [2 jobs][2 orientations][ch*cw]
+    uint16_t* d_dt_s;      // diagonal step planes: [2 jobs][ch*cw]
     uint32_t* d_dt_r;      // row-pass planes [2][ch*cw]
+    uint32_t* d_dt_b;      // zero bit rows, per job
     uint32_t* d_dt_z;      // diagonal zero bitmaps, per job
+    uint32_t* d_dt_z16;    // chunk-group summaries of the bitmaps, per job
     uint32_t* d_dt_cs;     // column chunk summaries, per job
-    size_t dt_z_words, dt_cs_words;  // per job
+    size_t dt_b_words, dt_z_words, dt_z16_words, dt_cs_words;  // per job
     float* d_dist;         // [2][ch*cw]: 0 = new, 1 = old
     float* d_rb;           // row-blurred weights [2][ch*cw]
     float* d_gk;           // 31 Gaussian taps
     double* d_H;           // RTVM_MAX_BATCH x 9 doubles: homographies handed to the warp
-    WarpParams* d_wp;
-    DtJob* d_jobs;         // [0] = new mask on the ROI, [1] = old mask on the canvas, [2] = stage API
+    WarpParams* d_wp;      // one per frame of a batch
+    DtJob* d_jobs;         // [2j] = new mask on the ROI, [2j+1] = old mask on the canvas of frame j of a
+                           // batch; then RTVM_JOB_STAGE (stage API) and RTVM_JOB_CANVAS (whole old mask)
     int canvas_ready;
 
     StreamState* d_state;
@@ -246,12 +250,20 @@ struct rtvm_ctx {
 // match.hip
 int rtvm_launch_hamming(rtvm_ctx* c, int sb, int nb, int cap_q, int cap_t, int sorted);
 // dt.hip
-int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h);
+#define RTVM_JOB_STAGE (2 * RTVM_MAX_BATCH)
+#define RTVM_JOB_CANVAS (2 * RTVM_MAX_BATCH + 1)
+// with_bits = 0: the zero bit rows of the jobs (DtJob::B) are already up to date
+int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h, int with_bits);
+int rtvm_launch_dt_bits(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h);
+void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int slot, int pitch, int h, int w);  // api.hip
 // warp.hip
 int rtvm_warp_setup(rtvm_ctx* c);  // uploads constant tables (after allocation)
 int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_off);
 int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out);
-int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, const int* d_skip);
+// warp parameters and distance-transform jobs of n frames (homographies d_H[9*j], optional
+// "do not stitch" flags d_skip[j]), then the whole of VideMosaic.warp() for frame j
+int rtvm_launch_warp_prep(rtvm_ctx* c, const double* d_H, const int* d_skip, int n);
+int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, int j);
 // orb.hip
 int rtvm_orb_plan(rtvm_ctx* c);   // host-side geometry (before allocation)
 int rtvm_orb_setup(rtvm_ctx* c);  // uploads tables (after allocation)

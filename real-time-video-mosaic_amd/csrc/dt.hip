@@ -11,16 +11,20 @@
 // which is three families of independent 1-D min-plus scans: along diagonals,
 // rows and columns.  All arithmetic is integer, so the result is bit-exact.
 //
-// Diagonal and column scans are cut into chunks of 32 rows, one lane per
-// (line, chunk): lanes of a wave sit on consecutive lines, so every step touches
-// consecutive pixels of one image row (coalesced), a chunk's 32 values live in
-// registers, and the chunks of a line are stitched through small summary arrays:
-//   k_dt_diag_a  32 mask bytes -> one 32-bit zero bitmap per (line, chunk)
-//   k_dt_diag_b  steps to the nearest zero along the line from the bitmaps
-//   k_dt_rows    row scans (one workgroup per row), only rows of the output window
-//   k_dt_cols_a  per (column, chunk): value leaving the chunk downwards / upwards
-//   k_dt_cols_b  carries from the other chunks' summaries, final column scan in
-//                registers, min with the row scan, distance out
+// The image is cut into chunks of 32 rows.  A diagonal line crosses a chunk in 32
+// pixels, whose zero flags form one 32-bit word; a column of a chunk is 32 values
+// held in the registers of one lane.
+//   k_dt_bits    mask bytes -> one zero bit per pixel (32 pixels per lane)
+//   k_dt_diag_a  per (line, chunk): the 32 zero bits of the line inside the chunk,
+//                gathered from the bit rows; per (line, 16 chunks): which chunks
+//                hold a zero
+//   k_dt_diag_b  per tile of 32 rows x 256 columns: steps to the nearest zero along
+//                both diagonals (bit scans inside the chunk, the chunk summaries
+//                beyond it), minimum of the two through LDS, one u16 plane out
+//   k_dt_scan    row scans of the output window's rows (wave prefix minima), and
+//                per (column, chunk) the values leaving the chunk downwards / upwards
+//   k_dt_cols    carries from the other chunks' summaries, column scan in registers,
+//                min with the row scan, distance out
 #include "common.h"
 
 namespace {
@@ -30,173 +34,390 @@ constexpr uint32_t DT_B = 89738u;              // cvRound(1.3693 * 65536)
 constexpr uint32_t DT_MAX = 0xFFFFFFFFu - DT_B;  // OpenCV's DIST_MAX
 constexpr uint32_t INF32 = 0xFFFFFFFFu;
 constexpr int CH = 32;                         // rows per chunk
+constexpr int GR = 16;                         // chunks per summary group
+constexpr int TW = 256;                        // columns per tile of k_dt_diag_b
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t v, uint32_t k) {
     return v > INF32 - k ? INF32 : v + k;
 }
 
-// E(q) in Q16 from the two diagonal step planes (0xFFFF = no zero on that diagonal).
-__device__ __forceinline__ uint32_t e_of(uint16_t a, uint16_t b) {
-    const uint32_t s = a < b ? a : b;
+// E(q) in Q16 from the step plane (0xFFFF = no zero on either diagonal).
+__device__ __forceinline__ uint32_t e_of(uint32_t s) {
     return s == 0xFFFFu ? INF32 : s * DT_B;
 }
 
-// blockIdx.z = 2 * job + orientation; orientation 0: lines x - y = const, 1: x + y = const.
-// x of line `line` at row y0 is xs; it moves by dx per row.
-struct DiagGeom {
-    int W, H, nlines, nch, line, dx, xs, ya;
-    bool ok;
+// 4 mask bytes -> 4 bits (bit i set iff byte i is zero)
+__device__ __forceinline__ uint32_t zero_nibble(uint32_t v) {
+    const uint32_t t = ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);  // 0x80 in every zero byte
+    return (((t >> 7) * 0x01020408u) >> 24) & 0xFu;
+}
+
+// One lane per 32 pixels of a row of the rectangle: bit i of word w of row y is set iff
+// pixel (32 w + i, y) lies inside the rectangle and is zero.
+__global__ __launch_bounds__(256) void k_dt_bits(const DtJob* __restrict__ jobs) {
+    const DtJob jb = jobs[blockIdx.z];
+    const int w0 = jb.x0 >> 5;
+    const int w = w0 + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = jb.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= jb.y1 || w * 32 >= jb.x1) return;
+    const int xa = w * 32;
+    const uint8_t* __restrict__ row = jb.mask + (size_t)y * jb.pitch;
+    uint32_t bits = 0;
+    if (xa + 32 <= jb.pitch && ((reinterpret_cast<uintptr_t>(row + xa) & 3) == 0)) {
+        const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(row + xa);
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) bits |= zero_nibble(v[i]) << (4 * i);
+    } else {
+        for (int i = 0; i < 32; i++)
+            if (xa + i < jb.pitch && row[xa + i] == 0) bits |= 1u << i;
+    }
+    // pixels outside the rectangle are walls, not zeros
+    if (xa < jb.x0) bits &= 0xFFFFFFFFu << (jb.x0 - xa);
+    if (xa + 32 > jb.x1) bits &= 0xFFFFFFFFu >> (xa + 32 - jb.x1);
+    jb.B[(size_t)y * jb.wpitch + w] = bits;
+}
+
+// Lines of orientation 0 run along x - y = const (x grows with y), those of orientation 1
+// along x + y = const.  Line `line` passes through column xs at row y0 of the rectangle.
+struct LineGeom {
+    int W, H, nlines, nch;
 };
-__device__ __forceinline__ DiagGeom diag_geom(const DtJob& jb, int orient) {
-    DiagGeom g;
+__device__ __forceinline__ LineGeom line_geom(const DtJob& jb) {
+    LineGeom g;
     g.W = jb.x1 - jb.x0;
     g.H = jb.y1 - jb.y0;
     g.nlines = g.W + g.H - 1;
     g.nch = (g.H + CH - 1) / CH;
-    g.line = blockIdx.x * 64 + threadIdx.x;
-    g.dx = orient ? -1 : 1;
-    g.xs = orient ? jb.x0 + g.line : jb.x0 - (g.H - 1) + g.line;
-    g.ya = jb.y0 + (int)blockIdx.y * CH;
-    g.ok = g.W > 0 && g.H > 0 && (int)blockIdx.y < g.nch && (int)blockIdx.x * 64 < g.nlines;
     return g;
 }
 
-__global__ __launch_bounds__(64) void k_dt_diag_a(const DtJob* __restrict__ jobs) {
+// blockIdx.z = 2 * job + orientation; one wave = 64 lines of one chunk, one workgroup =
+// the 16 chunks of a group.
+__global__ __launch_bounds__(1024) void k_dt_diag_a(const DtJob* __restrict__ jobs) {
     const DtJob jb = jobs[blockIdx.z >> 1];
     const int orient = blockIdx.z & 1;
-    const DiagGeom g = diag_geom(jb, orient);
-    if (!g.ok) return;
+    const LineGeom g = line_geom(jb);
+    if (g.W <= 0 || g.H <= 0 || (int)blockIdx.x * 64 >= g.nlines || (int)blockIdx.y * GR >= g.nch) return;
+    __shared__ uint32_t s_any[GR][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int line = blockIdx.x * 64 + lane;
+    const int c = blockIdx.y * GR + wave;
     uint32_t z = 0;
-    if (g.line < g.nlines) {
-        uint8_t v[CH];
+    if (line < g.nlines && c < g.nch) {
+        const int dx = orient ? -1 : 1;
+        const int xs = orient ? jb.x0 + line : jb.x0 - (g.H - 1) + line;
+        const int ya = jb.y0 + c * CH;
+        const int xt = xs + dx * (ya - jb.y0);  // column of the line at the chunk's first row
+        uint32_t w[CH];
 #pragma unroll
         for (int r = 0; r < CH; r++) {
-            const int y = g.ya + r;
-            const int x = g.xs + g.dx * (y - jb.y0);
+            const int y = ya + r, x = xt + dx * r;
             const bool in = y < jb.y1 && x >= jb.x0 && x < jb.x1;
-            v[r] = in ? jb.mask[(size_t)y * jb.pitch + x] : (uint8_t)1;
+            w[r] = in ? jb.B[(size_t)y * jb.wpitch + (x >> 5)] >> (x & 31) : 0u;
         }
 #pragma unroll
-        for (int r = 0; r < CH; r++) z |= (uint32_t)(v[r] == 0) << r;
+        for (int r = 0; r < CH; r++) z |= (w[r] & 1u) << r;
+        jb.Z[((size_t)orient * jb.znch + c) * jb.zpitch + line] = z;
     }
-    if (g.line < g.nlines) jb.Z[((size_t)orient * jb.znch + blockIdx.y) * jb.zpitch + g.line] = z;
+    s_any[wave][lane] = z != 0 ? 1u : 0u;
+    __syncthreads();
+    if (wave == 0 && line < g.nlines) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < GR; k++) m |= s_any[k][lane] << k;
+        jb.Z16[((size_t)orient * jb.zg + blockIdx.y) * jb.zpitch + line] = m;
+    }
 }
 
-__global__ __launch_bounds__(64) void k_dt_diag_b(const DtJob* __restrict__ jobs) {
-    const DtJob jb = jobs[blockIdx.z >> 1];
-    const int orient = blockIdx.z & 1;
-    const DiagGeom g = diag_geom(jb, orient);
-    if (!g.ok || g.line >= g.nlines) return;
-    const uint32_t* __restrict__ Z = jb.Z + (size_t)orient * jb.znch * jb.zpitch + g.line;
-    const int c = blockIdx.y;
+// Steps to the nearest zero along one line for the 32 rows of chunk c, written into the
+// LDS tile (first == true) or combined with what the other orientation left there.
+template <bool FIRST>
+__device__ __forceinline__ void diag_steps(const DtJob& jb, const LineGeom& g, int orient, int c, int line, int col0,
+                                           int dcol, uint16_t (*T)[TW]) {
+    const uint32_t* __restrict__ Z = jb.Z + (size_t)orient * jb.znch * jb.zpitch + line;
+    const uint32_t* __restrict__ Z16 = jb.Z16 + (size_t)orient * jb.zg * jb.zpitch + line;
     const uint32_t z = Z[(size_t)c * jb.zpitch];
-    // nearest zero of the line above / below this chunk, as a row index
-    long long above = -(1ll << 40), below = 1ll << 40;
-    for (int k = c - 1; k >= 0; k--) {
-        const uint32_t zz = Z[(size_t)k * jb.zpitch];
-        if (zz) {
-            above = jb.y0 + k * CH + (31 - __clz((int)zz));
-            break;
-        }
+    // nearest chunk with a zero above / below this one
+    const int gi = c / GR, ci = c % GR, ng = (g.nch + GR - 1) / GR;
+    int ka = -1, kb = -1;
+    {
+        const uint32_t own = Z16[(size_t)gi * jb.zpitch];
+        uint32_t m = own & ((1u << ci) - 1u);
+        if (m)
+            ka = gi * GR + (31 - __clz((int)m));
+        else
+            for (int k = gi - 1; k >= 0; k--) {
+                m = Z16[(size_t)k * jb.zpitch];
+                if (m) {
+                    ka = k * GR + (31 - __clz((int)m));
+                    break;
+                }
+            }
+        m = own & ~((2u << ci) - 1u);
+        if (m)
+            kb = gi * GR + (__ffs((int)m) - 1);
+        else
+            for (int k = gi + 1; k < ng; k++) {
+                m = Z16[(size_t)k * jb.zpitch];
+                if (m) {
+                    kb = k * GR + (__ffs((int)m) - 1);
+                    break;
+                }
+            }
     }
-    for (int k = c + 1; k < g.nch; k++) {
-        const uint32_t zz = Z[(size_t)k * jb.zpitch];
-        if (zz) {
-            below = jb.y0 + k * CH + (__ffs((int)zz) - 1);
-            break;
-        }
-    }
-    uint16_t* __restrict__ S = orient ? jb.sB : jb.sA;
+    // distance in rows from the chunk's first row up to the zero above, and from its last
+    // row down to the zero below (large = none)
+    int up = 1 << 20, down = 1 << 20;
+    if (ka >= 0) up = (c - ka) * CH - (31 - __clz((int)Z[(size_t)ka * jb.zpitch]));
+    if (kb >= 0) down = (kb - c) * CH + (__ffs((int)Z[(size_t)kb * jb.zpitch]) - 1) - (CH - 1);
 #pragma unroll
     for (int r = 0; r < CH; r++) {
-        const int y = g.ya + r;
-        const int x = g.xs + g.dx * (y - jb.y0);
-        if (y >= jb.y1 || x < jb.x0 || x >= jb.x1) continue;
+        const int col = col0 + dcol * r;
+        if (col < 0 || col >= TW) continue;
         const uint32_t lower = z & (0xFFFFFFFFu >> (31 - r));
         const uint32_t upper = z >> r;
-        const long long du = lower ? (long long)(r - (31 - __clz((int)lower))) : (long long)y - above;
-        const long long dd = upper ? (long long)(__ffs((int)upper) - 1) : below - (long long)y;
-        const long long d = du < dd ? du : dd;
-        S[(size_t)y * jb.pitch + x] = (uint16_t)(d > 0xFFFE ? 0xFFFF : d);
+        const int du = lower ? r - (31 - __clz((int)lower)) : up + r;
+        const int dd = upper ? __ffs((int)upper) - 1 : down + (CH - 1 - r);
+        const int d = du < dd ? du : dd;
+        const uint16_t s = (uint16_t)(d > 0xFFFE ? 0xFFFF : d);
+        if (FIRST)
+            T[r][col] = s;
+        else if (s < T[r][col])
+            T[r][col] = s;
     }
 }
 
-// Row scans: one workgroup of 256 threads per row of the output window; thread t
-// owns a contiguous segment.  R(x) = min_k E(k) + a*|x-k| as prefix/suffix minima of
-// E(k) -/+ a*k.
-__global__ __launch_bounds__(256) void k_dt_rows(const DtJob* __restrict__ jobs) {
-    const DtJob jb = jobs[blockIdx.y];
-    const int W = jb.x1 - jb.x0;
-    const int y = jb.oy0 + blockIdx.x;
-    if (W <= 0 || y >= jb.oy1) return;
-    const size_t row = (size_t)y * jb.pitch;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int S = (W + 255) / 256;
-    const int xa = jb.x0 + tid * S, xb = min(xa + S, jb.x1);
-    constexpr long long BIG = 1ll << 60;
-    const long long a = DT_A;
-    long long mf = BIG, mb = BIG;
-    for (int x = xa; x < xb; x++) {
-        const uint32_t e = e_of(jb.sA[row + x], jb.sB[row + x]);
-        if (e != INF32) {
-            mf = min(mf, (long long)e - a * x);
-            mb = min(mb, (long long)e + a * x);
+// One workgroup per tile of 32 rows x TW columns (columns on a grid of TW from 0, so the
+// rows of a tile are 16-byte aligned when the pitch is a multiple of 8).  Tiles that touch
+// neither the rows nor the columns of the output window are never read and are skipped.
+__global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ jobs) {
+    const DtJob jb = jobs[blockIdx.z];
+    const LineGeom g = line_geom(jb);
+    const int c = blockIdx.y;
+    const int X = ((jb.x0 / TW) + (int)blockIdx.x) * TW;
+    if (g.W <= 0 || g.H <= 0 || c >= g.nch || X >= jb.x1) return;
+    const int ya = jb.y0 + c * CH;
+    const bool rows_needed = ya < jb.oy1 && ya + CH > jb.oy0;
+    const bool cols_needed = X < jb.ox1 && X + TW > jb.ox0;
+    if (!rows_needed && !cols_needed) return;
+    __shared__ uint16_t T[CH][TW];
+    const int i = threadIdx.x;
+    // every pixel of the tile inside the rectangle lies on exactly one line of each family
+    if (i < TW + CH - 1) {
+        // orientation 0: the line through column X - 31 + i at the chunk's first row
+        const int line = (X - 31 + i) - jb.x0 + (g.H - 1) - c * CH;
+        if (line >= 0 && line < g.nlines) diag_steps<true>(jb, g, 0, c, line, i - 31, 1, T);
+    }
+    __syncthreads();
+    if (i < TW + CH - 1) {
+        // orientation 1: the line through column X + i at the chunk's first row
+        const int line = (X + i) - jb.x0 + c * CH;
+        if (line >= 0 && line < g.nlines) diag_steps<false>(jb, g, 1, c, line, i, -1, T);
+    }
+    __syncthreads();
+    const int nrows = min(CH, jb.y1 - ya);
+    if ((jb.pitch & 7) == 0 && X + TW <= jb.pitch) {
+        for (int e = i; e < nrows * (TW / 8); e += 320) {
+            const int r = e / (TW / 8), q = e % (TW / 8);
+            const int x = X + q * 8;
+            if (x + 8 <= jb.x0 || x >= jb.x1) continue;
+            *reinterpret_cast<uint4*>(jb.S + (size_t)(ya + r) * jb.pitch + x) = *reinterpret_cast<const uint4*>(&T[r][q * 8]);
+        }
+    } else {
+        for (int e = i; e < nrows * TW; e += 320) {
+            const int r = e / TW, x = X + e % TW;
+            if (x < jb.x0 || x >= jb.x1) continue;
+            jb.S[(size_t)(ya + r) * jb.pitch + x] = T[r][e % TW];
         }
     }
-    __shared__ long long s_f[4], s_b[4];
-    long long pf = mf, pb = mb;
+}
+
+// ---- row scans ---------------------------------------------------------------------
+// R(x) = min_k E(k) + a*|x-k| = min(prefix minimum of E(k) + a*(XR-k) minus a*(XR-x),
+//                                   suffix minimum of E(k) + a*k minus a*x)
+// with k, x relative to an 8-aligned origin.  A thread owns 8 consecutive pixels, a
+// workgroup 2048; wider rows take several passes with the running minimum carried over.
+
+__device__ __forceinline__ uint32_t wg_prefix_min_excl(uint32_t v, uint32_t* s_w, uint32_t carry_in, uint32_t* total) {
+    // exclusive prefix minimum over the 256 threads (thread order), seeded with carry_in
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t p = v;
+#pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const long long uf = __shfl_up(pf, o), ub = __shfl_down(pb, o);
-        if (lane >= o) pf = min(pf, uf);
-        if (lane + o < 64) pb = min(pb, ub);
+        const uint32_t u = __shfl_up(p, o);
+        if (lane >= o) p = min(p, u);
     }
-    if (lane == 63) s_f[wave] = pf;
-    if (lane == 0) s_b[wave] = pb;
     __syncthreads();
-    long long cf = __shfl_up(pf, 1), cb = __shfl_down(pb, 1);
-    if (lane == 0) cf = BIG;
-    if (lane == 63) cb = BIG;
-    for (int w = 0; w < 4; w++) {
-        if (w < wave) cf = min(cf, s_f[w]);
-        if (w > wave) cb = min(cb, s_b[w]);
+    if (lane == 63) s_w[wave] = p;
+    __syncthreads();
+    uint32_t ex = __shfl_up(p, 1);
+    if (lane == 0) ex = INF32;
+    uint32_t c = carry_in;
+    for (int w = 0; w < 4; w++)
+        if (w < wave) c = min(c, s_w[w]);
+    *total = min(min(min(s_w[0], s_w[1]), min(s_w[2], s_w[3])), carry_in);
+    return min(ex, c);
+}
+
+__device__ __forceinline__ uint32_t wg_suffix_min_excl(uint32_t v, uint32_t* s_w, uint32_t carry_in, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t p = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_down(p, o);
+        if (lane + o < 64) p = min(p, u);
     }
-    for (int x = xa; x < xb; x++) {
-        const uint32_t e = e_of(jb.sA[row + x], jb.sB[row + x]);
-        if (e != INF32) cf = min(cf, (long long)e - a * x);
-        const long long v = cf >= BIG / 2 ? (long long)INF32 : cf + a * x;
-        jb.R[row + x] = v > (long long)DT_MAX ? DT_MAX : (uint32_t)v;
+    __syncthreads();
+    if (lane == 0) s_w[wave] = p;
+    __syncthreads();
+    uint32_t ex = __shfl_down(p, 1);
+    if (lane == 63) ex = INF32;
+    uint32_t c = carry_in;
+    for (int w = 0; w < 4; w++)
+        if (w > wave) c = min(c, s_w[w]);
+    *total = min(min(min(s_w[0], s_w[1]), min(s_w[2], s_w[3])), carry_in);
+    return min(ex, c);
+}
+
+// E of the 8 pixels starting at x (8-aligned relative to the plane when the pitch allows)
+__device__ __forceinline__ void load_e8(const DtJob& jb, size_t row, int x, uint32_t* E) {
+    uint16_t s[8];
+    if ((jb.pitch & 7) == 0 && x >= 0 && x + 8 <= jb.pitch) {
+        const uint4 v = *reinterpret_cast<const uint4*>(jb.S + row + x);
+        s[0] = v.x & 0xFFFF, s[1] = v.x >> 16, s[2] = v.y & 0xFFFF, s[3] = v.y >> 16;
+        s[4] = v.z & 0xFFFF, s[5] = v.z >> 16, s[6] = v.w & 0xFFFF, s[7] = v.w >> 16;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = (x + i >= jb.x0 && x + i < jb.x1) ? jb.S[row + x + i] : (uint16_t)0xFFFF;
     }
-    for (int x = xb - 1; x >= xa; x--) {
-        const uint32_t e = e_of(jb.sA[row + x], jb.sB[row + x]);
-        if (e != INF32) cb = min(cb, (long long)e + a * x);
-        const long long v = cb >= BIG / 2 ? (long long)INF32 : cb - a * x;
-        const uint32_t r = v > (long long)DT_MAX ? DT_MAX : (uint32_t)v;
-        if (r < jb.R[row + x]) jb.R[row + x] = r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) E[i] = (x + i >= jb.x0 && x + i < jb.x1) ? e_of(s[i]) : INF32;
+}
+
+__device__ void dt_row(const DtJob& jb, int y, uint32_t* s_w) {
+    const int xo = jb.x0 & ~7;                          // origin of the relative coordinate
+    const int span = jb.x1 - xo;
+    const int P = (span + 2047) / 2048;                 // passes
+    const uint32_t XR = (uint32_t)(P * 2048 - 1);
+    const size_t row = (size_t)y * jb.pitch;
+    const int t = threadIdx.x;
+    if (P == 1) {
+        const int xr = t * 8, x = xo + xr;
+        uint32_t E[8], F[8];
+        if (xr < span)
+            load_e8(jb, row, x, E);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) E[i] = INF32;
+        }
+        uint32_t mf = INF32, mb = INF32;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (E[i] != INF32) {
+                mf = min(mf, E[i] + DT_A * (XR - (uint32_t)(xr + i)));
+                mb = min(mb, E[i] + DT_A * (uint32_t)(xr + i));
+            }
+        }
+        uint32_t tot;
+        uint32_t run = wg_prefix_min_excl(mf, s_w, INF32, &tot);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (E[i] != INF32) run = min(run, E[i] + DT_A * (XR - (uint32_t)(xr + i)));
+            F[i] = run == INF32 ? INF32 : run - DT_A * (XR - (uint32_t)(xr + i));
+        }
+        run = wg_suffix_min_excl(mb, s_w, INF32, &tot);
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+            if (E[i] != INF32) run = min(run, E[i] + DT_A * (uint32_t)(xr + i));
+            const uint32_t b = run == INF32 ? INF32 : run - DT_A * (uint32_t)(xr + i);
+            const uint32_t v = min(F[i], b);
+            F[i] = v > DT_MAX ? DT_MAX : v;
+        }
+        if (xr < span && x + 8 > jb.ox0 && x < jb.ox1) {
+            if ((jb.pitch & 3) == 0 && x >= jb.ox0 && x + 8 <= jb.ox1) {
+                uint4* o = reinterpret_cast<uint4*>(jb.R + row + x);
+                o[0] = make_uint4(F[0], F[1], F[2], F[3]);
+                o[1] = make_uint4(F[4], F[5], F[6], F[7]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (x + i >= jb.ox0 && x + i < jb.ox1) jb.R[row + x + i] = F[i];
+            }
+        }
+        return;
+    }
+    // several passes: forward results go through R, the backward sweep folds into them
+    uint32_t carry = INF32;
+    for (int p = 0; p < P; p++) {
+        const int xr = (p * 256 + t) * 8, x = xo + xr;
+        uint32_t E[8];
+        if (xr < span)
+            load_e8(jb, row, x, E);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) E[i] = INF32;
+        }
+        uint32_t mf = INF32;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (E[i] != INF32) mf = min(mf, E[i] + DT_A * (XR - (uint32_t)(xr + i)));
+        uint32_t tot;
+        uint32_t run = wg_prefix_min_excl(mf, s_w, carry, &tot);
+        carry = tot;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (E[i] != INF32) run = min(run, E[i] + DT_A * (XR - (uint32_t)(xr + i)));
+            const uint32_t f = run == INF32 ? INF32 : run - DT_A * (XR - (uint32_t)(xr + i));
+            if (x + i >= jb.ox0 && x + i < jb.ox1) jb.R[row + x + i] = f;
+        }
+    }
+    carry = INF32;
+    for (int p = P - 1; p >= 0; p--) {
+        const int xr = (p * 256 + t) * 8, x = xo + xr;
+        uint32_t E[8];
+        if (xr < span)
+            load_e8(jb, row, x, E);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) E[i] = INF32;
+        }
+        uint32_t mb = INF32;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (E[i] != INF32) mb = min(mb, E[i] + DT_A * (uint32_t)(xr + i));
+        uint32_t tot;
+        uint32_t run = wg_suffix_min_excl(mb, s_w, carry, &tot);
+        carry = tot;
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+            if (E[i] != INF32) run = min(run, E[i] + DT_A * (uint32_t)(xr + i));
+            const uint32_t b = run == INF32 ? INF32 : run - DT_A * (uint32_t)(xr + i);
+            if (x + i >= jb.ox0 && x + i < jb.ox1) {
+                const uint32_t v = min(jb.R[row + x + i], b);
+                jb.R[row + x + i] = v > DT_MAX ? DT_MAX : v;
+            }
+        }
     }
 }
 
-// E of the 32 rows of chunk c of column x (INF below the rectangle)
+// E of the 32 rows of a chunk of column x (INF below the rectangle)
 __device__ __forceinline__ void load_chunk_e(const DtJob& jb, int x, int ya, uint32_t* E) {
-    uint16_t a[CH], b[CH];
+    uint16_t s[CH];
 #pragma unroll
     for (int r = 0; r < CH; r++) {
         const int y = min(ya + r, jb.y1 - 1);
-        const size_t p = (size_t)y * jb.pitch + x;
-        a[r] = jb.sA[p];
-        b[r] = jb.sB[p];
+        s[r] = jb.S[(size_t)y * jb.pitch + x];
     }
 #pragma unroll
-    for (int r = 0; r < CH; r++) E[r] = ya + r < jb.y1 ? e_of(a[r], b[r]) : INF32;
+    for (int r = 0; r < CH; r++) E[r] = ya + r < jb.y1 ? e_of(s[r]) : INF32;
 }
 
 // Per (column, chunk): fe = value at the chunk's last row from the chunk's own pixels
 // (going down), be = value at its first row (going up).  Only columns of the output window.
-__global__ __launch_bounds__(64) void k_dt_cols_a(const DtJob* __restrict__ jobs) {
-    const DtJob jb = jobs[blockIdx.z];
-    const int H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
-    const int x = jb.ox0 + blockIdx.x * 64 + threadIdx.x;
-    const int c = blockIdx.y;
-    if (H <= 0 || c >= nch || x >= jb.ox1) return;
+__device__ void dt_col_summary(const DtJob& jb, int x, int c) {
     uint32_t E[CH];
     load_chunk_e(jb, x, jb.y0 + c * CH, E);
     uint32_t fe = INF32, be = INF32;
@@ -209,9 +430,29 @@ __global__ __launch_bounds__(64) void k_dt_cols_a(const DtJob* __restrict__ jobs
     jb.CS[((size_t)1 * jb.znch + c) * jb.cpitch + x] = be;
 }
 
+// blockIdx.y = job.  The first `nrow_blocks` workgroups scan one row of the output window
+// each; the others take 64 columns x 4 chunks of the column summaries.
+__global__ __launch_bounds__(256) void k_dt_scan(const DtJob* __restrict__ jobs, int nrow_blocks, int ncol_x) {
+    const DtJob jb = jobs[blockIdx.y];
+    const int W = jb.x1 - jb.x0, H = jb.y1 - jb.y0;
+    if (W <= 0 || H <= 0) return;
+    __shared__ uint32_t s_w[4];
+    if ((int)blockIdx.x < nrow_blocks) {
+        const int y = jb.oy0 + blockIdx.x;
+        if (y < jb.oy1) dt_row(jb, y, s_w);
+        return;
+    }
+    const int b = blockIdx.x - nrow_blocks;
+    const int nch = (H + CH - 1) / CH;
+    const int x = jb.ox0 + (b % ncol_x) * 64 + (threadIdx.x & 63);
+    const int c = (b / ncol_x) * 4 + (threadIdx.x >> 6);
+    if (c >= nch || x >= jb.ox1) return;
+    dt_col_summary(jb, x, c);
+}
+
 // Final column scan of the chunks that intersect the output window, in registers;
 // d = min(column scan, row scan), clamped to DIST_MAX, as float / 65536.
-__global__ __launch_bounds__(64) void k_dt_cols_b(const DtJob* __restrict__ jobs) {
+__global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs) {
     const DtJob jb = jobs[blockIdx.z];
     const int H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
     const int x = jb.ox0 + blockIdx.x * 64 + threadIdx.x;
@@ -220,19 +461,37 @@ __global__ __launch_bounds__(64) void k_dt_cols_b(const DtJob* __restrict__ jobs
     const int ya = jb.y0 + c * CH;
     if (ya >= jb.oy1) return;
     const size_t plane = (size_t)jb.znch * jb.cpitch;
-    uint32_t E[CH], F[CH];
+    uint32_t E[CH], F[CH], Rv[CH];
     load_chunk_e(jb, x, ya, E);
+#pragma unroll
+    for (int r = 0; r < CH; r++) {
+        const int y = ya + r;
+        Rv[r] = (y >= jb.oy0 && y < jb.oy1) ? jb.R[(size_t)y * jb.pitch + x] : INF32;
+    }
     // values arriving from the other chunks of the column: at the first row from above,
     // at the last row from below (chunk k's summary travels 32*|c-k| - 31 rows)
     uint32_t cf = INF32, cb = INF32;
-    for (int k = 0; k < nch; k++) {
-        if (k < c) {
-            const uint32_t fe = jb.CS[0 * plane + (size_t)k * jb.cpitch + x];
-            cf = min(cf, sat_add(fe, DT_A * (uint32_t)(CH * (c - k) - (CH - 1))));
-        } else if (k > c) {
-            const uint32_t be = jb.CS[1 * plane + (size_t)k * jb.cpitch + x];
-            cb = min(cb, sat_add(be, DT_A * (uint32_t)(CH * (k - c) - (CH - 1))));
+    {
+        const uint32_t* __restrict__ fe = jb.CS + x;
+        int k = 0;
+        for (; k + 4 <= c; k += 4) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = fe[(size_t)(k + u) * jb.cpitch];
+#pragma unroll
+            for (int u = 0; u < 4; u++) cf = min(cf, sat_add(v[u], DT_A * (uint32_t)(CH * (c - k - u) - (CH - 1))));
         }
+        for (; k < c; k++) cf = min(cf, sat_add(fe[(size_t)k * jb.cpitch], DT_A * (uint32_t)(CH * (c - k) - (CH - 1))));
+        const uint32_t* __restrict__ be = jb.CS + plane + x;
+        k = c + 1;
+        for (; k + 4 <= nch; k += 4) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = be[(size_t)(k + u) * jb.cpitch];
+#pragma unroll
+            for (int u = 0; u < 4; u++) cb = min(cb, sat_add(v[u], DT_A * (uint32_t)(CH * (k + u - c) - (CH - 1))));
+        }
+        for (; k < nch; k++) cb = min(cb, sat_add(be[(size_t)k * jb.cpitch], DT_A * (uint32_t)(CH * (k - c) - (CH - 1))));
     }
     uint32_t run = cf;
 #pragma unroll
@@ -248,10 +507,9 @@ __global__ __launch_bounds__(64) void k_dt_cols_b(const DtJob* __restrict__ jobs
         if (y >= jb.y1) continue;
         run = min(run, E[r]);
         if (y >= jb.oy0 && y < jb.oy1) {
-            const size_t p = (size_t)y * jb.pitch + x;
-            uint32_t d = min(min(run, F[r]), jb.R[p]);
+            uint32_t d = min(min(run, F[r]), Rv[r]);
             d = d > DT_MAX ? DT_MAX : d;
-            jb.dist[p] = (float)d * (1.f / 65536.f);
+            jb.dist[(size_t)y * jb.pitch + x] = (float)d * (1.f / 65536.f);
         }
         run = sat_add(run, DT_A);
     }
@@ -261,16 +519,24 @@ __global__ __launch_bounds__(64) void k_dt_cols_b(const DtJob* __restrict__ jobs
 
 // Queues the scan kernels for njobs jobs described in device memory; max_w/max_h
 // bound every job's rectangle (grid sizing).
-int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h) {
+int rtvm_launch_dt_bits(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h) {
+    if (max_w <= 0 || max_h <= 0) return RTVM_OK;
+    RTVM_LAUNCH(c, k_dt_bits, dim3((max_w / 32 + 2 + 63) / 64, (max_h + 3) / 4, njobs), dim3(256), 0, d_jobs);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}
+
+int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h, int with_bits) {
     if (max_w <= 0 || max_h <= 0) return RTVM_OK;
     if (max_w > 16384 || max_h > 16384) RTVM_FAIL(c, RTVM_E_ARG, "distance transform: image side above 16384");
     const int nlines = max_w + max_h - 1;
     const int nch = (max_h + CH - 1) / CH;
-    RTVM_LAUNCH(c, k_dt_diag_a, dim3((nlines + 63) / 64, nch, 2 * njobs), dim3(64), 0, d_jobs);
-    RTVM_LAUNCH(c, k_dt_diag_b, dim3((nlines + 63) / 64, nch, 2 * njobs), dim3(64), 0, d_jobs);
-    RTVM_LAUNCH(c, k_dt_rows, dim3(max_h, njobs), dim3(256), 0, d_jobs);
-    RTVM_LAUNCH(c, k_dt_cols_a, dim3((max_w + 63) / 64, nch, njobs), dim3(64), 0, d_jobs);
-    RTVM_LAUNCH(c, k_dt_cols_b, dim3((max_w + 63) / 64, nch + 1, njobs), dim3(64), 0, d_jobs);
+    const int ncol_x = (max_w + 63) / 64;
+    if (with_bits) RTVM_LAUNCH(c, k_dt_bits, dim3((max_w / 32 + 2 + 63) / 64, (max_h + 3) / 4, njobs), dim3(256), 0, d_jobs);
+    RTVM_LAUNCH(c, k_dt_diag_a, dim3((nlines + 63) / 64, (nch + GR - 1) / GR, 2 * njobs), dim3(1024), 0, d_jobs);
+    RTVM_LAUNCH(c, k_dt_diag_b, dim3(max_w / TW + 2, nch, njobs), dim3(320), 0, d_jobs);
+    RTVM_LAUNCH(c, k_dt_scan, dim3(max_h + ncol_x * ((nch + 3) / 4), njobs), dim3(256), 0, d_jobs, max_h, ncol_x);
+    RTVM_LAUNCH(c, k_dt_cols, dim3(ncol_x, nch + 1, njobs), dim3(64), 0, d_jobs);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }

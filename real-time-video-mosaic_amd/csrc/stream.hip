@@ -282,8 +282,9 @@ int queue_back_half(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, int 
     const int slot = (int)(c->seq & 3);
     RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
                 50.0, 0.3, ahead, c->d_rep + slot);
+    if ((r = rtvm_launch_warp_prep(c, c->d_H, c->d_skip, n))) return r;
     for (int j = 0; j < n; j++)
-        if ((r = rtvm_launch_warp_blend(c, ptrs[j], c->d_H + 9 * j, c->d_skip + j))) return r;
+        if ((r = rtvm_launch_warp_blend(c, ptrs[j], j))) return r;
     RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, sb, c->d_state, -1,
                 c->feat_prev, c->orb.max_kp);
     HIP_TRY(c, hipGetLastError());
@@ -498,7 +499,8 @@ extern "C" int rtvm_frame_commit(rtvm_ctx* c, const double H[9]) {
     memcpy(hp, H, 9 * sizeof(double));
     HIP_TRY(c, hipMemcpyAsync(c->d_H, hp, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int r;
-    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H, nullptr))) return r;
+    if ((r = rtvm_launch_warp_prep(c, c->d_H, nullptr, 1))) return r;
+    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, 0))) return r;
     RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
                 c->feat_prev, c->orb.max_kp);
     HIP_TRY(c, hipGetLastError());

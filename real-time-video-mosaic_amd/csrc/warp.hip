@@ -11,6 +11,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <vector>
 
 namespace {
 
@@ -20,12 +21,17 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
-// One thread: M = H^-1 (cv::invert's 3x3 closed form), the region of the canvas
-// the frame can touch, and the two distance-transform jobs of the frame.
+// One thread per frame (blockIdx.x = index in the batch): M = H^-1 (cv::invert's 3x3
+// closed form), the region of the canvas the frame can touch, and the two
+// distance-transform jobs of the frame.
 __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restrict__ wp,
                             DtJob* __restrict__ jobs, int fh, int fw, int ch, int cw, int force_full,
                             const int* __restrict__ skip) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    Hp += 9 * blockIdx.x;
+    wp += blockIdx.x;
+    if (jobs) jobs += 2 * blockIdx.x;
+    if (skip) skip += blockIdx.x;
     if (skip && *skip) {  // frame rejected upstream: nothing to stitch
         wp->rx0 = wp->ry0 = wp->rx1 = wp->ry1 = 0;
         wp->wx0 = wp->wy0 = wp->wx1 = wp->wy1 = 0;
@@ -125,13 +131,14 @@ __device__ __forceinline__ int tap(const uint8_t* __restrict__ src, int fh, int 
 // else float32 (OpenCV >= 4.11).  Also writes mask_new = any channel > 0.
 template <bool FIXED>
 __global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, const WarpParams* __restrict__ wp,
-                                              uint8_t* __restrict__ out, uint8_t* __restrict__ mask_new, int fh,
-                                              int fw, int ch, int cw) {
+                                              uint8_t* __restrict__ out, uint8_t* __restrict__ mask_new,
+                                              const DtJob* __restrict__ job_new, int fh, int fw, int ch, int cw) {
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
     const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
     if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 4 <= ry0) return;
     const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
-    if (x < rx0 || x >= rx1 || y < ry0 || y >= ry1) return;
+    if (y < ry0 || y >= ry1) return;  // a wave is 64 pixels of one row
+    const bool inroi = x >= rx0 && x < rx1;
     int v[3] = {0, 0, 0};
     if (FIXED) {
         const double* M = wp->M;
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, c
         const int ax = X & 31, ay = Y & 31;
         const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32;
         const int w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
-        if (sx >= -1 && sx < fw && sy >= -1 && sy < fh) {
+        if (inroi && sx >= -1 && sx < fw && sy >= -1 && sy < fh) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const int s = w00 * tap(src, fh, fw, sy, sx, c) + w01 * tap(src, fh, fw, sy, sx + 1, c) +
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, c
         const float w = (Mf[6] * fx + Mf[7] * fy) + Mf[8];
         const float sx = ((Mf[0] * fx + Mf[1] * fy) + Mf[2]) / w;
         const float sy = ((Mf[3] * fx + Mf[4] * fy) + Mf[5]) / w;
-        if (sx > -1.f && sx < (float)fw && sy > -1.f && sy < (float)fh) {
+        if (inroi && sx > -1.f && sx < (float)fw && sy > -1.f && sy < (float)fh) {
             const float flx = floorf(sx), fly = floorf(sy);
             const int ix = (int)flx, iy = (int)fly;
             const float a = sx - flx, b = sy - fly;
@@ -181,11 +188,23 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, c
             }
         }
     }
-    const size_t p = (size_t)y * cw + x;
-    out[3 * p] = (uint8_t)v[0];
-    out[3 * p + 1] = (uint8_t)v[1];
-    out[3 * p + 2] = (uint8_t)v[2];
-    if (mask_new) mask_new[p] = (v[0] | v[1] | v[2]) ? 255 : 0;
+    const bool zero = (v[0] | v[1] | v[2]) == 0;
+    if (inroi) {
+        const size_t p = (size_t)y * cw + x;
+        out[3 * p] = (uint8_t)v[0];
+        out[3 * p + 1] = (uint8_t)v[1];
+        out[3 * p + 2] = (uint8_t)v[2];
+        if (mask_new) mask_new[p] = zero ? 0 : 255;
+    }
+    if (job_new) {
+        // zero bit rows of the new mask for the distance transform (zero pixels of the ROI)
+        const unsigned long long bal = __ballot(inroi && zero);
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t* B = job_new->B + (size_t)y * job_new->wpitch + (bx >> 5);
+            B[0] = (uint32_t)bal;
+            B[1] = (uint32_t)(bal >> 32);
+        }
+    }
 }
 
 // weight_new = dn / (dn + do + 1e-6), weight_old = do / (...)  (main.py:892-894),
@@ -235,6 +254,9 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
 // and commit (main.py:905-927), per pixel of the ROI:
 //   new & old : canvas = trunc_u8(canvas * w_old + warped * w_new)
 //   new only  : canvas = warped
+// Also keeps mask_old (canvas pixel has a non-zero channel) and its zero bit rows (the
+// distance transform's input for the next frame) up to date: a wave is 64 pixels of one
+// row and rewrites the two bit words they belong to.
 __global__ __launch_bounds__(256) void k_blur_cols_commit(const WarpParams* __restrict__ wp,
                                                           const float* __restrict__ gk,
                                                           const float* __restrict__ rbn,
@@ -242,38 +264,49 @@ __global__ __launch_bounds__(256) void k_blur_cols_commit(const WarpParams* __re
                                                           const uint8_t* __restrict__ warped,
                                                           const uint8_t* __restrict__ mask_new,
                                                           uint8_t* __restrict__ mask_old,
-                                                          uint8_t* __restrict__ canvas, int ch, int cw) {
+                                                          uint8_t* __restrict__ canvas,
+                                                          const DtJob* __restrict__ job_old, int ch, int cw) {
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
     const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
     if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 4 <= ry0) return;
     const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
-    if (x < rx0 || x >= rx1 || y < ry0 || y >= ry1) return;
-    const size_t p = (size_t)y * cw + x;
-    if (!mask_new[p]) return;
-    if (!mask_old[p]) {
-        canvas[3 * p] = warped[3 * p];
-        canvas[3 * p + 1] = warped[3 * p + 1];
-        canvas[3 * p + 2] = warped[3 * p + 2];
-        mask_old[p] = 255;
-        return;
-    }
-    float a = gk[15] * rbn[p], b = gk[15] * rbo[p];
+    if (y < ry0 || y >= ry1) return;  // a wave is 64 pixels of one row
+    const bool oncanvas = x < cw;
+    const size_t p = (size_t)y * cw + (oncanvas ? x : 0);
+    int mo = oncanvas ? mask_old[p] : 255;
+    if (oncanvas && x >= rx0 && x < rx1 && mask_new[p]) {
+        if (!mo) {
+            canvas[3 * p] = warped[3 * p];
+            canvas[3 * p + 1] = warped[3 * p + 1];
+            canvas[3 * p + 2] = warped[3 * p + 2];
+            mo = 255;
+        } else {
+            float a = gk[15] * rbn[p], b = gk[15] * rbo[p];
 #pragma unroll
-    for (int i = 1; i <= 15; i++) {
-        const size_t pu = (size_t)reflect101(y + i, ch) * cw + x;
-        const size_t pd = (size_t)reflect101(y - i, ch) * cw + x;
-        a += gk[15 + i] * (rbn[pu] + rbn[pd]);
-        b += gk[15 + i] * (rbo[pu] + rbo[pd]);
-    }
-    int any = 0;
+            for (int i = 1; i <= 15; i++) {
+                const size_t pu = (size_t)reflect101(y + i, ch) * cw + x;
+                const size_t pd = (size_t)reflect101(y - i, ch) * cw + x;
+                a += gk[15 + i] * (rbn[pu] + rbn[pd]);
+                b += gk[15 + i] * (rbo[pu] + rbo[pd]);
+            }
+            int any = 0;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float v = (float)canvas[3 * p + c] * b + (float)warped[3 * p + c] * a;
-        const int q = (int)v;  // astype(uint8) truncates
-        canvas[3 * p + c] = (uint8_t)q;
-        any |= q & 255;
+            for (int c = 0; c < 3; c++) {
+                const float v = (float)canvas[3 * p + c] * b + (float)warped[3 * p + c] * a;
+                const int q = (int)v;  // astype(uint8) truncates
+                canvas[3 * p + c] = (uint8_t)q;
+                any |= q & 255;
+            }
+            mo = any ? 255 : 0;
+        }
+        mask_old[p] = (uint8_t)mo;
     }
-    mask_old[p] = any ? 255 : 0;
+    const unsigned long long bal = __ballot(oncanvas && mo == 0);
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t* B = job_old->B + (size_t)y * job_old->wpitch + (bx >> 5);
+        B[0] = (uint32_t)bal;
+        B[1] = (uint32_t)(bal >> 32);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_canvas_paste(const uint8_t* __restrict__ src, uint8_t* __restrict__ canvas,
@@ -308,25 +341,22 @@ int rtvm_warp_setup(rtvm_ctx* c) {
     float k[31];
     for (int i = 0; i < n; i++) k[i] = (float)(t[i] * sum);
     HIP_TRY(c, hipMemcpy(c->d_gk, k, sizeof(k), hipMemcpyHostToDevice));
-    const size_t n_px = (size_t)c->ch * c->cw;
-    DtJob jobs[3];
+    std::vector<DtJob> jobs(2 * RTVM_MAX_BATCH + 2);
     for (int j = 0; j < 2; j++) {
         jobs[j].mask = j == 0 ? c->d_mask_new : c->d_mask_old;
         jobs[j].pitch = c->cw;
         jobs[j].x0 = jobs[j].y0 = jobs[j].x1 = jobs[j].y1 = 0;
         jobs[j].ox0 = jobs[j].oy0 = jobs[j].ox1 = jobs[j].oy1 = 0;
-        jobs[j].sA = c->d_dt_s + (size_t)(2 * j) * n_px;
-        jobs[j].sB = c->d_dt_s + (size_t)(2 * j + 1) * n_px;
-        jobs[j].R = c->d_dt_r + (size_t)j * n_px;
-        jobs[j].dist = c->d_dist + (size_t)j * n_px;
-        jobs[j].Z = c->d_dt_z + (size_t)j * c->dt_z_words;
-        jobs[j].CS = c->d_dt_cs + (size_t)j * c->dt_cs_words;
-        jobs[j].znch = (c->ch + 31) / 32;
-        jobs[j].zpitch = c->cw + c->ch;
-        jobs[j].cpitch = c->cw;
+        rtvm_dt_job_planes(c, &jobs[j], j, c->cw, c->ch, c->cw);
     }
-    jobs[2] = jobs[0];
-    HIP_TRY(c, hipMemcpy(c->d_jobs, jobs, sizeof(jobs), hipMemcpyHostToDevice));
+    for (int j = 2; j < 2 * RTVM_MAX_BATCH; j++) jobs[j] = jobs[j & 1];
+    jobs[RTVM_JOB_STAGE] = jobs[0];
+    // the whole old mask: its zero bit rows are built once per canvas and then kept up to
+    // date by the commit kernel
+    jobs[RTVM_JOB_CANVAS] = jobs[1];
+    jobs[RTVM_JOB_CANVAS].x1 = jobs[RTVM_JOB_CANVAS].ox1 = c->cw;
+    jobs[RTVM_JOB_CANVAS].y1 = jobs[RTVM_JOB_CANVAS].oy1 = c->ch;
+    HIP_TRY(c, hipMemcpy(c->d_jobs, jobs.data(), jobs.size() * sizeof(DtJob), hipMemcpyHostToDevice));
     return RTVM_OK;
 }
 
@@ -337,6 +367,8 @@ int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int 
     RTVM_LAUNCH(c, k_canvas_paste, dim3((c->fw + 63) / 64, (c->fh + 3) / 4), dim3(256), 0, d_bgr,
                        c->d_canvas, c->d_mask_old, c->fh, c->fw, c->ch, c->cw, row_off, col_off);
     HIP_TRY(c, hipGetLastError());
+    int r = rtvm_launch_dt_bits(c, c->d_jobs + RTVM_JOB_CANVAS, 1, c->cw, c->ch);
+    if (r != RTVM_OK) return r;
     c->canvas_ready = 1;
     return RTVM_OK;
 }
@@ -348,34 +380,40 @@ int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, 
     const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
     if (c->flags & RTVM_FLAG_WARP_FIXED)
         RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
-                           c->fh, c->fw, c->ch, c->cw);
+                           (const DtJob*)nullptr, c->fh, c->fw, c->ch, c->cw);
     else
         RTVM_LAUNCH(c, k_warp<false>, grid, dim3(256), 0, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
-                           c->fh, c->fw, c->ch, c->cw);
+                           (const DtJob*)nullptr, c->fh, c->fw, c->ch, c->cw);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
 
-// The whole of VideMosaic.warp() for one frame, H read from device memory.
-int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, const int* d_skip) {
+int rtvm_launch_warp_prep(rtvm_ctx* c, const double* d_H, const int* d_skip, int n) {
+    RTVM_LAUNCH(c, k_warp_prep, dim3(n), dim3(64), 0, d_H, c->d_wp, c->d_jobs, c->fh, c->fw, c->ch, c->cw, 0, d_skip);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}
+
+// The whole of VideMosaic.warp() for frame j of the batch rtvm_launch_warp_prep prepared.
+int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, int j) {
     const size_t n_px = (size_t)c->ch * c->cw;
-    RTVM_LAUNCH(c, k_warp_prep, dim3(1), dim3(64), 0, d_H, c->d_wp, c->d_jobs, c->fh, c->fw, c->ch,
-                       c->cw, 0, d_skip);
+    const WarpParams* wp = c->d_wp + j;
+    const DtJob* jobs = c->d_jobs + 2 * j;
     const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
     if (c->flags & RTVM_FLAG_WARP_FIXED)
-        RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, d_bgr, c->d_wp, c->d_warped, c->d_mask_new,
-                           c->fh, c->fw, c->ch, c->cw);
+        RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, d_bgr, wp, c->d_warped, c->d_mask_new, jobs, c->fh, c->fw,
+                    c->ch, c->cw);
     else
-        RTVM_LAUNCH(c, k_warp<false>, grid, dim3(256), 0, d_bgr, c->d_wp, c->d_warped, c->d_mask_new,
-                           c->fh, c->fw, c->ch, c->cw);
-    int r = rtvm_launch_dt(c, c->d_jobs, 2, c->cw, c->ch);
+        RTVM_LAUNCH(c, k_warp<false>, grid, dim3(256), 0, d_bgr, wp, c->d_warped, c->d_mask_new, jobs, c->fh, c->fw,
+                    c->ch, c->cw);
+    int r = rtvm_launch_dt(c, jobs, 2, c->cw, c->ch, 0);
     if (r != RTVM_OK) return r;
     float* rbn = c->d_rb;
     float* rbo = c->d_rb + n_px;
-    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, c->ch), dim3(256), 0, c->d_wp, c->d_gk, c->d_dist,
+    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, c->ch), dim3(256), 0, wp, c->d_gk, c->d_dist,
                 c->d_dist + n_px, rbn, rbo, c->cw);
-    RTVM_LAUNCH(c, k_blur_cols_commit, grid, dim3(256), 0, c->d_wp, c->d_gk, rbn, rbo, c->d_warped,
-                       c->d_mask_new, c->d_mask_old, c->d_canvas, c->ch, c->cw);
+    RTVM_LAUNCH(c, k_blur_cols_commit, grid, dim3(256), 0, wp, c->d_gk, rbn, rbo, c->d_warped, c->d_mask_new,
+                c->d_mask_old, c->d_canvas, jobs + 1, c->ch, c->cw);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
