@@ -21,8 +21,8 @@ struct OrbDev {
     int cand_off[RTVM_NLEVELS], cand_cap[RTVM_NLEVELS];
     int sel_off[RTVM_NLEVELS];         // per-level selected arrays (capacity quota + 64)
     int xtab_off[RTVM_NLEVELS], ytab_off[RTVM_NLEVELS];
-    int tile_off[RTVM_NLEVELS + 1];    // 64x8 tiles of the FAST region, prefix over levels
-    int btile_off[RTVM_NLEVELS + 1];   // 64x8 tiles of the whole level, prefix over levels
+    int tile_off[RTVM_NLEVELS + 1];    // 64x32 tiles of the region inside the 31-pixel border, prefix over levels
+    int btile_off[RTVM_NLEVELS + 1];   // 64x32 tiles of the whole level, prefix over levels
     int umax[17];                      // half widths of the circular patch rows
     int gk7[7];                        // 7-tap Gaussian, 8-bit fixed point
     int max_kp;

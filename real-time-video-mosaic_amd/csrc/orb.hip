@@ -94,139 +94,124 @@ __device__ __forceinline__ int tile_level(const OrbDev& P, int tile, int* local)
     return l;
 }
 
-// Corner score of cv::FAST (type 9_16, threshold 20): max over the 16 arcs of 9
-// contiguous ring pixels of min(v - p) (bright centre) or min(p - v) (dark centre),
-// minus 1; 0 when no arc clears the threshold.  Scores are produced for the pixels
-// [30, W-30) x [30, H-30) of every level: the keypoints that survive the 31-pixel
-// border plus their 3x3 neighbourhood.
-__global__ __launch_bounds__(256) void k_fast_score(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
-    const FrameSlot& S = slots[sb + blockIdx.y];
-    const uint8_t* __restrict__ pyr = S.pyr;
-    uint8_t* __restrict__ score = S.score;
-    int local;
-    const int l = tile_level(P, blockIdx.x, &local);
-    const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
-    const int tiles_x = (W - 60 + 63) / 64;
-    const int tx0 = 30 + (local % tiles_x) * 64, ty0 = 30 + (local / tiles_x) * 8;
-    const uint8_t* img = pyr + P.off[l];
-    __shared__ uint8_t s[14][72];
-    for (int i = threadIdx.x; i < 14 * 70; i += 256) {
-        const int r = i / 70, c = i % 70;
-        const int y = min(ty0 - 3 + r, H - 1), x = min(tx0 - 3 + c, W - 1);
-        s[r][c] = img[(size_t)y * pitch + x];
+// Corner score of cv::FAST (type 9_16, threshold 20) of the pixel at LDS position
+// (row, col): max over the 16 arcs of 9 contiguous ring pixels of min(v - p) (bright
+// centre) or min(p - v) (dark centre), minus 1; 0 when no arc clears the threshold.
+template <int LP>
+__device__ __forceinline__ int fast_score_at(const uint8_t (*s)[LP], int row, int col) {
+    const int v = s[row][col];
+    int d[16];
+    d[0] = v - s[row + 3][col];
+    d[8] = v - s[row - 3][col];
+    // an arc of 9 contains one pixel of every opposite pair
+    if (!(max(d[0], d[8]) > FAST_T || min(d[0], d[8]) < -FAST_T)) return 0;
+    d[4] = v - s[row][col + 3];
+    d[12] = v - s[row][col - 3];
+    if (!(max(d[4], d[12]) > FAST_T || min(d[4], d[12]) < -FAST_T)) return 0;
+    d[1] = v - s[row + 3][col + 1];
+    d[2] = v - s[row + 2][col + 2];
+    d[3] = v - s[row + 1][col + 3];
+    d[5] = v - s[row - 1][col + 3];
+    d[6] = v - s[row - 2][col + 2];
+    d[7] = v - s[row - 3][col + 1];
+    d[9] = v - s[row - 3][col - 1];
+    d[10] = v - s[row - 2][col - 2];
+    d[11] = v - s[row - 1][col - 3];
+    d[13] = v - s[row + 1][col - 3];
+    d[14] = v - s[row + 2][col - 2];
+    d[15] = v - s[row + 3][col - 1];
+    bool bright = true, dark = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        bright &= max(d[k], d[k + 8]) > FAST_T;
+        dark &= min(d[k], d[k + 8]) < -FAST_T;
     }
-    __syncthreads();
-    const int cx = threadIdx.x & 63;
+    if (!(bright || dark)) return 0;
+    int best = 0;
+    // min over arcs of 9 by doubling: m2, m4, m8, then one more element
+    int m2[16], m4[16], M2[16], M4[16];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int cy = (threadIdx.x >> 6) + 4 * half;
-        const int x = tx0 + cx, y = ty0 + cy;
-        if (x >= W - 30 || y >= H - 30) continue;
-        const int v = s[cy + 3][cx + 3];
-        int d[16];
-        d[0] = v - s[cy + 6][cx + 3];
-        d[1] = v - s[cy + 6][cx + 4];
-        d[2] = v - s[cy + 5][cx + 5];
-        d[3] = v - s[cy + 4][cx + 6];
-        d[4] = v - s[cy + 3][cx + 6];
-        d[5] = v - s[cy + 2][cx + 6];
-        d[6] = v - s[cy + 1][cx + 5];
-        d[7] = v - s[cy + 0][cx + 4];
-        d[8] = v - s[cy + 0][cx + 3];
-        d[9] = v - s[cy + 0][cx + 2];
-        d[10] = v - s[cy + 1][cx + 1];
-        d[11] = v - s[cy + 2][cx + 0];
-        d[12] = v - s[cy + 3][cx + 0];
-        d[13] = v - s[cy + 4][cx + 0];
-        d[14] = v - s[cy + 5][cx + 1];
-        d[15] = v - s[cy + 6][cx + 2];
-        // an arc of 9 contains one pixel of every opposite pair
-        bool bright = true, dark = true;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            bright &= max(d[k], d[k + 8]) > FAST_T;
-            dark &= min(d[k], d[k + 8]) < -FAST_T;
-        }
-        int sc = 0;
-        if (bright || dark) {
-            int best = 0;
-            // min over arcs of 9 by doubling: m2, m4, m8, then one more element
-            int m2[16], m4[16], M2[16], M4[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                m2[k] = min(d[k], d[(k + 1) & 15]);
-                M2[k] = max(d[k], d[(k + 1) & 15]);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                m4[k] = min(m2[k], m2[(k + 2) & 15]);
-                M4[k] = max(M2[k], M2[(k + 2) & 15]);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int m9 = min(min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]);
-                const int M9 = max(max(M4[k], M4[(k + 4) & 15]), d[(k + 8) & 15]);
-                best = max(best, max(m9, -M9));
-            }
-            if (best > FAST_T) sc = best - 1;
-        }
-        score[P.off[l] + (size_t)y * pitch + x] = (uint8_t)sc;
+    for (int k = 0; k < 16; k++) {
+        m2[k] = min(d[k], d[(k + 1) & 15]);
+        M2[k] = max(d[k], d[(k + 1) & 15]);
     }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        m4[k] = min(m2[k], m2[(k + 2) & 15]);
+        M4[k] = max(M2[k], M2[(k + 2) & 15]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int m9 = min(min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int M9 = max(max(M4[k], M4[(k + 4) & 15]), d[(k + 8) & 15]);
+        best = max(best, max(m9, -M9));
+    }
+    return best > FAST_T ? best - 1 : 0;
 }
 
-// Keeps a scored pixel iff it beats its 8 neighbours strictly and lies at least
-// 31 pixels inside the level; appends (score << 24 | y << 12 | x) to the level's
-// candidate list and counts the score in the level's histogram (aggregated per
-// workgroup in LDS: one global atomic per workgroup and per occupied bin).
-__global__ __launch_bounds__(256) void k_fast_nms(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
+// FAST + 3x3 non-maximum suppression for one tile of 64 x 32 pixels of the region that
+// survives ORB's 31-pixel border: scores of the tile and a one-pixel rim in LDS, then a
+// pixel is kept iff its score beats its 8 neighbours strictly.  Keeps are appended as
+// (score << 24 | y << 12 | x) to the level's candidate list and counted in the level's
+// score histogram (aggregated per workgroup in LDS: one global atomic per workgroup
+// and per occupied bin).
+__global__ __launch_bounds__(256) void k_fast(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
     const FrameSlot& SL = slots[sb + blockIdx.y];
-    const uint8_t* __restrict__ score = SL.score;
     uint32_t* __restrict__ cand = SL.cand;
     int* __restrict__ cand_count = SL.cand_count;
     int* __restrict__ hist = SL.cand_count + RTVM_NLEVELS;
     int local;
     const int l = tile_level(P, blockIdx.x, &local);
     const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
-    const int tiles_x = (W - 60 + 63) / 64;
-    const int x = 30 + (local % tiles_x) * 64 + (threadIdx.x & 63);
-    const uint8_t* S = score + P.off[l];
-    // block-level aggregation: one counter atomic per block, histogram bins through LDS
+    const int tiles_x = (W - 2 * EDGE + 63) / 64;
+    const int tx0 = EDGE + (local % tiles_x) * 64, ty0 = EDGE + (local / tiles_x) * 32;
+    const uint8_t* __restrict__ img = SL.pyr + P.off[l];
+    // pixels: rows ty0-4 .. ty0+35, columns tx0-7 .. tx0+72 (tx0-7 is a multiple of 4)
+    __shared__ __align__(16) uint8_t s[40][80];
+    __shared__ uint8_t sc[34][68];
     __shared__ int s_hist[256];
+    __shared__ uint32_t s_list[512];
     __shared__ int s_cnt, s_base;
-    s_hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_cnt = 0;
+    const int tid = threadIdx.x;
+    s_hist[tid] = 0;
+    if (tid == 0) s_cnt = 0;
+    for (int i = tid; i < 40 * 20; i += 256) {
+        const int r = i / 20, q = i % 20;
+        const int y = min(ty0 - 4 + r, H - 1), x = min(tx0 - 7 + 4 * q, pitch - 4);
+        *reinterpret_cast<uint32_t*>(&s[r][4 * q]) = *reinterpret_cast<const uint32_t*>(img + (size_t)y * pitch + x);
+    }
     __syncthreads();
-    int my_pos[2] = {-1, -1}, my_s[2] = {0, 0}, my_y[2] = {0, 0};
+    // score-tile position (r, c) is pixel (tx0 - 1 + c, ty0 - 1 + r) = LDS (r + 3, c + 6)
+    for (int i = tid; i < 34 * 66; i += 256) {
+        const int r = i / 66, c = i % 66;
+        sc[r][c] = (uint8_t)fast_score_at<80>(s, r + 3, c + 6);
+    }
+    __syncthreads();
+    const int cx = tid & 63, x = tx0 + cx;
+    if (x < W - EDGE) {
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int y = 30 + (local / tiles_x) * 8 + (threadIdx.x >> 6) + 4 * half;
-        if (x >= EDGE && x < W - EDGE && y >= EDGE && y < H - EDGE) {
-            const uint8_t* p = S + (size_t)y * pitch + x;
-            const int s = p[0];
-            if (s && s > p[-1] && s > p[1] && s > p[-pitch - 1] && s > p[-pitch] && s > p[-pitch + 1] &&
-                s > p[pitch - 1] && s > p[pitch] && s > p[pitch + 1]) {
-                my_pos[half] = atomicAdd(&s_cnt, 1);
-                my_s[half] = s;
-                my_y[half] = y;
-                atomicAdd(&s_hist[s], 1);
+        for (int k = 0; k < 8; k++) {
+            const int cy = (tid >> 6) + 4 * k, y = ty0 + cy;
+            if (y >= H - EDGE) break;
+            const int v = sc[cy + 1][cx + 1];
+            if (v && v > sc[cy][cx] && v > sc[cy][cx + 1] && v > sc[cy][cx + 2] && v > sc[cy + 1][cx] &&
+                v > sc[cy + 1][cx + 2] && v > sc[cy + 2][cx] && v > sc[cy + 2][cx + 1] && v > sc[cy + 2][cx + 2]) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                s_list[pos] = ((uint32_t)v << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+                atomicAdd(&s_hist[v], 1);
             }
         }
     }
     __syncthreads();
-    const int n = s_cnt;
+    const int n = s_cnt;  // a strict 3x3 maximum: at most one per 2x2 block, 512 per tile
     if (n == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(&cand_count[l], n);
+    if (tid == 0) s_base = atomicAdd(&cand_count[l], n);
     __syncthreads();
     const int base = s_base;
-#pragma unroll
-    for (int half = 0; half < 2; half++)
-        if (my_pos[half] >= 0) {
-            const int pos = base + my_pos[half];
-            if (pos < P.cand_cap[l])
-                cand[P.cand_off[l] + pos] = ((uint32_t)my_s[half] << 24) | ((uint32_t)my_y[half] << 12) | (uint32_t)x;
-        }
-    const int hcount = s_hist[threadIdx.x];
-    if (hcount) atomicAdd(&hist[l * 256 + threadIdx.x], hcount);
+    for (int i = tid; i < n; i += 256)
+        if (base + i < P.cand_cap[l]) cand[P.cand_off[l] + base + i] = s_list[i];
+    const int hcount = s_hist[tid];
+    if (hcount) atomicAdd(&hist[l * 256 + tid], hcount);
 }
 
 // ------------------------------------------------------------------ selection
@@ -378,49 +363,88 @@ __global__ __launch_bounds__(1024) void k_orb_select(OrbDev P, const FrameSlot* 
 // ------------------------------------------------------------------ blur
 // GaussianBlur(7x7, sigma 2) as ORB runs it on each level: integer taps
 // cvRound(k * 256), exact row and column sums, round half to even, saturate.
+// One workgroup per tile of 64 x 32 pixels.
 __global__ __launch_bounds__(256) void k_blur7(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
     const FrameSlot& SL = slots[sb + blockIdx.y];
     const uint8_t* __restrict__ pyr = SL.pyr;
     uint8_t* __restrict__ out = SL.pyr_blur;
-    int local;
     int l = 0;
 #pragma unroll
     for (int k = 1; k < RTVM_NLEVELS; k++)
         if ((int)blockIdx.x >= P.btile_off[k]) l = k;
-    local = blockIdx.x - P.btile_off[l];
+    const int local = blockIdx.x - P.btile_off[l];
     const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
     const int tiles_x = (W + 63) / 64;
-    const int tx0 = (local % tiles_x) * 64, ty0 = (local / tiles_x) * 8;
-    const uint8_t* img = pyr + P.off[l];
-    __shared__ uint8_t s[14][72];
-    __shared__ int r[14][64];
-    for (int i = threadIdx.x; i < 14 * 70; i += 256) {
-        const int rr = i / 70, c = i % 70;
-        const int y = reflect101(ty0 - 3 + rr, H), x = reflect101(tx0 - 3 + c, W);
-        s[rr][c] = img[(size_t)y * pitch + x];
+    const int tx0 = (local % tiles_x) * 64, ty0 = (local / tiles_x) * 32;
+    const uint8_t* __restrict__ img = pyr + P.off[l];
+    // pixels: rows ty0-3 .. ty0+34, columns tx0-4 .. tx0+67 (LDS column = x - tx0 + 4)
+    __shared__ __align__(16) uint8_t s[38][72];
+    __shared__ uint32_t r[38][32];
+    const int tid = threadIdx.x;
+    if (tx0 >= 4 && tx0 + 68 <= W && ty0 >= 3 && ty0 + 35 <= H) {
+        for (int i = tid; i < 38 * 18; i += 256) {
+            const int rr = i / 18, q = i % 18;
+            *reinterpret_cast<uint32_t*>(&s[rr][4 * q]) =
+                *reinterpret_cast<const uint32_t*>(img + (size_t)(ty0 - 3 + rr) * pitch + tx0 - 4 + 4 * q);
+        }
+    } else {
+        for (int i = tid; i < 38 * 70; i += 256) {
+            const int rr = i / 70, c = i % 70;
+            const int y = reflect101(ty0 - 3 + rr, H), x = reflect101(tx0 - 3 + c, W);
+            s[rr][c + 1] = img[(size_t)y * pitch + x];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 14 * 64; i += 256) {
-        const int rr = i >> 6, c = i & 63;
-        int a = 0;
+    // row pass: 4 consecutive outputs per task from 12 staged bytes (3 aligned words);
+    // the sums fit 16 bits (the taps add up to 257: at most 65535) and are stored two per word
+    for (int i = tid; i < 38 * 16; i += 256) {
+        const int rr = i >> 4, g = i & 15;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&s[rr][4 * g]);
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        uint32_t px[12];
 #pragma unroll
-        for (int k = 0; k < 7; k++) a += P.gk7[k] * s[rr][c + k];
-        r[rr][c] = a;
+        for (int k = 0; k < 4; k++) {
+            px[k] = (w0 >> (8 * k)) & 255u;
+            px[4 + k] = (w1 >> (8 * k)) & 255u;
+            px[8 + k] = (w2 >> (8 * k)) & 255u;
+        }
+        uint32_t a[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            a[o] = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) a[o] += (uint32_t)P.gk7[k] * px[o + 1 + k];
+        }
+        r[rr][2 * g] = a[0] | (a[1] << 16);
+        r[rr][2 * g + 1] = a[2] | (a[3] << 16);
     }
     __syncthreads();
-    const int cx = threadIdx.x & 63;
+    // column pass: 2 adjacent columns x 4 rows per thread from 10 packed words
+    const int cp = tid & 31, rg = tid >> 5;
+    const int x = tx0 + 2 * cp;
+    if (x >= W) return;
+    uint32_t v[10];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int cy = (threadIdx.x >> 6) + 4 * half;
-        const int x = tx0 + cx, y = ty0 + cy;
-        if (x >= W || y >= H) continue;
-        unsigned a = 0;
+    for (int j = 0; j < 10; j++) v[j] = r[4 * rg + j][cp];
 #pragma unroll
-        for (int k = 0; k < 7; k++) a += (unsigned)P.gk7[k] * (unsigned)r[cy + k][cx];
-        unsigned q = a >> 16;
-        const unsigned rem = a & 0xFFFFu;
-        if (rem > 32768u || (rem == 32768u && (q & 1u))) q++;
-        out[P.off[l] + (size_t)y * pitch + x] = (uint8_t)(q > 255u ? 255u : q);
+    for (int i = 0; i < 4; i++) {
+        const int y = ty0 + 4 * rg + i;
+        if (y >= H) break;
+        uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            a0 += (uint32_t)P.gk7[k] * (v[i + k] & 0xFFFFu);
+            a1 += (uint32_t)P.gk7[k] * (v[i + k] >> 16);
+        }
+        uint32_t q0 = a0 >> 16, q1 = a1 >> 16;
+        const uint32_t m0 = a0 & 0xFFFFu, m1 = a1 & 0xFFFFu;
+        if (m0 > 32768u || (m0 == 32768u && (q0 & 1u))) q0++;
+        if (m1 > 32768u || (m1 == 32768u && (q1 & 1u))) q1++;
+        q0 = q0 > 255u ? 255u : q0;
+        q1 = q1 > 255u ? 255u : q1;
+        // x is even and the pitch a multiple of 64: the pair is 2-byte aligned; a column past
+        // the level's width lands in the row padding
+        *reinterpret_cast<uint16_t*>(out + P.off[l] + (size_t)y * pitch + x) = (uint16_t)(q0 | (q1 << 8));
     }
 }
 
@@ -573,9 +597,10 @@ int rtvm_orb_plan(rtvm_ctx* c) {
         xt += P.w[l];
         yt += P.h[l];
         P.tile_off[l] = tiles;
-        if (P.w[l] > 2 * EDGE && P.h[l] > 2 * EDGE) tiles += ((P.w[l] - 60 + 63) / 64) * ((P.h[l] - 60 + 7) / 8);
+        if (P.w[l] > 2 * EDGE && P.h[l] > 2 * EDGE)
+            tiles += ((P.w[l] - 2 * EDGE + 63) / 64) * ((P.h[l] - 2 * EDGE + 31) / 32);
         P.btile_off[l] = btiles;
-        btiles += ((P.w[l] + 63) / 64) * ((P.h[l] + 7) / 8);
+        btiles += ((P.w[l] + 63) / 64) * ((P.h[l] + 31) / 32);
     }
     P.tile_off[RTVM_NLEVELS] = tiles;
     P.btile_off[RTVM_NLEVELS] = btiles;
@@ -652,8 +677,7 @@ int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
                     P.pitch[l - 1], P.off[l], P.w[l], P.h[l], P.pitch[l], c->d_xofs + P.xtab_off[l],
                     c->d_xw + P.xtab_off[l], c->d_yofs + P.ytab_off[l], c->d_yw + P.ytab_off[l]);
     if (P.tile_off[RTVM_NLEVELS] > 0) {
-        RTVM_LAUNCH(c, k_fast_score, dim3(P.tile_off[RTVM_NLEVELS], nb), dim3(256), 0, P, sl, sb);
-        RTVM_LAUNCH(c, k_fast_nms, dim3(P.tile_off[RTVM_NLEVELS], nb), dim3(256), 0, P, sl, sb);
+        RTVM_LAUNCH(c, k_fast, dim3(P.tile_off[RTVM_NLEVELS], nb), dim3(256), 0, P, sl, sb);
     }
     RTVM_LAUNCH(c, k_orb_select, dim3(RTVM_NLEVELS, nb), dim3(1024), 0, P, sl, sb);
     RTVM_LAUNCH(c, k_blur7, dim3(P.btile_off[RTVM_NLEVELS], nb), dim3(256), 0, P, sl, sb);

@@ -210,53 +210,78 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, c
 // weight_new = dn / (dn + do + 1e-6), weight_old = do / (...)  (main.py:892-894),
 // evaluated while staging, then the row pass of cv2.GaussianBlur(w, (31,31), 0)
 // (main.py:897-898) for both weights: 31 taps added left to right in float32,
-// BORDER_REFLECT_101 at the canvas edge.  dn is zero outside the ROI.  One
-// workgroup = 256 consecutive pixels of one row, staged through LDS.
+// BORDER_REFLECT_101 at the canvas edge.  dn is zero outside the ROI.  One wave =
+// 256 consecutive pixels of one row staged through LDS, 4 outputs per lane from a
+// window of 34 staged values; a workgroup takes 4 rows.
 __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
                                                    const float* __restrict__ dn, const float* __restrict__ dold,
                                                    float* __restrict__ rbn, float* __restrict__ rbo, int cw) {
     const int rx0 = wp->rx0, rx1 = wp->rx1, wy0 = wp->wy0, wy1 = wp->wy1;
-    const int bx = blockIdx.x * 256, y = blockIdx.y;
-    if (y < wy0 || y >= wy1 || bx >= rx1 || bx + 256 <= rx0) return;
-    __shared__ float s_n[256 + 30], s_o[256 + 30];
-    __shared__ float s_k[31];
+    const int bx = blockIdx.x * 256, by = blockIdx.y * 4;
+    if (by >= wy1 || by + 4 <= wy0 || bx >= rx1 || bx + 256 <= rx0) return;
+    __shared__ __align__(16) float s_n[4][288], s_o[4][288];
+    __shared__ float s_k[32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int y = by + wv;
+    const bool row_ok = y >= wy0 && y < wy1;
     const size_t row = (size_t)y * cw;
-    const bool row_in_roi = y >= wp->ry0 && y < wp->ry1;
-    for (int i = threadIdx.x; i < 256 + 30; i += 256) {
-        const int xs = reflect101(bx - 15 + i, cw);
-        // distances exist on [wx0, wx1); columns this row pass never needs may lie outside
-        float wn = 0.f, wo = 0.f;
-        if (xs >= wp->wx0 && xs < wp->wx1) {
-            const float a = (row_in_roi && xs >= rx0 && xs < rx1) ? dn[row + xs] : 0.f;
-            const float b = dold[row + xs];
-            const float sum = (a + b) + 1e-6f;
-            wn = a / sum;
-            wo = b / sum;
+    if (row_ok) {
+        const bool row_in_roi = y >= wp->ry0 && y < wp->ry1;
+        for (int i = lane; i < 288; i += 64) {
+            float wn = 0.f, wo = 0.f;
+            if (i < 256 + 30) {
+                const int xs = reflect101(bx - 15 + i, cw);
+                // distances exist on [wx0, wx1); columns this row pass never needs may lie outside
+                if (xs >= wp->wx0 && xs < wp->wx1) {
+                    const float a = (row_in_roi && xs >= rx0 && xs < rx1) ? dn[row + xs] : 0.f;
+                    const float b = dold[row + xs];
+                    const float sum = (a + b) + 1e-6f;
+                    wn = a / sum;
+                    wo = b / sum;
+                }
+            }
+            s_n[wv][i] = wn;
+            s_o[wv][i] = wo;
         }
-        s_n[i] = wn;
-        s_o[i] = wo;
     }
     if (threadIdx.x < 31) s_k[threadIdx.x] = gk[threadIdx.x];
     __syncthreads();
-    const int x = bx + threadIdx.x;
-    if (x < rx0 || x >= rx1) return;
-    float a = s_k[0] * s_n[threadIdx.x], b = s_k[0] * s_o[threadIdx.x];
+    if (!row_ok) return;
+    const int x = bx + 4 * lane;
+    if (x + 4 <= rx0 || x >= rx1) return;
+    float k[31];
 #pragma unroll
-    for (int i = 1; i < 31; i++) {
-        a += s_k[i] * s_n[threadIdx.x + i];
-        b += s_k[i] * s_o[threadIdx.x + i];
+    for (int i = 0; i < 31; i++) k[i] = s_k[i];
+    float vn[36], vo[36];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const float4 a = *reinterpret_cast<const float4*>(&s_n[wv][4 * lane + 4 * q]);
+        const float4 b = *reinterpret_cast<const float4*>(&s_o[wv][4 * lane + 4 * q]);
+        vn[4 * q] = a.x, vn[4 * q + 1] = a.y, vn[4 * q + 2] = a.z, vn[4 * q + 3] = a.w;
+        vo[4 * q] = b.x, vo[4 * q + 1] = b.y, vo[4 * q + 2] = b.z, vo[4 * q + 3] = b.w;
     }
-    rbn[row + x] = a;
-    rbo[row + x] = b;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        if (x + o < rx0 || x + o >= rx1) continue;
+        float a = k[0] * vn[o], b = k[0] * vo[o];
+#pragma unroll
+        for (int i = 1; i < 31; i++) {
+            a += k[i] * vn[o + i];
+            b += k[i] * vo[o + i];
+        }
+        rbn[row + x + o] = a;
+        rbo[row + x + o] = b;
+    }
 }
 
 // Column pass of the blur (centre tap, then symmetric pairs outwards), blend
 // and commit (main.py:905-927), per pixel of the ROI:
 //   new & old : canvas = trunc_u8(canvas * w_old + warped * w_new)
 //   new only  : canvas = warped
-// Also keeps mask_old (canvas pixel has a non-zero channel) and its zero bit rows (the
-// distance transform's input for the next frame) up to date: a wave is 64 pixels of one
-// row and rewrites the two bit words they belong to.
+// A lane takes 4 consecutive rows of one column: a window of 34 row-blurred weights
+// serves the 4 column sums.  Also keeps mask_old (canvas pixel has a non-zero channel)
+// and its zero bit rows (the distance transform's input for the next frame) up to date:
+// a wave is 64 pixels of a row and rewrites the two bit words they belong to.
 __global__ __launch_bounds__(256) void k_blur_cols_commit(const WarpParams* __restrict__ wp,
                                                           const float* __restrict__ gk,
                                                           const float* __restrict__ rbn,
@@ -267,45 +292,77 @@ __global__ __launch_bounds__(256) void k_blur_cols_commit(const WarpParams* __re
                                                           uint8_t* __restrict__ canvas,
                                                           const DtJob* __restrict__ job_old, int ch, int cw) {
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
-    const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
-    if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 4 <= ry0) return;
-    const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
-    if (y < ry0 || y >= ry1) return;  // a wave is 64 pixels of one row
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 16;
+    if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 16 <= ry0) return;
+    const int x = bx + (threadIdx.x & 63), ya = by + 4 * (threadIdx.x >> 6);
+    if (ya >= ry1 || ya + 4 <= ry0) return;  // a wave is 64 pixels of 4 rows
     const bool oncanvas = x < cw;
-    const size_t p = (size_t)y * cw + (oncanvas ? x : 0);
-    int mo = oncanvas ? mask_old[p] : 255;
-    if (oncanvas && x >= rx0 && x < rx1 && mask_new[p]) {
-        if (!mo) {
+    const bool incol = oncanvas && x >= rx0 && x < rx1;
+    int mo[4], state[4];  // state: 0 = untouched, 1 = paste, 2 = blend
+    bool any_blend = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int y = ya + i;
+        const bool rowin = y >= ry0 && y < ry1;  // implies y < ch
+        const size_t p = (size_t)(rowin ? y : ry0) * cw + (oncanvas ? x : 0);
+        mo[i] = (oncanvas && y < ch) ? mask_old[(size_t)min(y, ch - 1) * cw + x] : 255;
+        state[i] = 0;
+        if (incol && rowin && mask_new[p]) state[i] = mo[i] ? 2 : 1;
+        any_blend |= state[i] == 2;
+    }
+    float a[4], b[4];
+    if (any_blend) {
+        float vn[34], vo[34];
+#pragma unroll
+        for (int j = 0; j < 34; j++) {
+            const size_t q = (size_t)reflect101(ya - 15 + j, ch) * cw + x;
+            vn[j] = rbn[q];
+            vo[j] = rbo[q];
+        }
+        float k[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) k[i] = gk[15 + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            a[i] = k[0] * vn[15 + i];
+            b[i] = k[0] * vo[15 + i];
+#pragma unroll
+            for (int t = 1; t <= 15; t++) {
+                a[i] += k[t] * (vn[15 + i + t] + vn[15 + i - t]);
+                b[i] += k[t] * (vo[15 + i + t] + vo[15 + i - t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int y = ya + i;
+        const size_t p = (size_t)y * cw + x;
+        if (state[i] == 1) {
             canvas[3 * p] = warped[3 * p];
             canvas[3 * p + 1] = warped[3 * p + 1];
             canvas[3 * p + 2] = warped[3 * p + 2];
-            mo = 255;
-        } else {
-            float a = gk[15] * rbn[p], b = gk[15] * rbo[p];
-#pragma unroll
-            for (int i = 1; i <= 15; i++) {
-                const size_t pu = (size_t)reflect101(y + i, ch) * cw + x;
-                const size_t pd = (size_t)reflect101(y - i, ch) * cw + x;
-                a += gk[15 + i] * (rbn[pu] + rbn[pd]);
-                b += gk[15 + i] * (rbo[pu] + rbo[pd]);
-            }
+            mo[i] = 255;
+            mask_old[p] = 255;
+        } else if (state[i] == 2) {
             int any = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float v = (float)canvas[3 * p + c] * b + (float)warped[3 * p + c] * a;
+                const float v = (float)canvas[3 * p + c] * b[i] + (float)warped[3 * p + c] * a[i];
                 const int q = (int)v;  // astype(uint8) truncates
                 canvas[3 * p + c] = (uint8_t)q;
                 any |= q & 255;
             }
-            mo = any ? 255 : 0;
+            mo[i] = any ? 255 : 0;
+            mask_old[p] = (uint8_t)mo[i];
         }
-        mask_old[p] = (uint8_t)mo;
-    }
-    const unsigned long long bal = __ballot(oncanvas && mo == 0);
-    if ((threadIdx.x & 63) == 0) {
-        uint32_t* B = job_old->B + (size_t)y * job_old->wpitch + (bx >> 5);
-        B[0] = (uint32_t)bal;
-        B[1] = (uint32_t)(bal >> 32);
+        if (y < ch) {  // wave-uniform
+            const unsigned long long bal = __ballot(oncanvas && mo[i] == 0);
+            if ((threadIdx.x & 63) == 0) {
+                uint32_t* B = job_old->B + (size_t)y * job_old->wpitch + (bx >> 5);
+                B[0] = (uint32_t)bal;
+                B[1] = (uint32_t)(bal >> 32);
+            }
+        }
     }
 }
 
@@ -410,9 +467,9 @@ int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, int j) {
     if (r != RTVM_OK) return r;
     float* rbn = c->d_rb;
     float* rbo = c->d_rb + n_px;
-    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, c->ch), dim3(256), 0, wp, c->d_gk, c->d_dist,
+    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, (c->ch + 3) / 4), dim3(256), 0, wp, c->d_gk, c->d_dist,
                 c->d_dist + n_px, rbn, rbo, c->cw);
-    RTVM_LAUNCH(c, k_blur_cols_commit, grid, dim3(256), 0, wp, c->d_gk, rbn, rbo, c->d_warped, c->d_mask_new,
+    RTVM_LAUNCH(c, k_blur_cols_commit, dim3((c->cw + 63) / 64, (c->ch + 15) / 16), dim3(256), 0, wp, c->d_gk, rbn, rbo, c->d_warped, c->d_mask_new,
                 c->d_mask_old, c->d_canvas, jobs + 1, c->ch, c->cw);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
