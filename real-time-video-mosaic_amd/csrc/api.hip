@@ -126,22 +126,81 @@ int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int with_orb) {
     return RTVM_OK;
 }
 
-// Work planes of distance-transform job `slot` (0 or 1) for an image of h x w pixels with
-// the given pitch.
-void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int slot, int pitch, int h, int w) {
+// One device allocation per frame of a batch: warped frame, its mask, and the work planes
+// of the two distance transforms (kind 0 = new mask, 1 = predicted old mask).
+struct SidePlanes {
+    uint16_t* S;
+    uint32_t* R;
+    float* dist;
+    uint32_t *B, *Z, *Z16, *CS;
+};
+
+static void carve_side(const rtvm_ctx* c, Carver& k, SideDev& sd, SidePlanes p[2]) {
     const size_t n_px = (size_t)c->ch * c->cw;
-    jb->S = c->d_dt_s + (size_t)slot * n_px;
-    jb->R = c->d_dt_r + (size_t)slot * n_px;
-    jb->dist = c->d_dist + (size_t)slot * n_px;
-    jb->B = c->d_dt_b + (size_t)slot * c->dt_b_words;
-    jb->Z = c->d_dt_z + (size_t)slot * c->dt_z_words;
-    jb->Z16 = c->d_dt_z16 + (size_t)slot * c->dt_z16_words;
-    jb->CS = c->d_dt_cs + (size_t)slot * c->dt_cs_words;
+    sd.warped = k.take<uint8_t>(n_px * 3);
+    sd.mask_new = k.take<uint8_t>(n_px);
+    for (int kind = 0; kind < 2; kind++) {
+        p[kind].S = k.take<uint16_t>(n_px + 64);
+        p[kind].R = k.take<uint32_t>(n_px + 64);
+        p[kind].dist = k.take<float>(n_px);
+        p[kind].B = k.take<uint32_t>(c->dt_b_words);
+        p[kind].Z = k.take<uint32_t>(c->dt_z_words);
+        p[kind].Z16 = k.take<uint32_t>(c->dt_z16_words);
+        p[kind].CS = k.take<uint32_t>(c->dt_cs_words);
+    }
+    sd.dist_new = p[0].dist;
+    sd.dist_old = p[1].dist;
+}
+
+void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int side, int kind, int pitch, int h, int w) {
+    SideDev sd;
+    SidePlanes p[2];
+    Carver k{(char*)c->side_arena[side], 0};
+    carve_side(c, k, sd, p);
+    jb->S = p[kind].S;
+    jb->R = p[kind].R;
+    jb->dist = p[kind].dist;
+    jb->B = p[kind].B;
+    jb->Z = p[kind].Z;
+    jb->Z16 = p[kind].Z16;
+    jb->CS = p[kind].CS;
     jb->wpitch = (pitch + 31) / 32 + 2;
     jb->znch = (h + 31) / 32;
     jb->zg = (jb->znch + 15) / 16;
     jb->zpitch = w + h;
     jb->cpitch = w;
+}
+
+// Allocates the planes of frame `side` of a batch and publishes them: d_side[side] and the
+// constant part of the frame's two distance-transform jobs.
+int rtvm_side_alloc(rtvm_ctx* c, int side) {
+    SideDev sd;
+    SidePlanes p[2];
+    Carver dry{nullptr, 0};
+    carve_side(c, dry, sd, p);
+    const size_t bytes = dry.off + 256;
+    void* arena = nullptr;
+    hipError_t e = hipMalloc(&arena, bytes);
+    if (e != hipSuccess)
+        RTVM_FAIL(c, RTVM_E_NOMEM, "hipMalloc(%zu bytes) for the warp planes of batch frame %d failed: %s", bytes, side,
+                  hipGetErrorString(e));
+    c->side_arena[side] = arena;
+    HIP_TRY(c, hipMemset(arena, 0, bytes));
+    Carver k{(char*)arena, 0};
+    carve_side(c, k, sd, p);
+    c->h_side[side] = sd;
+    HIP_TRY(c, hipMemcpy(&c->d_side[side], &sd, sizeof(SideDev), hipMemcpyHostToDevice));
+    DtJob jobs[2];
+    for (int kind = 0; kind < 2; kind++) {
+        DtJob& jb = jobs[kind];
+        memset(&jb, 0, sizeof(jb));
+        jb.mask = kind ? c->d_mask_old : sd.mask_new;
+        jb.pitch = c->cw;
+        rtvm_dt_job_planes(c, &jb, side, kind, c->cw, c->ch, c->cw);
+    }
+    HIP_TRY(c, hipMemcpy(&c->d_jobs[side], &jobs[0], sizeof(DtJob), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(&c->d_jobs[RTVM_MAX_BATCH + side], &jobs[1], sizeof(DtJob), hipMemcpyHostToDevice));
+    return RTVM_OK;
 }
 
 namespace {
@@ -174,11 +233,7 @@ int alloc_all(rtvm_ctx* c) {
     // canvas / warp / blend
     const size_t n_px = (size_t)c->ch * c->cw;
     ALLOC(c, d_canvas, n_px * 3);
-    ALLOC(c, d_warped, n_px * 3);
-    ALLOC(c, d_mask_new, n_px);
     ALLOC(c, d_mask_old, n_px);
-    ALLOC(c, d_dt_s, n_px * 2 + 64);
-    ALLOC(c, d_dt_r, n_px * 2 + 64);
     {
         // sized for any image rtvm_distance_transform accepts: h < ch + 64, h + w <= ch + cw
         const size_t nch = (size_t)(c->ch + 31) / 32 + 1, lines = (size_t)c->cw + c->ch + 64;
@@ -187,16 +242,17 @@ int alloc_all(rtvm_ctx* c) {
         c->dt_z16_words = 2 * ((nch + 15) / 16 + 1) * lines;
         c->dt_cs_words = 2 * nch * lines;
     }
-    ALLOC(c, d_dt_b, c->dt_b_words * 2);
-    ALLOC(c, d_dt_z, c->dt_z_words * 2);
-    ALLOC(c, d_dt_z16, c->dt_z16_words * 2);
-    ALLOC(c, d_dt_cs, c->dt_cs_words * 2);
-    ALLOC(c, d_dist, n_px * 2);
+    ALLOC(c, d_bold, c->dt_b_words);
     ALLOC(c, d_rb, n_px * 2);
     ALLOC(c, d_gk, 32);
     ALLOC(c, d_H, RTVM_MAX_BATCH * 9 + 16);
     ALLOC(c, d_wp, RTVM_MAX_BATCH);
     ALLOC(c, d_jobs, 2 * RTVM_MAX_BATCH + 2);
+    ALLOC(c, d_side, RTVM_MAX_BATCH);
+    c->h_side = (SideDev*)calloc(RTVM_MAX_BATCH, sizeof(SideDev));
+    if (!c->h_side) RTVM_FAIL(c, RTVM_E_NOMEM, "host allocation failed");
+    if ((r = rtvm_side_alloc(c, 0))) return r;
+    c->n_side = 1;
     if ((r = rtvm_warp_setup(c))) return r;
     // RANSAC constant table
     c->rs_raw_n = 32768;
@@ -224,6 +280,7 @@ int alloc_all(rtvm_ctx* c) {
         if ((r = rtvm_orb_setup(c))) return r;
     }
     ALLOC(c, d_state, 1);
+    ALLOC(c, d_snap, RTVM_MAX_BATCH);
     ALLOC(c, d_wtab, 32);
     ALLOC(c, d_skip, RTVM_MAX_BATCH);
     if ((r = rtvm_stream_setup(c))) return r;
@@ -231,8 +288,8 @@ int alloc_all(rtvm_ctx* c) {
 }
 
 void free_all(rtvm_ctx* c) {
-    void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas, c->d_warped, c->d_mask_new,
-                    c->d_mask_old, c->d_dt_s, c->d_dt_r, c->d_dt_b, c->d_dt_z, c->d_dt_z16, c->d_dt_cs, c->d_dist, c->d_rb, c->d_gk, c->d_H,
+    void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas,
+                    c->d_mask_old, c->d_bold, c->d_side, c->d_snap, c->d_rb, c->d_gk, c->d_H,
                     c->d_wp, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
                     c->d_skip};
     free_feat(&c->feat_prev);
@@ -240,6 +297,9 @@ void free_all(rtvm_ctx* c) {
         if (p) (void)hipFree(p);
     for (int i = 0; i <= RTVM_MAX_SLOTS; i++)
         if (c->slot_arena[i]) (void)hipFree(c->slot_arena[i]);
+    for (int i = 0; i < RTVM_MAX_BATCH; i++)
+        if (c->side_arena[i]) (void)hipFree(c->side_arena[i]);
+    free(c->h_side);
     free(c->h_slots);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (int k = 0; k < RTVM_NSETS; k++) {
@@ -451,6 +511,10 @@ extern "C" int rtvm_reserve_batch(rtvm_ctx* c, int n) {
         if ((r = rtvm_slots_alloc(c, s, c->orb.max_kp, 1))) return r;
         c->n_batch = s + 1;
     }
+    for (int s = c->n_side; s < n; s++) {
+        if ((r = rtvm_side_alloc(c, s))) return r;
+        c->n_side = s + 1;
+    }
     for (int s = c->n_set1; s < n; s++) {
         for (int k = 1; k < RTVM_NSETS; k++)
             if ((r = rtvm_slots_alloc(c, k * RTVM_MAX_BATCH + s, c->orb.max_kp, 1))) return r;
@@ -524,8 +588,8 @@ extern "C" int rtvm_warp_perspective(rtvm_ctx* c, const uint8_t* bgr, const doub
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
     if ((r = upload_H(c, H))) return r;
-    if ((r = rtvm_launch_warp_only(c, c->d_bgr, c->d_H, c->d_warped))) return r;
-    HIP_TRY(c, hipMemcpyAsync(out, c->d_warped, (size_t)c->ch * c->cw * 3, hipMemcpyDeviceToHost, c->stream));
+    if ((r = rtvm_launch_warp_only(c, c->d_bgr, c->d_H, c->h_side[0].warped))) return r;
+    HIP_TRY(c, hipMemcpyAsync(out, c->h_side[0].warped, (size_t)c->ch * c->cw * 3, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RTVM_OK;
 }
@@ -537,7 +601,7 @@ extern "C" int rtvm_distance_transform(rtvm_ctx* c, const uint8_t* mask, int h, 
         RTVM_FAIL(c, RTVM_E_ARG, "distance_transform: %dx%d exceeds the context's canvas (%dx%d)", h, w, c->ch, c->cw);
     HIP_TRY(c, hipSetDevice(c->device));
     DtJob* jb = (DtJob*)((char*)c->h_pinned + 1024);
-    jb->mask = c->d_mask_new;
+    jb->mask = c->h_side[0].mask_new;
     jb->pitch = w;
     jb->x0 = jb->y0 = 0;
     jb->x1 = w;
@@ -545,12 +609,12 @@ extern "C" int rtvm_distance_transform(rtvm_ctx* c, const uint8_t* mask, int h, 
     jb->ox0 = jb->oy0 = 0;
     jb->ox1 = w;
     jb->oy1 = h;
-    rtvm_dt_job_planes(c, jb, 0, w, h, w);
+    rtvm_dt_job_planes(c, jb, 0, 0, w, h, w);
     HIP_TRY(c, hipMemcpyAsync(c->d_jobs + RTVM_JOB_STAGE, jb, sizeof(DtJob), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_mask_new, mask, (size_t)h * w, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_side[0].mask_new, mask, (size_t)h * w, hipMemcpyHostToDevice, c->stream));
     int r = rtvm_launch_dt(c, c->d_jobs + RTVM_JOB_STAGE, 1, w, h, 1);
     if (r) return r;
-    HIP_TRY(c, hipMemcpyAsync(dist, c->d_dist, (size_t)h * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dist, c->h_side[0].dist_new, (size_t)h * w * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RTVM_OK;
 }
@@ -564,8 +628,7 @@ extern "C" int rtvm_warp_blend(rtvm_ctx* c, const uint8_t* bgr, const double H[9
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
     if ((r = upload_H(c, H))) return r;
-    if ((r = rtvm_launch_warp_prep(c, c->d_H, nullptr, 1))) return r;
-    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, 0))) return r;
+    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H))) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RTVM_OK;
 }

@@ -102,6 +102,16 @@ struct DtJob {
     int wpitch, znch, zg, zpitch, cpitch;
 };
 
+// The planes one frame of a batch is warped into and measured on, besides the canvas.
+// Every frame of a batch has its own set, so that the warps and the distance transforms
+// of a whole batch run as single launches.
+struct SideDev {
+    uint8_t* warped;     // ch*cw*3: the frame in canvas coordinates (ROI only)
+    uint8_t* mask_new;   // ch*cw: warped pixel has a non-zero channel
+    float* dist_new;     // distance transform of mask_new
+    float* dist_old;     // distance transform of the canvas mask as it is before this frame
+};
+
 // Per-frame warp parameters, written on the device by k_warp_prep.
 struct WarpParams {
     double M[9];       // H^-1
@@ -128,6 +138,8 @@ struct StreamState {
     int last_good;     // batch index of the last frame that advanced the state, -1 if none
     int tail_ok;       // the last frame of the last batch advanced the state (a batch whose front
                        // half was matched against that frame ahead of time is valid)
+    int bad_frame;     // first frame of the batch whose blend cleared a canvas pixel: the canvas
+                       // masks predicted for the later frames of the batch are wrong
     int b_status[RTVM_MAX_BATCH];
     int b_matches[RTVM_MAX_BATCH];
     int b_kp[RTVM_MAX_BATCH];
@@ -203,26 +215,24 @@ struct rtvm_ctx {
 
     // --- canvas / warp / blend ---
     uint8_t* d_canvas;     // ch*cw*3
-    uint8_t* d_warped;     // ch*cw*3
-    uint8_t* d_mask_new;   // ch*cw
-    uint8_t* d_mask_old;   // ch*cw
-    uint16_t* d_dt_s;      // diagonal step planes: [2 jobs][ch*cw]
-    uint32_t* d_dt_r;      // row-pass planes [2][ch*cw]
-    uint32_t* d_dt_b;      // zero bit rows, per job
-    uint32_t* d_dt_z;      // diagonal zero bitmaps, per job
-    uint32_t* d_dt_z16;    // chunk-group summaries of the bitmaps, per job
-    uint32_t* d_dt_cs;     // column chunk summaries, per job
-    size_t dt_b_words, dt_z_words, dt_z16_words, dt_cs_words;  // per job
-    float* d_dist;         // [2][ch*cw]: 0 = new, 1 = old
+    uint8_t* d_mask_old;   // ch*cw: canvas pixel has a non-zero channel
+    uint32_t* d_bold;      // zero bit rows of d_mask_old, kept up to date by the commit kernel
+    size_t dt_b_words, dt_z_words, dt_z16_words, dt_cs_words;  // per distance-transform job
+    SideDev* h_side;       // per frame of a batch (host mirror of d_side)
+    SideDev* d_side;
+    void* side_arena[RTVM_MAX_BATCH];  // one device allocation per frame of a batch
+    int n_side;            // sides 0..n_side-1 are allocated
     float* d_rb;           // row-blurred weights [2][ch*cw]
     float* d_gk;           // 31 Gaussian taps
     double* d_H;           // RTVM_MAX_BATCH x 9 doubles: homographies handed to the warp
     WarpParams* d_wp;      // one per frame of a batch
-    DtJob* d_jobs;         // [2j] = new mask on the ROI, [2j+1] = old mask on the canvas of frame j of a
-                           // batch; then RTVM_JOB_STAGE (stage API) and RTVM_JOB_CANVAS (whole old mask)
+    DtJob* d_jobs;         // [j] = new mask on the ROI, [RTVM_MAX_BATCH + j] = old mask on the canvas for
+                           // frame j of a batch; then RTVM_JOB_STAGE (stage API) and RTVM_JOB_CANVAS
+                           // (the whole old mask, for its bit rows)
     int canvas_ready;
 
     StreamState* d_state;
+    StreamState* d_snap;   // state after each frame of the batch (RTVM_MAX_BATCH entries)
     double* d_wtab;        // smoothing weights, row n = linspace(0.5, 1, n) / sum
     int* d_skip;           // RTVM_MAX_BATCH flags: 1 when the frame is not to be stitched
     int stream_ready;
@@ -255,15 +265,23 @@ int rtvm_launch_hamming(rtvm_ctx* c, int sb, int nb, int cap_q, int cap_t, int s
 // with_bits = 0: the zero bit rows of the jobs (DtJob::B) are already up to date
 int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h, int with_bits);
 int rtvm_launch_dt_bits(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h);
-void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int slot, int pitch, int h, int w);  // api.hip
+// api.hip: work planes of side `side`, kind 0 (new mask) or 1 (old mask), for an h x w image
+void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int side, int kind, int pitch, int h, int w);
+int rtvm_side_alloc(rtvm_ctx* c, int side);
 // warp.hip
 int rtvm_warp_setup(rtvm_ctx* c);  // uploads constant tables (after allocation)
 int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_off);
 int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out);
-// warp parameters and distance-transform jobs of n frames (homographies d_H[9*j], optional
-// "do not stitch" flags d_skip[j]), then the whole of VideMosaic.warp() for frame j
+// VideMosaic.warp() for the n frames of a batch (homographies d_H[9*j], optional "do not
+// stitch" flags d_skip[j]): warp parameters and distance-transform jobs; warps, masks and
+// new-mask distances of all frames; predicted canvas masks and their distances for all
+// frames; then, frame by frame, weights + blur + blend + commit.
 int rtvm_launch_warp_prep(rtvm_ctx* c, const double* d_H, const int* d_skip, int n);
-int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, int j);
+int rtvm_launch_new_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n);
+int rtvm_launch_old_sides(rtvm_ctx* c, int n);
+int rtvm_launch_blend_commit(rtvm_ctx* c, int j);
+// all of the above for one frame
+int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H);
 // orb.hip
 int rtvm_orb_plan(rtvm_ctx* c);   // host-side geometry (before allocation)
 int rtvm_orb_setup(rtvm_ctx* c);  // uploads tables (after allocation)

@@ -73,7 +73,7 @@ __device__ bool validate_h(const double* H, double trans_thr, double scale_thr) 
 // "do not stitch" flag of every frame.
 __global__ void k_batch_glue(const FrameSlot* __restrict__ slots, int sb, int n, StreamState* __restrict__ st,
                              const double* __restrict__ wtab, double* __restrict__ H_out, int* __restrict__ skip,
-                             double trans_thr, double scale_thr, int ahead, BatchReport* __restrict__ rep) {
+                             double trans_thr, double scale_thr, int ahead, StreamState* __restrict__ snap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int n_done = 0, last_good = -1;
     bool abort = st->abort != 0;
@@ -101,6 +101,8 @@ __global__ void k_batch_glue(const FrameSlot* __restrict__ slots, int sb, int n,
         if (status) {
             st->status = st->b_status[j] = status;
             if (j < n - 1) abort = true;  // the later frames were matched against this one
+            st->last_good = last_good;
+            snap[j] = *st;
             continue;
         }
         double Hr[9];
@@ -145,12 +147,41 @@ __global__ void k_batch_glue(const FrameSlot* __restrict__ slots, int sb, int n,
         st->status = st->b_status[j] = status;
         skip[j] = 0;
         last_good = j;
+        st->last_good = last_good;
+        snap[j] = *st;  // the state to return to when a later frame of the batch cannot be stitched
     }
     st->abort = abort ? 1 : 0;
     st->n_done = n_done;
     st->last_good = last_good;
     st->tail_ok = (!abort && last_good == n - 1) ? 1 : 0;
-    rep->n_done = n_done;
+}
+
+// End of a batch.  The canvas masks of frames 1..n-1 were predicted (a blend of two
+// non-zero pixels stays non-zero); when the blend of frame `bad` broke that, the later
+// frames were left untouched: the state goes back to what it was after frame `bad` and
+// they are reported pending, like the rest of a batch after a skipped frame.  Then the
+// report the host reads.
+__global__ void k_batch_finish(StreamState* __restrict__ st, const StreamState* __restrict__ snap, int n,
+                               BatchReport* __restrict__ rep) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int bad = st->bad_frame;
+    bool later = false;
+    if (bad >= 0 && bad < n - 1)
+        for (int j = bad + 1; j < n; j++) later |= st->b_status[j] != RTVM_FRAME_PENDING;
+    if (later) {
+        *st = snap[bad];
+        for (int j = bad + 1; j < n; j++) {
+            st->b_status[j] = RTVM_FRAME_PENDING;
+            st->b_matches[j] = 0;
+            st->b_kp[j] = 0;
+        }
+        st->abort = 1;
+        st->n_done = bad + 1;
+        st->last_good = bad;
+        st->tail_ok = 0;
+    }
+    st->bad_frame = 0x7FFFFFFF;
+    rep->n_done = st->n_done;
     rep->abort = st->abort;
     rep->tail_ok = st->tail_ok;
     for (int j = 0; j < n; j++) {
@@ -219,6 +250,7 @@ __global__ void k_state_init(StreamState* st, int row_off, int col_off, int* ski
     st->n_done = 0;
     st->last_good = -1;
     st->tail_ok = 1;
+    st->bad_frame = 0x7FFFFFFF;
     for (int j = 0; j < RTVM_MAX_BATCH; j++) skip[j] = 0;
 }
 
@@ -281,10 +313,13 @@ int queue_back_half(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, int 
     c->seq += 1;
     const int slot = (int)(c->seq & 3);
     RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
-                50.0, 0.3, ahead, c->d_rep + slot);
+                50.0, 0.3, ahead, c->d_snap);
     if ((r = rtvm_launch_warp_prep(c, c->d_H, c->d_skip, n))) return r;
+    if ((r = rtvm_launch_new_sides(c, ptrs, n))) return r;
+    if ((r = rtvm_launch_old_sides(c, n))) return r;
     for (int j = 0; j < n; j++)
-        if ((r = rtvm_launch_warp_blend(c, ptrs[j], j))) return r;
+        if ((r = rtvm_launch_blend_commit(c, j))) return r;
+    RTVM_LAUNCH(c, k_batch_finish, dim3(1), dim3(64), 0, c->d_state, c->d_snap, n, c->d_rep + slot);
     RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, sb, c->d_state, -1,
                 c->feat_prev, c->orb.max_kp);
     HIP_TRY(c, hipGetLastError());
@@ -499,8 +534,7 @@ extern "C" int rtvm_frame_commit(rtvm_ctx* c, const double H[9]) {
     memcpy(hp, H, 9 * sizeof(double));
     HIP_TRY(c, hipMemcpyAsync(c->d_H, hp, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int r;
-    if ((r = rtvm_launch_warp_prep(c, c->d_H, nullptr, 1))) return r;
-    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, 0))) return r;
+    if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H))) return r;
     RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
                 c->feat_prev, c->orb.max_kp);
     HIP_TRY(c, hipGetLastError());

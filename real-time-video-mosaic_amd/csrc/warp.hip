@@ -25,20 +25,21 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // closed form), the region of the canvas the frame can touch, and the two
 // distance-transform jobs of the frame.
 __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restrict__ wp,
-                            DtJob* __restrict__ jobs, int fh, int fw, int ch, int cw, int force_full,
-                            const int* __restrict__ skip) {
+                            DtJob* __restrict__ jobs_new, DtJob* __restrict__ jobs_old, int fh, int fw, int ch,
+                            int cw, int force_full, const int* __restrict__ skip, StreamState* __restrict__ st) {
     if (threadIdx.x != 0) return;
+    if (st && blockIdx.x == 0) st->bad_frame = 0x7FFFFFFF;  // no blend of this batch has cleared a pixel yet
     Hp += 9 * blockIdx.x;
     wp += blockIdx.x;
-    if (jobs) jobs += 2 * blockIdx.x;
+    DtJob* jobs[2] = {jobs_new ? jobs_new + blockIdx.x : nullptr, jobs_old ? jobs_old + blockIdx.x : nullptr};
     if (skip) skip += blockIdx.x;
     if (skip && *skip) {  // frame rejected upstream: nothing to stitch
         wp->rx0 = wp->ry0 = wp->rx1 = wp->ry1 = 0;
         wp->wx0 = wp->wy0 = wp->wx1 = wp->wy1 = 0;
-        if (jobs)
-            for (int j = 0; j < 2; j++) {
-                jobs[j].x0 = jobs[j].y0 = jobs[j].x1 = jobs[j].y1 = 0;
-                jobs[j].ox0 = jobs[j].oy0 = jobs[j].ox1 = jobs[j].oy1 = 0;
+        for (int j = 0; j < 2; j++)
+            if (jobs[j]) {
+                jobs[j]->x0 = jobs[j]->y0 = jobs[j]->x1 = jobs[j]->y1 = 0;
+                jobs[j]->ox0 = jobs[j]->oy0 = jobs[j]->ox1 = jobs[j]->oy1 = 0;
             }
         return;
     }
@@ -104,21 +105,23 @@ __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restric
     wp->wy1 = empty ? 0 : min(ch, y1 + 15);
     const int bh0 = ch < 16 ? ch : 16;
     wp->bw0 = (1024 / bh0) < cw ? (1024 / bh0) : cw;
-    if (jobs) {
+    if (jobs[0]) {
         // new mask: transform on the ROI (its rim is zero, so nothing outside can be nearer)
-        jobs[0].x0 = jobs[0].ox0 = x0;
-        jobs[0].y0 = jobs[0].oy0 = y0;
-        jobs[0].x1 = jobs[0].ox1 = x1;
-        jobs[0].y1 = jobs[0].oy1 = y1;
+        jobs[0]->x0 = jobs[0]->ox0 = x0;
+        jobs[0]->y0 = jobs[0]->oy0 = y0;
+        jobs[0]->x1 = jobs[0]->ox1 = x1;
+        jobs[0]->y1 = jobs[0]->oy1 = y1;
+    }
+    if (jobs[1]) {
         // old mask: transform on the whole canvas, distances needed where the weights are
-        jobs[1].x0 = 0;
-        jobs[1].y0 = 0;
-        jobs[1].x1 = empty ? 0 : cw;
-        jobs[1].y1 = empty ? 0 : ch;
-        jobs[1].ox0 = wp->wx0;
-        jobs[1].oy0 = wp->wy0;
-        jobs[1].ox1 = wp->wx1;
-        jobs[1].oy1 = wp->wy1;
+        jobs[1]->x0 = 0;
+        jobs[1]->y0 = 0;
+        jobs[1]->x1 = empty ? 0 : cw;
+        jobs[1]->y1 = empty ? 0 : ch;
+        jobs[1]->ox0 = wp->wx0;
+        jobs[1]->oy0 = wp->wy0;
+        jobs[1]->ox1 = wp->wx1;
+        jobs[1]->oy1 = wp->wy1;
     }
 }
 
@@ -129,10 +132,17 @@ __device__ __forceinline__ int tap(const uint8_t* __restrict__ src, int fh, int 
 // cv2.warpPerspective(frame, H, (cw, ch), INTER_LINEAR), BORDER_CONSTANT 0, for the
 // pixels of the region of interest.  FIXED: 1/32-pixel fixed point (OpenCV <= 4.10),
 // else float32 (OpenCV >= 4.11).  Also writes mask_new = any channel > 0.
+// blockIdx.z = frame of the batch: source srcs.p[z], parameters wp[z], output planes
+// sides[z] (or `out_only`, without mask, for the stage entry point), bit rows of jobs_new[z].
 template <bool FIXED>
-__global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, const WarpParams* __restrict__ wp,
-                                              uint8_t* __restrict__ out, uint8_t* __restrict__ mask_new,
-                                              const DtJob* __restrict__ job_new, int fh, int fw, int ch, int cw) {
+__global__ __launch_bounds__(256) void k_warp(BatchPtrs srcs, const WarpParams* __restrict__ wps,
+                                              const SideDev* __restrict__ sides, uint8_t* __restrict__ out_only,
+                                              const DtJob* __restrict__ jobs_new, int fh, int fw, int ch, int cw) {
+    const uint8_t* __restrict__ src = srcs.p[blockIdx.z];
+    const WarpParams* __restrict__ wp = wps + blockIdx.z;
+    uint8_t* __restrict__ out = out_only ? out_only : sides[blockIdx.z].warped;
+    uint8_t* __restrict__ mask_new = out_only ? nullptr : sides[blockIdx.z].mask_new;
+    const DtJob* __restrict__ job_new = jobs_new ? jobs_new + blockIdx.z : nullptr;
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
     const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
     if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 4 <= ry0) return;
@@ -207,6 +217,31 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, c
     }
 }
 
+// The canvas mask each frame of a batch will meet, as zero bit rows, assuming that a pixel
+// of the canvas is non-zero after a frame iff it was non-zero before or the warped frame is
+// non-zero there (a blend of two non-zero pixels stays non-zero; the commit kernel reports
+// the rare blend that does not).  One thread per word: frame j sees `cur`, then the zero
+// bits of frame j's new mask are folded in.  Lets the distance transforms of the old mask
+// run for the whole batch at once.
+__global__ __launch_bounds__(256) void k_pred_bits(const uint32_t* __restrict__ bold, const WarpParams* __restrict__ wp,
+                                                   const DtJob* __restrict__ jobs_new,
+                                                   const DtJob* __restrict__ jobs_old, int n, int ch, int cw) {
+    const int w = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= ch || w * 32 >= cw) return;
+    const int wpitch = jobs_old[0].wpitch;
+    uint32_t cur = bold[(size_t)y * wpitch + w];
+    const int xa = w * 32;
+    for (int j = 0; j < n; j++) {
+        jobs_old[j].B[(size_t)y * wpitch + w] = cur;
+        const int rx0 = wp[j].rx0, rx1 = wp[j].rx1;
+        if (y < wp[j].ry0 || y >= wp[j].ry1 || xa + 32 <= rx0 || xa >= rx1) continue;  // new mask is zero here
+        uint32_t roi = 0xFFFFFFFFu;
+        if (xa < rx0) roi &= 0xFFFFFFFFu << (rx0 - xa);
+        if (xa + 32 > rx1) roi &= 0xFFFFFFFFu >> (xa + 32 - rx1);
+        cur &= jobs_new[j].B[(size_t)y * wpitch + w] | ~roi;
+    }
+}
+
 // weight_new = dn / (dn + do + 1e-6), weight_old = do / (...)  (main.py:892-894),
 // evaluated while staging, then the row pass of cv2.GaussianBlur(w, (31,31), 0)
 // (main.py:897-898) for both weights: 31 taps added left to right in float32,
@@ -214,8 +249,12 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, c
 // 256 consecutive pixels of one row staged through LDS, 4 outputs per lane from a
 // window of 34 staged values; a workgroup takes 4 rows.
 __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
-                                                   const float* __restrict__ dn, const float* __restrict__ dold,
-                                                   float* __restrict__ rbn, float* __restrict__ rbo, int cw) {
+                                                   const SideDev* __restrict__ side, float* __restrict__ rbn,
+                                                   float* __restrict__ rbo, int cw,
+                                                   const StreamState* __restrict__ st, int j) {
+    if (st->bad_frame < j) return;  // the canvas mask predicted for this frame is wrong: left pending
+    const float* __restrict__ dn = side->dist_new;
+    const float* __restrict__ dold = side->dist_old;
     const int rx0 = wp->rx0, rx1 = wp->rx1, wy0 = wp->wy0, wy1 = wp->wy1;
     const int bx = blockIdx.x * 256, by = blockIdx.y * 4;
     if (by >= wy1 || by + 4 <= wy0 || bx >= rx1 || bx + 256 <= rx0) return;
@@ -286,11 +325,14 @@ __global__ __launch_bounds__(256) void k_blur_cols_commit(const WarpParams* __re
                                                           const float* __restrict__ gk,
                                                           const float* __restrict__ rbn,
                                                           const float* __restrict__ rbo,
-                                                          const uint8_t* __restrict__ warped,
-                                                          const uint8_t* __restrict__ mask_new,
+                                                          const SideDev* __restrict__ side,
                                                           uint8_t* __restrict__ mask_old,
-                                                          uint8_t* __restrict__ canvas,
-                                                          const DtJob* __restrict__ job_old, int ch, int cw) {
+                                                          uint8_t* __restrict__ canvas, uint32_t* __restrict__ bold,
+                                                          int wpitch, int ch, int cw, StreamState* __restrict__ st,
+                                                          int j) {
+    if (st->bad_frame < j) return;  // the canvas mask predicted for this frame is wrong: left pending
+    const uint8_t* __restrict__ warped = side->warped;
+    const uint8_t* __restrict__ mask_new = side->mask_new;
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
     const int bx = blockIdx.x * 64, by = blockIdx.y * 16;
     if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 16 <= ry0) return;
@@ -354,11 +396,14 @@ __global__ __launch_bounds__(256) void k_blur_cols_commit(const WarpParams* __re
             }
             mo[i] = any ? 255 : 0;
             mask_old[p] = (uint8_t)mo[i];
+            // two non-zero pixels blended to zero: the masks predicted for the later frames of
+            // the batch do not hold
+            if (!any) atomicMin(&st->bad_frame, j);
         }
         if (y < ch) {  // wave-uniform
             const unsigned long long bal = __ballot(oncanvas && mo[i] == 0);
             if ((threadIdx.x & 63) == 0) {
-                uint32_t* B = job_old->B + (size_t)y * job_old->wpitch + (bx >> 5);
+                uint32_t* B = bold + (size_t)y * wpitch + (bx >> 5);
                 B[0] = (uint32_t)bal;
                 B[1] = (uint32_t)(bal >> 32);
             }
@@ -398,22 +443,17 @@ int rtvm_warp_setup(rtvm_ctx* c) {
     float k[31];
     for (int i = 0; i < n; i++) k[i] = (float)(t[i] * sum);
     HIP_TRY(c, hipMemcpy(c->d_gk, k, sizeof(k), hipMemcpyHostToDevice));
-    std::vector<DtJob> jobs(2 * RTVM_MAX_BATCH + 2);
-    for (int j = 0; j < 2; j++) {
-        jobs[j].mask = j == 0 ? c->d_mask_new : c->d_mask_old;
-        jobs[j].pitch = c->cw;
-        jobs[j].x0 = jobs[j].y0 = jobs[j].x1 = jobs[j].y1 = 0;
-        jobs[j].ox0 = jobs[j].oy0 = jobs[j].ox1 = jobs[j].oy1 = 0;
-        rtvm_dt_job_planes(c, &jobs[j], j, c->cw, c->ch, c->cw);
-    }
-    for (int j = 2; j < 2 * RTVM_MAX_BATCH; j++) jobs[j] = jobs[j & 1];
-    jobs[RTVM_JOB_STAGE] = jobs[0];
-    // the whole old mask: its zero bit rows are built once per canvas and then kept up to
-    // date by the commit kernel
-    jobs[RTVM_JOB_CANVAS] = jobs[1];
-    jobs[RTVM_JOB_CANVAS].x1 = jobs[RTVM_JOB_CANVAS].ox1 = c->cw;
-    jobs[RTVM_JOB_CANVAS].y1 = jobs[RTVM_JOB_CANVAS].oy1 = c->ch;
-    HIP_TRY(c, hipMemcpy(c->d_jobs, jobs.data(), jobs.size() * sizeof(DtJob), hipMemcpyHostToDevice));
+    // the whole old mask as a distance-transform job: only its zero bit rows are ever built
+    // (once per canvas; the commit kernel keeps them up to date)
+    DtJob jb;
+    memset(&jb, 0, sizeof(jb));
+    rtvm_dt_job_planes(c, &jb, 0, 1, c->cw, c->ch, c->cw);
+    jb.mask = c->d_mask_old;
+    jb.pitch = c->cw;
+    jb.x1 = jb.ox1 = c->cw;
+    jb.y1 = jb.oy1 = c->ch;
+    jb.B = c->d_bold;
+    HIP_TRY(c, hipMemcpy(c->d_jobs + RTVM_JOB_CANVAS, &jb, sizeof(DtJob), hipMemcpyHostToDevice));
     return RTVM_OK;
 }
 
@@ -432,45 +472,72 @@ int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int 
 
 // Full-canvas warp into d_out (stage parity of cv2.warpPerspective alone).
 int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out) {
-    RTVM_LAUNCH(c, k_warp_prep, dim3(1), dim3(64), 0, d_H, c->d_wp, (DtJob*)nullptr, c->fh, c->fw,
-                       c->ch, c->cw, 1, (const int*)nullptr);
-    const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
+    RTVM_LAUNCH(c, k_warp_prep, dim3(1), dim3(64), 0, d_H, c->d_wp, (DtJob*)nullptr, (DtJob*)nullptr, c->fh, c->fw,
+                c->ch, c->cw, 1, (const int*)nullptr, (StreamState*)nullptr);
+    BatchPtrs bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.p[0] = d_bgr;
+    const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4, 1);
     if (c->flags & RTVM_FLAG_WARP_FIXED)
-        RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
-                           (const DtJob*)nullptr, c->fh, c->fw, c->ch, c->cw);
+        RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, bp, c->d_wp, (const SideDev*)nullptr, d_out,
+                    (const DtJob*)nullptr, c->fh, c->fw, c->ch, c->cw);
     else
-        RTVM_LAUNCH(c, k_warp<false>, grid, dim3(256), 0, d_bgr, c->d_wp, d_out, (uint8_t*)nullptr,
-                           (const DtJob*)nullptr, c->fh, c->fw, c->ch, c->cw);
+        RTVM_LAUNCH(c, k_warp<false>, grid, dim3(256), 0, bp, c->d_wp, (const SideDev*)nullptr, d_out,
+                    (const DtJob*)nullptr, c->fh, c->fw, c->ch, c->cw);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
 
 int rtvm_launch_warp_prep(rtvm_ctx* c, const double* d_H, const int* d_skip, int n) {
-    RTVM_LAUNCH(c, k_warp_prep, dim3(n), dim3(64), 0, d_H, c->d_wp, c->d_jobs, c->fh, c->fw, c->ch, c->cw, 0, d_skip);
+    if (n < 1 || n > c->n_side) RTVM_FAIL(c, RTVM_E_STATE, "warp: %d frames, planes for %d", n, c->n_side);
+    RTVM_LAUNCH(c, k_warp_prep, dim3(n), dim3(64), 0, d_H, c->d_wp, c->d_jobs, c->d_jobs + RTVM_MAX_BATCH, c->fh, c->fw,
+                c->ch, c->cw, 0, d_skip, c->d_state);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
 
-// The whole of VideMosaic.warp() for frame j of the batch rtvm_launch_warp_prep prepared.
-int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, int j) {
+// Warps, masks, zero bits and new-mask distance transforms of the n frames of the batch
+// rtvm_launch_warp_prep prepared.  Reads nothing of the canvas.
+int rtvm_launch_new_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n) {
+    BatchPtrs bp;
+    memset(&bp, 0, sizeof(bp));
+    for (int j = 0; j < n; j++) bp.p[j] = d_bgr[j];
+    const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4, n);
+    if (c->flags & RTVM_FLAG_WARP_FIXED)
+        RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, bp, c->d_wp, c->d_side, (uint8_t*)nullptr, c->d_jobs, c->fh,
+                    c->fw, c->ch, c->cw);
+    else
+        RTVM_LAUNCH(c, k_warp<false>, grid, dim3(256), 0, bp, c->d_wp, c->d_side, (uint8_t*)nullptr, c->d_jobs, c->fh,
+                    c->fw, c->ch, c->cw);
+    return rtvm_launch_dt(c, c->d_jobs, n, c->cw, c->ch, 0);
+}
+
+// Predicted canvas masks of the n frames and their distance transforms.
+int rtvm_launch_old_sides(rtvm_ctx* c, int n) {
+    RTVM_LAUNCH(c, k_pred_bits, dim3(((c->cw + 31) / 32 + 63) / 64, (c->ch + 3) / 4), dim3(256), 0, c->d_bold, c->d_wp,
+                c->d_jobs, c->d_jobs + RTVM_MAX_BATCH, n, c->ch, c->cw);
+    return rtvm_launch_dt(c, c->d_jobs + RTVM_MAX_BATCH, n, c->cw, c->ch, 0);
+}
+
+// Weights, blur, blend and commit of frame j.
+int rtvm_launch_blend_commit(rtvm_ctx* c, int j) {
     const size_t n_px = (size_t)c->ch * c->cw;
     const WarpParams* wp = c->d_wp + j;
-    const DtJob* jobs = c->d_jobs + 2 * j;
-    const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
-    if (c->flags & RTVM_FLAG_WARP_FIXED)
-        RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, d_bgr, wp, c->d_warped, c->d_mask_new, jobs, c->fh, c->fw,
-                    c->ch, c->cw);
-    else
-        RTVM_LAUNCH(c, k_warp<false>, grid, dim3(256), 0, d_bgr, wp, c->d_warped, c->d_mask_new, jobs, c->fh, c->fw,
-                    c->ch, c->cw);
-    int r = rtvm_launch_dt(c, jobs, 2, c->cw, c->ch, 0);
-    if (r != RTVM_OK) return r;
     float* rbn = c->d_rb;
     float* rbo = c->d_rb + n_px;
-    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, (c->ch + 3) / 4), dim3(256), 0, wp, c->d_gk, c->d_dist,
-                c->d_dist + n_px, rbn, rbo, c->cw);
-    RTVM_LAUNCH(c, k_blur_cols_commit, dim3((c->cw + 63) / 64, (c->ch + 15) / 16), dim3(256), 0, wp, c->d_gk, rbn, rbo, c->d_warped, c->d_mask_new,
-                c->d_mask_old, c->d_canvas, jobs + 1, c->ch, c->cw);
+    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, (c->ch + 3) / 4), dim3(256), 0, wp, c->d_gk, c->d_side + j, rbn,
+                rbo, c->cw, c->d_state, j);
+    RTVM_LAUNCH(c, k_blur_cols_commit, dim3((c->cw + 63) / 64, (c->ch + 15) / 16), dim3(256), 0, wp, c->d_gk, rbn, rbo,
+                c->d_side + j, c->d_mask_old, c->d_canvas, c->d_bold, (c->cw + 31) / 32 + 2, c->ch, c->cw, c->d_state, j);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
+}
+
+// The whole of VideMosaic.warp() for one frame, H read from device memory.
+int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H) {
+    int r;
+    if ((r = rtvm_launch_warp_prep(c, d_H, nullptr, 1))) return r;
+    if ((r = rtvm_launch_new_sides(c, &d_bgr, 1))) return r;
+    if ((r = rtvm_launch_old_sides(c, 1))) return r;
+    return rtvm_launch_blend_commit(c, 0);
 }

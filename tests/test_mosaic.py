@@ -223,3 +223,37 @@ def test_batches_queued_back_to_back():
     assert np.array_equal(H, om2.H)
     assert np.array_equal(ctx.canvas_read(), om2.canvas)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_batch_with_pixels_that_blend_to_zero():
+    """Two pixels of value 1 blend to 0 (the blurred weights add up to slightly less than 1), which
+    clears the canvas mask there.  The batched path predicts the canvas masks of a batch ahead of
+    time on the assumption that this does not happen; when it does, the later frames of the batch
+    come back pending and are processed again: the result stays the frame-by-frame one."""
+    import torch
+    frames, _ = video(11, seed=9)
+    frames = [f.copy() for f in frames]
+    for f in frames:
+        f[90:150, 200:280] = 1
+    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=500)
+    om = OracleMosaic(frames[0], nfeatures=500, glue="explicit")
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+    ctx.reserve_batch(5)
+    ctx.stream_begin(dev[0].data_ptr(), om.w_offset, om.h_offset)
+    ctx.process_batch([d.data_ptr() for d in dev[1:6]])
+    done, st, _, _ = ctx.batch_status(5)
+    assert 1 <= done < 5 and st[:done].tolist() == [0] * done and st[done:].tolist() == [8] * (5 - done)
+    status = ctx.process_video([d.data_ptr() for d in dev[1 + done:]], batch=5)
+    ref = []
+    for f in frames[1:]:
+        om.process_frame(f)
+        ref.append(om.status)
+    assert [0] * done + status.tolist() == ref
+    st, nk, nm, H = ctx.frame_status()
+    assert np.array_equal(H, om.H)
+    canvas = ctx.canvas_read()
+    assert np.array_equal(canvas, om.canvas)
+    assert (canvas[om.canvas.any(axis=2)].size > 0)
+    ctx.close()
