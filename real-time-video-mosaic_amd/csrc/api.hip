@@ -150,6 +150,8 @@ static void carve_side(const rtvm_ctx* c, Carver& k, SideDev& sd, SidePlanes p[2
     }
     sd.dist_new = p[0].dist;
     sd.dist_old = p[1].dist;
+    sd.rbn = k.take<float>(n_px);
+    sd.rbo = k.take<float>(n_px);
 }
 
 void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int side, int kind, int pitch, int h, int w) {
@@ -243,7 +245,6 @@ int alloc_all(rtvm_ctx* c) {
         c->dt_cs_words = 2 * nch * lines;
     }
     ALLOC(c, d_bold, c->dt_b_words);
-    ALLOC(c, d_rb, n_px * 2);
     ALLOC(c, d_gk, 32);
     ALLOC(c, d_H, RTVM_MAX_BATCH * 9 + 16);
     ALLOC(c, d_wp, RTVM_MAX_BATCH);
@@ -289,7 +290,7 @@ int alloc_all(rtvm_ctx* c) {
 
 void free_all(rtvm_ctx* c) {
     void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas,
-                    c->d_mask_old, c->d_bold, c->d_side, c->d_snap, c->d_rb, c->d_gk, c->d_H,
+                    c->d_mask_old, c->d_bold, c->d_side, c->d_snap, c->d_gk, c->d_H,
                     c->d_wp, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
                     c->d_skip};
     free_feat(&c->feat_prev);

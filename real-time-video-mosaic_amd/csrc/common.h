@@ -108,8 +108,11 @@ struct DtJob {
 struct SideDev {
     uint8_t* warped;     // ch*cw*3: the frame in canvas coordinates (ROI only)
     uint8_t* mask_new;   // ch*cw: warped pixel has a non-zero channel
-    float* dist_new;     // distance transform of mask_new
-    float* dist_old;     // distance transform of the canvas mask as it is before this frame
+    float* dist_new;     // distance transform of mask_new; after the blur: blend weight of the frame
+    float* dist_old;     // distance transform of the canvas mask as it is before this frame; after
+                         // the blur: blend weight of the canvas
+    float* rbn;          // row-blurred weights
+    float* rbo;
 };
 
 // Per-frame warp parameters, written on the device by k_warp_prep.
@@ -222,7 +225,6 @@ struct rtvm_ctx {
     SideDev* d_side;
     void* side_arena[RTVM_MAX_BATCH];  // one device allocation per frame of a batch
     int n_side;            // sides 0..n_side-1 are allocated
-    float* d_rb;           // row-blurred weights [2][ch*cw]
     float* d_gk;           // 31 Gaussian taps
     double* d_H;           // RTVM_MAX_BATCH x 9 doubles: homographies handed to the warp
     WarpParams* d_wp;      // one per frame of a batch
@@ -275,10 +277,11 @@ int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, 
 // VideMosaic.warp() for the n frames of a batch (homographies d_H[9*j], optional "do not
 // stitch" flags d_skip[j]): warp parameters and distance-transform jobs; warps, masks and
 // new-mask distances of all frames; predicted canvas masks and their distances for all
-// frames; then, frame by frame, weights + blur + blend + commit.
+// frames; weights and their 31x31 blur for all frames; then, frame by frame, blend + commit.
 int rtvm_launch_warp_prep(rtvm_ctx* c, const double* d_H, const int* d_skip, int n);
 int rtvm_launch_new_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n);
 int rtvm_launch_old_sides(rtvm_ctx* c, int n);
+int rtvm_launch_weights(rtvm_ctx* c, int n);
 int rtvm_launch_blend_commit(rtvm_ctx* c, int j);
 // all of the above for one frame
 int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H);

@@ -247,17 +247,16 @@ __global__ __launch_bounds__(256) void k_pred_bits(const uint32_t* __restrict__ 
 // (main.py:897-898) for both weights: 31 taps added left to right in float32,
 // BORDER_REFLECT_101 at the canvas edge.  dn is zero outside the ROI.  One wave =
 // 256 consecutive pixels of one row staged through LDS, 4 outputs per lane from a
-// window of 34 staged values; a workgroup takes 4 rows.
-__global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
-                                                   const SideDev* __restrict__ side, float* __restrict__ rbn,
-                                                   float* __restrict__ rbo, int cw,
-                                                   const StreamState* __restrict__ st, int j) {
-    if (st->bad_frame < j) return;  // the canvas mask predicted for this frame is wrong: left pending
-    const float* __restrict__ dn = side->dist_new;
-    const float* __restrict__ dold = side->dist_old;
+// window of 34 staged values; a workgroup takes 4 rows; blockIdx.z = frame of the batch.
+__global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
+                                                   const SideDev* __restrict__ sides, int cw) {
+    const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const int rx0 = wp->rx0, rx1 = wp->rx1, wy0 = wp->wy0, wy1 = wp->wy1;
     const int bx = blockIdx.x * 256, by = blockIdx.y * 4;
     if (by >= wy1 || by + 4 <= wy0 || bx >= rx1 || bx + 256 <= rx0) return;
+    const SideDev side = sides[blockIdx.z];
+    const float* __restrict__ dn = side.dist_new;
+    const float* __restrict__ dold = side.dist_old;
     __shared__ __align__(16) float s_n[4][288], s_o[4][288];
     __shared__ float s_k[32];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -308,106 +307,107 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
             a += k[i] * vn[o + i];
             b += k[i] * vo[o + i];
         }
-        rbn[row + x + o] = a;
-        rbo[row + x + o] = b;
+        side.rbn[row + x + o] = a;
+        side.rbo[row + x + o] = b;
     }
 }
 
-// Column pass of the blur (centre tap, then symmetric pairs outwards), blend
-// and commit (main.py:905-927), per pixel of the ROI:
-//   new & old : canvas = trunc_u8(canvas * w_old + warped * w_new)
-//   new only  : canvas = warped
-// A lane takes 4 consecutive rows of one column: a window of 34 row-blurred weights
-// serves the 4 column sums.  Also keeps mask_old (canvas pixel has a non-zero channel)
-// and its zero bit rows (the distance transform's input for the next frame) up to date:
-// a wave is 64 pixels of a row and rewrites the two bit words they belong to.
-__global__ __launch_bounds__(256) void k_blur_cols_commit(const WarpParams* __restrict__ wp,
-                                                          const float* __restrict__ gk,
-                                                          const float* __restrict__ rbn,
-                                                          const float* __restrict__ rbo,
-                                                          const SideDev* __restrict__ side,
-                                                          uint8_t* __restrict__ mask_old,
-                                                          uint8_t* __restrict__ canvas, uint32_t* __restrict__ bold,
-                                                          int wpitch, int ch, int cw, StreamState* __restrict__ st,
-                                                          int j) {
-    if (st->bad_frame < j) return;  // the canvas mask predicted for this frame is wrong: left pending
-    const uint8_t* __restrict__ warped = side->warped;
-    const uint8_t* __restrict__ mask_new = side->mask_new;
+// Column pass of the blur (centre tap, then symmetric pairs outwards) for the pixels of the
+// ROI the warped frame covers: the final blend weights of the frame and of the canvas
+// (main.py:897-898), stored over the distance planes.  A lane takes 4 consecutive rows of
+// one column: a window of 34 row-blurred weights serves the 4 column sums.  blockIdx.z =
+// frame of the batch.
+__global__ __launch_bounds__(256) void k_blur_cols(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
+                                                   const SideDev* __restrict__ sides, int ch, int cw) {
+    const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
     const int bx = blockIdx.x * 64, by = blockIdx.y * 16;
     if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 16 <= ry0) return;
     const int x = bx + (threadIdx.x & 63), ya = by + 4 * (threadIdx.x >> 6);
-    if (ya >= ry1 || ya + 4 <= ry0) return;  // a wave is 64 pixels of 4 rows
+    if (x < rx0 || x >= rx1 || ya >= ry1 || ya + 4 <= ry0) return;
+    const SideDev side = sides[blockIdx.z];
+    bool need[4], any = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int y = ya + i;
+        need[i] = y >= ry0 && y < ry1 && side.mask_new[(size_t)y * cw + x];
+        any |= need[i];
+    }
+    if (!any) return;
+    float vn[34], vo[34];
+#pragma unroll
+    for (int j = 0; j < 34; j++) {
+        const size_t q = (size_t)reflect101(ya - 15 + j, ch) * cw + x;
+        vn[j] = side.rbn[q];
+        vo[j] = side.rbo[q];
+    }
+    float k[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) k[i] = gk[15 + i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (!need[i]) continue;
+        float a = k[0] * vn[15 + i], b = k[0] * vo[15 + i];
+#pragma unroll
+        for (int t = 1; t <= 15; t++) {
+            a += k[t] * (vn[15 + i + t] + vn[15 + i - t]);
+            b += k[t] * (vo[15 + i + t] + vo[15 + i - t]);
+        }
+        const size_t p = (size_t)(ya + i) * cw + x;
+        side.dist_new[p] = a;
+        side.dist_old[p] = b;
+    }
+}
+
+// Blend and commit of one frame (main.py:905-927), per pixel of the ROI the warped frame
+// covers:
+//   new & old : canvas = trunc_u8(canvas * w_old + warped * w_new)
+//   new only  : canvas = warped
+// Also keeps mask_old (canvas pixel has a non-zero channel) and its zero bit rows (the seed
+// of the next batch's predicted masks) up to date: a wave is 64 pixels of a row and
+// rewrites the two bit words they belong to.
+__global__ __launch_bounds__(256) void k_commit(const WarpParams* __restrict__ wp, const SideDev* __restrict__ sidep,
+                                                uint8_t* __restrict__ mask_old, uint8_t* __restrict__ canvas,
+                                                uint32_t* __restrict__ bold, int wpitch, int ch, int cw,
+                                                StreamState* __restrict__ st, int j) {
+    if (st->bad_frame < j) return;  // the canvas mask predicted for this frame is wrong: left pending
+    const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
+    if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 4 <= ry0) return;
+    const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
+    if (y < ry0 || y >= ry1) return;  // a wave is 64 pixels of one row
+    const SideDev side = *sidep;
     const bool oncanvas = x < cw;
-    const bool incol = oncanvas && x >= rx0 && x < rx1;
-    int mo[4], state[4];  // state: 0 = untouched, 1 = paste, 2 = blend
-    bool any_blend = false;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int y = ya + i;
-        const bool rowin = y >= ry0 && y < ry1;  // implies y < ch
-        const size_t p = (size_t)(rowin ? y : ry0) * cw + (oncanvas ? x : 0);
-        mo[i] = (oncanvas && y < ch) ? mask_old[(size_t)min(y, ch - 1) * cw + x] : 255;
-        state[i] = 0;
-        if (incol && rowin && mask_new[p]) state[i] = mo[i] ? 2 : 1;
-        any_blend |= state[i] == 2;
-    }
-    float a[4], b[4];
-    if (any_blend) {
-        float vn[34], vo[34];
-#pragma unroll
-        for (int j = 0; j < 34; j++) {
-            const size_t q = (size_t)reflect101(ya - 15 + j, ch) * cw + x;
-            vn[j] = rbn[q];
-            vo[j] = rbo[q];
-        }
-        float k[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) k[i] = gk[15 + i];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            a[i] = k[0] * vn[15 + i];
-            b[i] = k[0] * vo[15 + i];
-#pragma unroll
-            for (int t = 1; t <= 15; t++) {
-                a[i] += k[t] * (vn[15 + i + t] + vn[15 + i - t]);
-                b[i] += k[t] * (vo[15 + i + t] + vo[15 + i - t]);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int y = ya + i;
-        const size_t p = (size_t)y * cw + x;
-        if (state[i] == 1) {
-            canvas[3 * p] = warped[3 * p];
-            canvas[3 * p + 1] = warped[3 * p + 1];
-            canvas[3 * p + 2] = warped[3 * p + 2];
-            mo[i] = 255;
-            mask_old[p] = 255;
-        } else if (state[i] == 2) {
+    const size_t p = (size_t)y * cw + (oncanvas ? x : 0);
+    int mo = oncanvas ? mask_old[p] : 255;
+    if (oncanvas && x >= rx0 && x < rx1 && side.mask_new[p]) {
+        if (!mo) {
+            canvas[3 * p] = side.warped[3 * p];
+            canvas[3 * p + 1] = side.warped[3 * p + 1];
+            canvas[3 * p + 2] = side.warped[3 * p + 2];
+            mo = 255;
+        } else {
+            const float a = side.dist_new[p], b = side.dist_old[p];
             int any = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float v = (float)canvas[3 * p + c] * b[i] + (float)warped[3 * p + c] * a[i];
+                const float v = (float)canvas[3 * p + c] * b + (float)side.warped[3 * p + c] * a;
                 const int q = (int)v;  // astype(uint8) truncates
                 canvas[3 * p + c] = (uint8_t)q;
                 any |= q & 255;
             }
-            mo[i] = any ? 255 : 0;
-            mask_old[p] = (uint8_t)mo[i];
+            mo = any ? 255 : 0;
             // two non-zero pixels blended to zero: the masks predicted for the later frames of
             // the batch do not hold
             if (!any) atomicMin(&st->bad_frame, j);
         }
-        if (y < ch) {  // wave-uniform
-            const unsigned long long bal = __ballot(oncanvas && mo[i] == 0);
-            if ((threadIdx.x & 63) == 0) {
-                uint32_t* B = bold + (size_t)y * wpitch + (bx >> 5);
-                B[0] = (uint32_t)bal;
-                B[1] = (uint32_t)(bal >> 32);
-            }
-        }
+        mask_old[p] = (uint8_t)mo;
+    }
+    const unsigned long long bal = __ballot(oncanvas && mo == 0);
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t* B = bold + (size_t)y * wpitch + (bx >> 5);
+        B[0] = (uint32_t)bal;
+        B[1] = (uint32_t)(bal >> 32);
     }
 }
 
@@ -519,16 +519,20 @@ int rtvm_launch_old_sides(rtvm_ctx* c, int n) {
     return rtvm_launch_dt(c, c->d_jobs + RTVM_MAX_BATCH, n, c->cw, c->ch, 0);
 }
 
-// Weights, blur, blend and commit of frame j.
+// Blend weights of the n frames: dn / (dn + do + eps) and its 31x31 Gaussian blur.
+int rtvm_launch_weights(rtvm_ctx* c, int n) {
+    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, (c->ch + 3) / 4, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side,
+                c->cw);
+    RTVM_LAUNCH(c, k_blur_cols, dim3((c->cw + 63) / 64, (c->ch + 15) / 16, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side,
+                c->ch, c->cw);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}
+
+// Blend and commit of frame j.
 int rtvm_launch_blend_commit(rtvm_ctx* c, int j) {
-    const size_t n_px = (size_t)c->ch * c->cw;
-    const WarpParams* wp = c->d_wp + j;
-    float* rbn = c->d_rb;
-    float* rbo = c->d_rb + n_px;
-    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, (c->ch + 3) / 4), dim3(256), 0, wp, c->d_gk, c->d_side + j, rbn,
-                rbo, c->cw, c->d_state, j);
-    RTVM_LAUNCH(c, k_blur_cols_commit, dim3((c->cw + 63) / 64, (c->ch + 15) / 16), dim3(256), 0, wp, c->d_gk, rbn, rbo,
-                c->d_side + j, c->d_mask_old, c->d_canvas, c->d_bold, (c->cw + 31) / 32 + 2, c->ch, c->cw, c->d_state, j);
+    RTVM_LAUNCH(c, k_commit, dim3((c->cw + 63) / 64, (c->ch + 3) / 4), dim3(256), 0, c->d_wp + j, c->d_side + j,
+                c->d_mask_old, c->d_canvas, c->d_bold, (c->cw + 31) / 32 + 2, c->ch, c->cw, c->d_state, j);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
@@ -539,5 +543,6 @@ int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H)
     if ((r = rtvm_launch_warp_prep(c, d_H, nullptr, 1))) return r;
     if ((r = rtvm_launch_new_sides(c, &d_bgr, 1))) return r;
     if ((r = rtvm_launch_old_sides(c, 1))) return r;
+    if ((r = rtvm_launch_weights(c, 1))) return r;
     return rtvm_launch_blend_commit(c, 0);
 }
