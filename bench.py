@@ -113,11 +113,11 @@ def stream_seed(rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--config", default="720p_orb1000", choices=sorted(CONFIGS))
     ap.add_argument("--warp-mode", default="float", choices=["float", "fixed"])
-    ap.add_argument("--batch", type=int, default=16, help="frames per rtvm_process_batch call (1..32)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per rtvm_process_batch call (1..32)")
     ap.add_argument("--single-stream", action="store_true", help="queue every batch on one HIP stream")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel timing table to this JSON file")
@@ -172,7 +172,7 @@ def main():
     run(1, W)
     ctx.sync()
     # --- un-timed pass over a few frames with every kernel timed: finds the dominant kernel
-    probe = min(16, K)
+    probe = min(B, K)
     ctx.profile_start(None)
     run(1 + W, probe)
     table = ctx.profile_stop()

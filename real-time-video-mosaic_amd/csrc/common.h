@@ -267,6 +267,9 @@ int rtvm_launch_hamming(rtvm_ctx* c, int sb, int nb, int cap_q, int cap_t, int s
 // with_bits = 0: the zero bit rows of the jobs (DtJob::B) are already up to date
 int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h, int with_bits);
 int rtvm_launch_dt_bits(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h);
+// jobs d_jobs[0 .. n_first) and d_jobs[second .. second + n_second) in the same launches
+int rtvm_launch_dt2(rtvm_ctx* c, const DtJob* d_jobs, int n_first, int second, int n_second, int max_w, int max_h,
+                    int with_bits);
 // api.hip: work planes of side `side`, kind 0 (new mask) or 1 (old mask), for an h x w image
 void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int side, int kind, int pitch, int h, int w);
 int rtvm_side_alloc(rtvm_ctx* c, int side);
@@ -279,8 +282,7 @@ int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, 
 // new-mask distances of all frames; predicted canvas masks and their distances for all
 // frames; weights and their 31x31 blur for all frames; then, frame by frame, blend + commit.
 int rtvm_launch_warp_prep(rtvm_ctx* c, const double* d_H, const int* d_skip, int n);
-int rtvm_launch_new_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n);
-int rtvm_launch_old_sides(rtvm_ctx* c, int n);
+int rtvm_launch_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n);
 int rtvm_launch_weights(rtvm_ctx* c, int n);
 int rtvm_launch_blend_commit(rtvm_ctx* c, int j);
 // all of the above for one frame

@@ -46,6 +46,12 @@ __device__ __forceinline__ uint32_t e_of(uint32_t s) {
     return s == 0xFFFFu ? INF32 : s * DT_B;
 }
 
+// A launch serves jobs[0 .. n_first) and then jobs[second ...]: the new-mask and the
+// old-mask jobs of a batch live in two arrays.
+__device__ __forceinline__ int job_index(int i, int n_first, int second) {
+    return i < n_first ? i : second + (i - n_first);
+}
+
 // 4 mask bytes -> 4 bits (bit i set iff byte i is zero)
 __device__ __forceinline__ uint32_t zero_nibble(uint32_t v) {
     const uint32_t t = ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);  // 0x80 in every zero byte
@@ -54,8 +60,8 @@ __device__ __forceinline__ uint32_t zero_nibble(uint32_t v) {
 
 // One lane per 32 pixels of a row of the rectangle: bit i of word w of row y is set iff
 // pixel (32 w + i, y) lies inside the rectangle and is zero.
-__global__ __launch_bounds__(256) void k_dt_bits(const DtJob* __restrict__ jobs) {
-    const DtJob jb = jobs[blockIdx.z];
+__global__ __launch_bounds__(256) void k_dt_bits(const DtJob* __restrict__ jobs, int n_first, int second) {
+    const DtJob jb = jobs[job_index(blockIdx.z, n_first, second)];
     const int w0 = jb.x0 >> 5;
     const int w = w0 + blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = jb.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -96,8 +102,8 @@ __device__ __forceinline__ LineGeom line_geom(const DtJob& jb) {
 
 // blockIdx.z = 2 * job + orientation; one wave = 64 lines of one chunk, one workgroup =
 // the 16 chunks of a group.
-__global__ __launch_bounds__(1024) void k_dt_diag_a(const DtJob* __restrict__ jobs) {
-    const DtJob jb = jobs[blockIdx.z >> 1];
+__global__ __launch_bounds__(1024) void k_dt_diag_a(const DtJob* __restrict__ jobs, int n_first, int second) {
+    const DtJob jb = jobs[job_index(blockIdx.z >> 1, n_first, second)];
     const int orient = blockIdx.z & 1;
     const LineGeom g = line_geom(jb);
     if (g.W <= 0 || g.H <= 0 || (int)blockIdx.x * 64 >= g.nlines || (int)blockIdx.y * GR >= g.nch) return;
@@ -193,8 +199,8 @@ __device__ __forceinline__ void diag_steps(const DtJob& jb, const LineGeom& g, i
 // One workgroup per tile of 32 rows x TW columns (columns on a grid of TW from 0, so the
 // rows of a tile are 16-byte aligned when the pitch is a multiple of 8).  Tiles that touch
 // neither the rows nor the columns of the output window are never read and are skipped.
-__global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ jobs) {
-    const DtJob jb = jobs[blockIdx.z];
+__global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ jobs, int n_first, int second) {
+    const DtJob jb = jobs[job_index(blockIdx.z, n_first, second)];
     const LineGeom g = line_geom(jb);
     const int c = blockIdx.y;
     const int X = ((jb.x0 / TW) + (int)blockIdx.x) * TW;
@@ -432,8 +438,9 @@ __device__ void dt_col_summary(const DtJob& jb, int x, int c) {
 
 // blockIdx.y = job.  The first `nrow_blocks` workgroups scan one row of the output window
 // each; the others take 64 columns x 4 chunks of the column summaries.
-__global__ __launch_bounds__(256) void k_dt_scan(const DtJob* __restrict__ jobs, int nrow_blocks, int ncol_x) {
-    const DtJob jb = jobs[blockIdx.y];
+__global__ __launch_bounds__(256) void k_dt_scan(const DtJob* __restrict__ jobs, int n_first, int second, int nrow_blocks,
+                                                 int ncol_x) {
+    const DtJob jb = jobs[job_index(blockIdx.y, n_first, second)];
     const int W = jb.x1 - jb.x0, H = jb.y1 - jb.y0;
     if (W <= 0 || H <= 0) return;
     __shared__ uint32_t s_w[4];
@@ -452,8 +459,8 @@ __global__ __launch_bounds__(256) void k_dt_scan(const DtJob* __restrict__ jobs,
 
 // Final column scan of the chunks that intersect the output window, in registers;
 // d = min(column scan, row scan), clamped to DIST_MAX, as float / 65536.
-__global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs) {
-    const DtJob jb = jobs[blockIdx.z];
+__global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs, int n_first, int second) {
+    const DtJob jb = jobs[job_index(blockIdx.z, n_first, second)];
     const int H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
     const int x = jb.ox0 + blockIdx.x * 64 + threadIdx.x;
     const int c = (jb.oy0 - jb.y0) / CH + blockIdx.y;
@@ -521,22 +528,33 @@ __global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs) 
 // bound every job's rectangle (grid sizing).
 int rtvm_launch_dt_bits(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h) {
     if (max_w <= 0 || max_h <= 0) return RTVM_OK;
-    RTVM_LAUNCH(c, k_dt_bits, dim3((max_w / 32 + 2 + 63) / 64, (max_h + 3) / 4, njobs), dim3(256), 0, d_jobs);
+    RTVM_LAUNCH(c, k_dt_bits, dim3((max_w / 32 + 2 + 63) / 64, (max_h + 3) / 4, njobs), dim3(256), 0, d_jobs, njobs, 0);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}
+
+// Jobs d_jobs[0 .. n_first) and d_jobs[second .. second + n_second).
+int rtvm_launch_dt2(rtvm_ctx* c, const DtJob* d_jobs, int n_first, int second, int n_second, int max_w, int max_h,
+                    int with_bits) {
+    if (max_w <= 0 || max_h <= 0) return RTVM_OK;
+    if (max_w > 16384 || max_h > 16384) RTVM_FAIL(c, RTVM_E_ARG, "distance transform: image side above 16384");
+    const int njobs = n_first + n_second;
+    const int nlines = max_w + max_h - 1;
+    const int nch = (max_h + CH - 1) / CH;
+    const int ncol_x = (max_w + 63) / 64;
+    if (with_bits)
+        RTVM_LAUNCH(c, k_dt_bits, dim3((max_w / 32 + 2 + 63) / 64, (max_h + 3) / 4, njobs), dim3(256), 0, d_jobs, n_first,
+                    second);
+    RTVM_LAUNCH(c, k_dt_diag_a, dim3((nlines + 63) / 64, (nch + GR - 1) / GR, 2 * njobs), dim3(1024), 0, d_jobs, n_first,
+                second);
+    RTVM_LAUNCH(c, k_dt_diag_b, dim3(max_w / TW + 2, nch, njobs), dim3(320), 0, d_jobs, n_first, second);
+    RTVM_LAUNCH(c, k_dt_scan, dim3(max_h + ncol_x * ((nch + 3) / 4), njobs), dim3(256), 0, d_jobs, n_first, second, max_h,
+                ncol_x);
+    RTVM_LAUNCH(c, k_dt_cols, dim3(ncol_x, nch + 1, njobs), dim3(64), 0, d_jobs, n_first, second);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
 
 int rtvm_launch_dt(rtvm_ctx* c, const DtJob* d_jobs, int njobs, int max_w, int max_h, int with_bits) {
-    if (max_w <= 0 || max_h <= 0) return RTVM_OK;
-    if (max_w > 16384 || max_h > 16384) RTVM_FAIL(c, RTVM_E_ARG, "distance transform: image side above 16384");
-    const int nlines = max_w + max_h - 1;
-    const int nch = (max_h + CH - 1) / CH;
-    const int ncol_x = (max_w + 63) / 64;
-    if (with_bits) RTVM_LAUNCH(c, k_dt_bits, dim3((max_w / 32 + 2 + 63) / 64, (max_h + 3) / 4, njobs), dim3(256), 0, d_jobs);
-    RTVM_LAUNCH(c, k_dt_diag_a, dim3((nlines + 63) / 64, (nch + GR - 1) / GR, 2 * njobs), dim3(1024), 0, d_jobs);
-    RTVM_LAUNCH(c, k_dt_diag_b, dim3(max_w / TW + 2, nch, njobs), dim3(320), 0, d_jobs);
-    RTVM_LAUNCH(c, k_dt_scan, dim3(max_h + ncol_x * ((nch + 3) / 4), njobs), dim3(256), 0, d_jobs, max_h, ncol_x);
-    RTVM_LAUNCH(c, k_dt_cols, dim3(ncol_x, nch + 1, njobs), dim3(64), 0, d_jobs);
-    HIP_TRY(c, hipGetLastError());
-    return RTVM_OK;
+    return rtvm_launch_dt2(c, d_jobs, njobs, 0, 0, max_w, max_h, with_bits);
 }

@@ -315,8 +315,7 @@ int queue_back_half(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, int 
     RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
                 50.0, 0.3, ahead, c->d_snap);
     if ((r = rtvm_launch_warp_prep(c, c->d_H, c->d_skip, n))) return r;
-    if ((r = rtvm_launch_new_sides(c, ptrs, n))) return r;
-    if ((r = rtvm_launch_old_sides(c, n))) return r;
+    if ((r = rtvm_launch_sides(c, ptrs, n))) return r;
     if ((r = rtvm_launch_weights(c, n))) return r;
     for (int j = 0; j < n; j++)
         if ((r = rtvm_launch_blend_commit(c, j))) return r;

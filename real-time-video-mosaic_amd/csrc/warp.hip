@@ -496,9 +496,10 @@ int rtvm_launch_warp_prep(rtvm_ctx* c, const double* d_H, const int* d_skip, int
     return RTVM_OK;
 }
 
-// Warps, masks, zero bits and new-mask distance transforms of the n frames of the batch
-// rtvm_launch_warp_prep prepared.  Reads nothing of the canvas.
-int rtvm_launch_new_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n) {
+// For the n frames of the batch rtvm_launch_warp_prep prepared: warps, masks and zero
+// bits; the canvas masks the frames are predicted to meet; the distance transforms of all
+// 2n masks.
+int rtvm_launch_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n) {
     BatchPtrs bp;
     memset(&bp, 0, sizeof(bp));
     for (int j = 0; j < n; j++) bp.p[j] = d_bgr[j];
@@ -509,14 +510,9 @@ int rtvm_launch_new_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n) {
     else
         RTVM_LAUNCH(c, k_warp<false>, grid, dim3(256), 0, bp, c->d_wp, c->d_side, (uint8_t*)nullptr, c->d_jobs, c->fh,
                     c->fw, c->ch, c->cw);
-    return rtvm_launch_dt(c, c->d_jobs, n, c->cw, c->ch, 0);
-}
-
-// Predicted canvas masks of the n frames and their distance transforms.
-int rtvm_launch_old_sides(rtvm_ctx* c, int n) {
     RTVM_LAUNCH(c, k_pred_bits, dim3(((c->cw + 31) / 32 + 63) / 64, (c->ch + 3) / 4), dim3(256), 0, c->d_bold, c->d_wp,
                 c->d_jobs, c->d_jobs + RTVM_MAX_BATCH, n, c->ch, c->cw);
-    return rtvm_launch_dt(c, c->d_jobs + RTVM_MAX_BATCH, n, c->cw, c->ch, 0);
+    return rtvm_launch_dt2(c, c->d_jobs, n, RTVM_MAX_BATCH, n, c->cw, c->ch, 0);
 }
 
 // Blend weights of the n frames: dn / (dn + do + eps) and its 31x31 Gaussian blur.
@@ -541,8 +537,7 @@ int rtvm_launch_blend_commit(rtvm_ctx* c, int j) {
 int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H) {
     int r;
     if ((r = rtvm_launch_warp_prep(c, d_H, nullptr, 1))) return r;
-    if ((r = rtvm_launch_new_sides(c, &d_bgr, 1))) return r;
-    if ((r = rtvm_launch_old_sides(c, 1))) return r;
+    if ((r = rtvm_launch_sides(c, &d_bgr, 1))) return r;
     if ((r = rtvm_launch_weights(c, 1))) return r;
     return rtvm_launch_blend_commit(c, 0);
 }
