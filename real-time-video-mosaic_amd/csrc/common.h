@@ -220,6 +220,8 @@ struct rtvm_ctx {
     uint8_t* d_canvas;     // ch*cw*3
     uint8_t* d_mask_old;   // ch*cw: canvas pixel has a non-zero channel
     uint32_t* d_bold;      // zero bit rows of d_mask_old, kept up to date by the commit kernel
+    uint8_t* d_snap_canvas;  // canvas and mask as they were before the batch being committed
+    uint8_t* d_snap_mask;
     size_t dt_b_words, dt_z_words, dt_z16_words, dt_cs_words;  // per distance-transform job
     SideDev* h_side;       // per frame of a batch (host mirror of d_side)
     SideDev* d_side;
@@ -280,11 +282,12 @@ int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, 
 // VideMosaic.warp() for the n frames of a batch (homographies d_H[9*j], optional "do not
 // stitch" flags d_skip[j]): warp parameters and distance-transform jobs; warps, masks and
 // new-mask distances of all frames; predicted canvas masks and their distances for all
-// frames; weights and their 31x31 blur for all frames; then, frame by frame, blend + commit.
+// frames; weights and their 31x31 blur for all frames; blend + commit of all frames, pixel
+// by pixel in frame order.
 int rtvm_launch_warp_prep(rtvm_ctx* c, const double* d_H, const int* d_skip, int n);
 int rtvm_launch_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n);
 int rtvm_launch_weights(rtvm_ctx* c, int n);
-int rtvm_launch_blend_commit(rtvm_ctx* c, int j);
+int rtvm_launch_commit(rtvm_ctx* c, int n);
 // all of the above for one frame
 int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H);
 // orb.hip

@@ -317,8 +317,7 @@ int queue_back_half(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, int 
     if ((r = rtvm_launch_warp_prep(c, c->d_H, c->d_skip, n))) return r;
     if ((r = rtvm_launch_sides(c, ptrs, n))) return r;
     if ((r = rtvm_launch_weights(c, n))) return r;
-    for (int j = 0; j < n; j++)
-        if ((r = rtvm_launch_blend_commit(c, j))) return r;
+    if ((r = rtvm_launch_commit(c, n))) return r;
     RTVM_LAUNCH(c, k_batch_finish, dim3(1), dim3(64), 0, c->d_state, c->d_snap, n, c->d_rep + slot);
     RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, sb, c->d_state, -1,
                 c->feat_prev, c->orb.max_kp);

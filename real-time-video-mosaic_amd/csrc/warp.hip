@@ -359,48 +359,83 @@ __global__ __launch_bounds__(256) void k_blur_cols(const WarpParams* __restrict_
     }
 }
 
-// Blend and commit of one frame (main.py:905-927), per pixel of the ROI the warped frame
-// covers:
+// Blend and commit of all frames of a batch (main.py:905-927).  With the blend weights
+// of every frame already known, what a frame does to a canvas pixel depends on that pixel
+// alone, so one thread carries its pixel through the frames in order:
 //   new & old : canvas = trunc_u8(canvas * w_old + warped * w_new)
 //   new only  : canvas = warped
-// Also keeps mask_old (canvas pixel has a non-zero channel) and its zero bit rows (the seed
-// of the next batch's predicted masks) up to date: a wave is 64 pixels of a row and
-// rewrites the two bit words they belong to.
-__global__ __launch_bounds__(256) void k_commit(const WarpParams* __restrict__ wp, const SideDev* __restrict__ sidep,
-                                                uint8_t* __restrict__ mask_old, uint8_t* __restrict__ canvas,
+// and writes canvas, mask_old (pixel has a non-zero channel) and the mask's zero bit rows
+// (the seed of the next batch's predicted masks; a wave is 64 pixels of a row and rewrites
+// their two bit words) once.
+//
+// The weights of frames 1..n-1 rest on predicted canvas masks, and the prediction fails
+// when two non-zero pixels blend to zero: the first such frame goes into st->bad_frame.
+// REDO = false is the optimistic pass: it applies every frame and saves what the canvas
+// held before into the snapshot planes.  REDO = true runs after it, does nothing unless a
+// frame before the last went bad, and then rebuilds the touched pixels from the snapshot
+// with the frames up to the bad one only (the later ones come back pending).
+template <bool REDO>
+__global__ __launch_bounds__(256) void k_commit(const WarpParams* __restrict__ wps, const SideDev* __restrict__ sides,
+                                                int n, uint8_t* __restrict__ mask_old, uint8_t* __restrict__ canvas,
+                                                uint8_t* __restrict__ snap_mask, uint8_t* __restrict__ snap_canvas,
                                                 uint32_t* __restrict__ bold, int wpitch, int ch, int cw,
-                                                StreamState* __restrict__ st, int j) {
-    if (st->bad_frame < j) return;  // the canvas mask predicted for this frame is wrong: left pending
-    const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
+                                                StreamState* __restrict__ st) {
+    int last = n - 1;
+    if (REDO) {
+        last = st->bad_frame;
+        if (last >= n - 1) return;  // every frame was applied with the right weights
+    }
     const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
-    if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 4 <= ry0) return;
     const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
-    if (y < ry0 || y >= ry1) return;  // a wave is 64 pixels of one row
-    const SideDev side = *sidep;
-    const bool oncanvas = x < cw;
+    // does any frame of the batch touch this wave's 64 pixels?
+    bool touched = false;
+    for (int j = 0; j < n; j++) {
+        const WarpParams* __restrict__ wp = wps + j;
+        touched |= y >= wp->ry0 && y < wp->ry1 && bx < wp->rx1 && bx + 64 > wp->rx0;
+    }
+    if (!touched) return;
+    const bool oncanvas = x < cw;  // y < ch: inside some ROI
     const size_t p = (size_t)y * cw + (oncanvas ? x : 0);
-    int mo = oncanvas ? mask_old[p] : 255;
-    if (oncanvas && x >= rx0 && x < rx1 && side.mask_new[p]) {
+    int c0 = 0, c1 = 0, c2 = 0, mo = 255;
+    if (oncanvas) {
+        const uint8_t* __restrict__ src_c = REDO ? snap_canvas : canvas;
+        const uint8_t* __restrict__ src_m = REDO ? snap_mask : mask_old;
+        c0 = src_c[3 * p], c1 = src_c[3 * p + 1], c2 = src_c[3 * p + 2];
+        mo = src_m[p];
+        if (!REDO) {
+            snap_canvas[3 * p] = (uint8_t)c0;
+            snap_canvas[3 * p + 1] = (uint8_t)c1;
+            snap_canvas[3 * p + 2] = (uint8_t)c2;
+            snap_mask[p] = (uint8_t)mo;
+        }
+    }
+    bool changed = REDO;
+    for (int j = 0; j <= last; j++) {
+        const WarpParams* __restrict__ wp = wps + j;
+        if (y < wp->ry0 || y >= wp->ry1 || bx >= wp->rx1 || bx + 64 <= wp->rx0) continue;  // wave-uniform
+        if (!oncanvas || x < wp->rx0 || x >= wp->rx1) continue;
+        const SideDev& side = sides[j];
+        if (!side.mask_new[p]) continue;
+        const int w0 = side.warped[3 * p], w1 = side.warped[3 * p + 1], w2 = side.warped[3 * p + 2];
+        changed = true;
         if (!mo) {
-            canvas[3 * p] = side.warped[3 * p];
-            canvas[3 * p + 1] = side.warped[3 * p + 1];
-            canvas[3 * p + 2] = side.warped[3 * p + 2];
+            c0 = w0, c1 = w1, c2 = w2;
             mo = 255;
         } else {
             const float a = side.dist_new[p], b = side.dist_old[p];
-            int any = 0;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float v = (float)canvas[3 * p + c] * b + (float)side.warped[3 * p + c] * a;
-                const int q = (int)v;  // astype(uint8) truncates
-                canvas[3 * p + c] = (uint8_t)q;
-                any |= q & 255;
-            }
-            mo = any ? 255 : 0;
+            c0 = (int)((float)c0 * b + (float)w0 * a) & 255;  // astype(uint8) truncates
+            c1 = (int)((float)c1 * b + (float)w1 * a) & 255;
+            c2 = (int)((float)c2 * b + (float)w2 * a) & 255;
+            mo = (c0 | c1 | c2) ? 255 : 0;
             // two non-zero pixels blended to zero: the masks predicted for the later frames of
             // the batch do not hold
-            if (!any) atomicMin(&st->bad_frame, j);
+            if (!REDO && !mo) atomicMin(&st->bad_frame, j);
         }
+    }
+    if (oncanvas && changed) {
+        canvas[3 * p] = (uint8_t)c0;
+        canvas[3 * p + 1] = (uint8_t)c1;
+        canvas[3 * p + 2] = (uint8_t)c2;
         mask_old[p] = (uint8_t)mo;
     }
     const unsigned long long bal = __ballot(oncanvas && mo == 0);
@@ -525,10 +560,15 @@ int rtvm_launch_weights(rtvm_ctx* c, int n) {
     return RTVM_OK;
 }
 
-// Blend and commit of frame j.
-int rtvm_launch_blend_commit(rtvm_ctx* c, int j) {
-    RTVM_LAUNCH(c, k_commit, dim3((c->cw + 63) / 64, (c->ch + 3) / 4), dim3(256), 0, c->d_wp + j, c->d_side + j,
-                c->d_mask_old, c->d_canvas, c->d_bold, (c->cw + 31) / 32 + 2, c->ch, c->cw, c->d_state, j);
+// Blend and commit of the n frames of the batch, in order.
+int rtvm_launch_commit(rtvm_ctx* c, int n) {
+    const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
+    const int wpitch = (c->cw + 31) / 32 + 2;
+    RTVM_LAUNCH(c, k_commit<false>, grid, dim3(256), 0, c->d_wp, c->d_side, n, c->d_mask_old, c->d_canvas, c->d_snap_mask,
+                c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state);
+    if (n > 1)
+        RTVM_LAUNCH(c, k_commit<true>, grid, dim3(256), 0, c->d_wp, c->d_side, n, c->d_mask_old, c->d_canvas,
+                    c->d_snap_mask, c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
@@ -539,5 +579,5 @@ int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H)
     if ((r = rtvm_launch_warp_prep(c, d_H, nullptr, 1))) return r;
     if ((r = rtvm_launch_sides(c, &d_bgr, 1))) return r;
     if ((r = rtvm_launch_weights(c, 1))) return r;
-    return rtvm_launch_blend_commit(c, 0);
+    return rtvm_launch_commit(c, 1);
 }
