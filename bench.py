@@ -42,12 +42,14 @@ def pyramid_pixels(fh, fw):
     return tot
 
 
-def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px):
-    """Compulsory HBM bytes of one launch: every input read once, every output written once.
+def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
+    """Compulsory HBM bytes per frame of all launches of a kernel: every input read once, every
+    output written once.  Every kernel is launched once (k_resize: seven times) per batch and
+    serves all frames of the batch.
 
     The distance transform runs two jobs per frame: the new mask on the frame's region of the
-    canvas (roi_px pixels) and the old mask on the whole canvas, whose distances are only needed
-    on the blend window (the region plus the 15-pixel blur margin)."""
+    canvas (roi_px pixels) and the (predicted) old mask on the whole canvas, whose distances are
+    only needed on the blend window (the region plus the 15-pixel blur margin)."""
     P, C, S = fh * fw, ch * cw, pyramid_pixels(fh, fw)
     win_h, win_w = min(ch, fh + 38), min(cw, fw + 38)
     win = win_h * win_w
@@ -57,19 +59,19 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px):
     win2 = roi_px + win                 # output windows of both jobs
     table = {
         "k_gray": 3 * P + P,
-        "k_fast_score": S + S,                 # level pixels in, score map out
-        "k_fast_nms": S,                       # score map in (candidates are a few KB)
+        "k_fast": S,                           # level pixels in (candidates out are a few KB)
         "k_blur7": S + S,
-        "k_resize": (S - P) / 7 * (1.44 + 1),  # per launch: previous level in, level out (mean over 7 launches)
-        "k_warp<false>": 3 * P + 4 * roi_px,   # frame in, warped u8x3 + mask out
-        "k_warp<true>": 3 * P + 4 * roi_px,
-        "k_dt_diag_a": A + A / 4,              # mask in, one zero bit per pixel and orientation out
-        "k_dt_diag_b": A / 4 + 4 * A,          # bitmaps in, two u16 step planes out
-        "k_dt_rows": 4 * rows_px + 4 * rows_px,              # step planes in, u32 row scan out
-        "k_dt_cols_a": 4 * cols_px + cols_px / 4,            # step planes in, two u32 per 32-row chunk out
-        "k_dt_cols_b": 4 * win2 + 4 * win2 + 4 * win2 + cols_px / 4,  # steps + row scan + summaries in, f32 out
-        "k_blur_rows": 4 * roi_px + 4 * win + 8 * win,       # two distance planes in, two row-blurred weights out
-        "k_blur_cols_commit": 8 * win + 4 * roi_px + 6 * roi_px + roi_px,  # weights, warped+mask, canvas r/w, mask out
+        "k_resize": (S - P) * (1.44 + 1),      # levels 1..7: previous level in, level out
+        "k_warp<false>": 3 * P + 4 * roi_px + roi_px / 8,   # frame in, warped u8x3 + mask + zero bits out
+        "k_warp<true>": 3 * P + 4 * roi_px + roi_px / 8,
+        "k_dt_diag_a": A / 8 + A / 4,          # zero bit rows in, one bit per pixel and orientation out
+        "k_dt_diag_b": A / 4 + 2 * A,          # diagonal bitmaps in, u16 step plane out
+        "k_dt_scan": 2 * rows_px + 4 * win2 + 2 * cols_px + cols_px / 4,  # steps in; row scan + chunk summaries out
+        "k_dt_cols": 2 * win2 + 4 * win2 + cols_px / 4 + 4 * win2,      # steps, row scan, summaries in; f32 out
+        "k_blur_rows": 4 * roi_px + 4 * win + 8 * roi_px,   # two distance planes in, two row-blurred weights out
+        "k_blur_cols": 8 * win + roi_px + 8 * roi_px,       # row-blurred weights + mask in, final weights out
+        # per frame: mask + warped + two weights in; per batch: canvas + mask in/out and their snapshot
+        "k_commit<false>": 12 * roi_px + 12 * roi_px / batch,
         "k_hamming_argmin": 2 * nkp * 32 * 2,
         "k_rs_refine": nkp * 16,               # matched point pairs in (latency bound: fp64 solver chains)
     }
@@ -215,10 +217,12 @@ def main():
         roi_px = min(ch * cw, (fh + 8) * (fw + 8))
         launches, total_ms = dom[0], dom[1]
         avg_s = total_ms / launches * 1e-3
-        ab = algorithmic_bytes(dominant, fh, fw, ch, cw, nf, roi_px)
+        ab_frame = algorithmic_bytes(dominant, fh, fw, ch, cw, nf, roi_px, B)
+        ab = ab_frame * K / launches if ab_frame else None   # per launch: K frames went through `launches` launches
         roof = {"kernel": dominant, "bound": "hbm", "launches": launches, "avg_us": avg_s * 1e6,
                 "achieved": (ab / avg_s / 1e9) if ab else None, "peak": 8000.0, "unit": "GB/s",
-                "frac": (ab / avg_s / 1e9 / 8000.0) if ab else None, "algorithmic_bytes": ab, "traffic": None,
+                "frac": (ab / avg_s / 1e9 / 8000.0) if ab else None, "algorithmic_bytes": ab,
+                "algorithmic_bytes_per_frame": ab_frame, "frames_per_launch": K / launches, "traffic": None,
                 "stream": "main (canvas half): the stream that bounds the frame rate",
                 "longest_kernel_any_stream": {"kernel": longest, "us_per_frame": table[longest][1] * 1e3 / probe,
                                               "stream": ["main", "detect+match", "ransac"][table[longest][2]]}}
@@ -243,7 +247,7 @@ def main():
         }
         if args.kernel_table:
             rows = {k: {"launches": v[0], "total_ms": v[1], "avg_us": v[1] / v[0] * 1e3, "stream": v[2],
-                        "algorithmic_bytes": algorithmic_bytes(k, fh, fw, ch, cw, nf, roi_px)}
+                        "algorithmic_bytes_per_frame": algorithmic_bytes(k, fh, fw, ch, cw, nf, roi_px, B)}
                     for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])}
             os.makedirs(os.path.dirname(os.path.abspath(args.kernel_table)), exist_ok=True)
             with open(args.kernel_table, "w") as f:

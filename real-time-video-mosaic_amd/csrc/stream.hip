@@ -70,90 +70,139 @@ __device__ bool validate_h(const double* H, double trans_thr, double scale_thr) 
 // main.py:722-746 and 756 for the n frames of a batch, in order: skip rules,
 // validate, smooth (weighted mean of at most five relative homographies),
 // H = H_old @ H_smoothed, H_old = H.  Writes the absolute homography and the
-// "do not stitch" flag of every frame.
-__global__ void k_batch_glue(const FrameSlot* __restrict__ slots, int sb, int n, StreamState* __restrict__ st,
-                             const double* __restrict__ wtab, double* __restrict__ H_out, int* __restrict__ skip,
-                             double trans_thr, double scale_thr, int ahead, StreamState* __restrict__ snap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// "do not stitch" flag of every frame, and a copy of the state after every frame.
+// One wave: the state and the per-frame inputs are brought into LDS by all lanes, lane 0
+// runs the chain, all lanes copy the snapshots out.
+__global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__ slots, int sb, int n,
+                                                   StreamState* __restrict__ st_g, const double* __restrict__ wtab,
+                                                   double* __restrict__ H_out, int* __restrict__ skip,
+                                                   double trans_thr, double scale_thr, int ahead,
+                                                   StreamState* __restrict__ snap) {
+    __shared__ StreamState S;
+    __shared__ int s_m[RTVM_MAX_BATCH], s_found[RTVM_MAX_BATCH], s_kp[RTVM_MAX_BATCH], s_skip[RTVM_MAX_BATCH];
+    __shared__ double s_H[RTVM_MAX_BATCH][9], s_Habs[RTVM_MAX_BATCH][9];
+    __shared__ double s_w[30];
+    __shared__ int s_snap;
+    const int lane = threadIdx.x;
+    constexpr int WORDS = (int)(sizeof(StreamState) / sizeof(uint32_t));
+    static_assert(sizeof(StreamState) % sizeof(uint32_t) == 0, "StreamState is copied word by word");
+    {
+        const uint32_t* g = reinterpret_cast<const uint32_t*>(st_g);
+        uint32_t* l = reinterpret_cast<uint32_t*>(&S);
+        for (int i = lane; i < WORDS; i += 64) l[i] = g[i];
+    }
+    if (lane < n) {
+        const FrameSlot& F = slots[sb + lane];
+        s_m[lane] = *F.m_count;
+        s_found[lane] = *F.rs_found;
+        s_kp[lane] = *F.feat.count;
+        for (int i = 0; i < 9; i++) s_H[lane][i] = F.rs_H[i];
+        s_skip[lane] = 1;
+    }
+    if (lane < 30) s_w[lane] = wtab[lane];
+    __syncthreads();
+    StreamState* st = &S;
     int n_done = 0, last_good = -1;
-    bool abort = st->abort != 0;
-    // matched ahead of time against a frame that did not advance the state
-    if (ahead && !st->tail_ok) abort = true;
+    bool abort = false;  // lane 0's
+    if (lane == 0) {
+        abort = st->abort != 0;
+        // matched ahead of time against a frame that did not advance the state
+        if (ahead && !st->tail_ok) abort = true;
+    }
     for (int j = 0; j < n; j++) {
-        const FrameSlot& S = slots[sb + j];
-        skip[j] = 1;
-        if (abort) {
-            st->b_status[j] = RTVM_FRAME_PENDING;
-            st->b_matches[j] = 0;
-            st->b_kp[j] = 0;
-            continue;
-        }
-        n_done = j + 1;
-        st->frame_index += 1;
-        const int m = *S.m_count;
-        st->n_matches = st->b_matches[j] = m;
-        st->n_kp = st->b_kp[j] = *S.feat.count;
-        int status = 0;
-        if (m < 4)
-            status = RTVM_FRAME_FEW_MATCHES;
-        else if (!*S.rs_found)
-            status = RTVM_FRAME_NO_HOMOGRAPHY;
-        if (status) {
-            st->status = st->b_status[j] = status;
-            if (j < n - 1) abort = true;  // the later frames were matched against this one
-            st->last_good = last_good;
-            snap[j] = *st;
-            continue;
-        }
-        double Hr[9];
-        for (int i = 0; i < 9; i++) Hr[i] = S.rs_H[i];
-        if (!validate_h(Hr, trans_thr, scale_thr)) {
-            for (int i = 0; i < 9; i++) Hr[i] = (i % 4 == 0) ? 1. : 0.;
-            status |= RTVM_FRAME_INVALID_H;
-        } else {
-            for (int i = 0; i < 9; i++) st->last_valid_H[i] = Hr[i];
-        }
-        // smooth_homography
-        int k = st->hist_len;
-        if (k == 5) {
-            for (int a = 0; a < 4; a++)
-                for (int i = 0; i < 9; i++) st->hist[a][i] = st->hist[a + 1][i];
-            k = 4;
-        }
-        for (int i = 0; i < 9; i++) st->hist[k][i] = Hr[i];
-        k++;
-        st->hist_len = k;
-        double Hs[9];
-        if (k < 2) {
-            for (int i = 0; i < 9; i++) Hs[i] = Hr[i];
-        } else {
-            for (int i = 0; i < 9; i++) {
-                double s = 0.;
-                for (int a = 0; a < k; a++) s += wtab[k * 5 + a] * st->hist[a][i];
-                Hs[i] = s;
+        if (lane == 0) {
+            s_snap = 0;
+            if (abort) {
+                st->b_status[j] = RTVM_FRAME_PENDING;
+                st->b_matches[j] = 0;
+                st->b_kp[j] = 0;
+            } else {
+                s_snap = 1;
+                n_done = j + 1;
+                st->frame_index += 1;
+                const int m = s_m[j];
+                st->n_matches = st->b_matches[j] = m;
+                st->n_kp = st->b_kp[j] = s_kp[j];
+                int status = 0;
+                if (m < 4)
+                    status = RTVM_FRAME_FEW_MATCHES;
+                else if (!s_found[j])
+                    status = RTVM_FRAME_NO_HOMOGRAPHY;
+                if (status) {
+                    st->status = st->b_status[j] = status;
+                    if (j < n - 1) abort = true;  // the later frames were matched against this one
+                } else {
+                    double Hr[9];
+                    for (int i = 0; i < 9; i++) Hr[i] = s_H[j][i];
+                    if (!validate_h(Hr, trans_thr, scale_thr)) {
+                        for (int i = 0; i < 9; i++) Hr[i] = (i % 4 == 0) ? 1. : 0.;
+                        status |= RTVM_FRAME_INVALID_H;
+                    } else {
+                        for (int i = 0; i < 9; i++) st->last_valid_H[i] = Hr[i];
+                    }
+                    // smooth_homography
+                    int k = st->hist_len;
+                    if (k == 5) {
+                        for (int a = 0; a < 4; a++)
+                            for (int i = 0; i < 9; i++) st->hist[a][i] = st->hist[a + 1][i];
+                        k = 4;
+                    }
+                    for (int i = 0; i < 9; i++) st->hist[k][i] = Hr[i];
+                    k++;
+                    st->hist_len = k;
+                    double Hs[9];
+                    if (k < 2) {
+                        for (int i = 0; i < 9; i++) Hs[i] = Hr[i];
+                    } else {
+                        for (int i = 0; i < 9; i++) {
+                            double acc = 0.;
+                            for (int a = 0; a < k; a++) acc += s_w[k * 5 + a] * st->hist[a][i];
+                            Hs[i] = acc;
+                        }
+                    }
+                    // self.H = np.matmul(self.H_old, H_relative_smoothed)
+                    double H[9];
+                    for (int r = 0; r < 3; r++)
+                        for (int c2 = 0; c2 < 3; c2++)
+                            H[r * 3 + c2] = (st->H_old[r * 3] * Hs[c2] + st->H_old[r * 3 + 1] * Hs[3 + c2]) +
+                                            st->H_old[r * 3 + 2] * Hs[6 + c2];
+                    for (int i = 0; i < 9; i++) {
+                        st->H_abs[i] = H[i];
+                        st->H_old[i] = H[i];
+                        s_Habs[j][i] = H[i];
+                    }
+                    st->status = st->b_status[j] = status;
+                    s_skip[j] = 0;
+                    last_good = j;
+                }
+                st->last_good = last_good;
             }
         }
-        // self.H = np.matmul(self.H_old, H_relative_smoothed)
-        double H[9];
-        for (int r = 0; r < 3; r++)
-            for (int c2 = 0; c2 < 3; c2++)
-                H[r * 3 + c2] =
-                    (st->H_old[r * 3] * Hs[c2] + st->H_old[r * 3 + 1] * Hs[3 + c2]) + st->H_old[r * 3 + 2] * Hs[6 + c2];
-        for (int i = 0; i < 9; i++) {
-            st->H_abs[i] = H[i];
-            st->H_old[i] = H[i];
-            H_out[9 * j + i] = H[i];
+        __syncthreads();
+        if (s_snap) {  // the state to return to when a later frame of the batch cannot be stitched
+            const uint32_t* l = reinterpret_cast<const uint32_t*>(&S);
+            uint32_t* g = reinterpret_cast<uint32_t*>(snap + j);
+            for (int i = lane; i < WORDS; i += 64) g[i] = l[i];
         }
-        st->status = st->b_status[j] = status;
-        skip[j] = 0;
-        last_good = j;
-        st->last_good = last_good;
-        snap[j] = *st;  // the state to return to when a later frame of the batch cannot be stitched
+        __syncthreads();
     }
-    st->abort = abort ? 1 : 0;
-    st->n_done = n_done;
-    st->last_good = last_good;
-    st->tail_ok = (!abort && last_good == n - 1) ? 1 : 0;
+    if (lane == 0) {
+        st->abort = abort ? 1 : 0;
+        st->n_done = n_done;
+        st->last_good = last_good;
+        st->tail_ok = (!abort && last_good == n - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    {
+        const uint32_t* l = reinterpret_cast<const uint32_t*>(&S);
+        uint32_t* g = reinterpret_cast<uint32_t*>(st_g);
+        for (int i = lane; i < WORDS; i += 64) g[i] = l[i];
+    }
+    if (lane < n) {
+        skip[lane] = s_skip[lane];
+        if (!s_skip[lane])
+            for (int i = 0; i < 9; i++) H_out[9 * lane + i] = s_Habs[lane][i];
+    }
 }
 
 // End of a batch.  The canvas masks of frames 1..n-1 were predicted (a blend of two
