@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per rtvm_process_batch call (1..32)")
     ap.add_argument("--single-stream", action="store_true", help="queue every batch on one HIP stream")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--dropin-frames", type=int, default=32,
+                    help="frames of the PCIe-inclusive sample through the Python VideMosaic class (0 = skip)")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel timing table to this JSON file")
     args = ap.parse_args()
 
@@ -226,6 +228,22 @@ def main():
                 "stream": "main (canvas half): the stream that bounds the frame rate",
                 "longest_kernel_any_stream": {"kernel": longest, "us_per_frame": table[longest][1] * 1e3 / probe,
                                               "stream": ["main", "detect+match", "ransac"][table[longest][2]]}}
+        dropin = None
+        if args.dropin_frames > 0:
+            # the drop-in class as the reference's main loop drives it: one host frame per call
+            # (H2D copy + RANSAC read-back + host-side validate/smooth/chain + commit)
+            nd = min(args.dropin_frames, T - 1)
+            host_frames = frames[:nd + 1].cpu().numpy()
+            vm = rtvm.VideMosaic(host_frames[0], detector_type="orb", nfeatures=nf, canvas_size=(ch, cw),
+                                 device=local_rank, warp_mode=args.warp_mode, show_intermediate=False,
+                                 visualize=False)
+            td0 = time.perf_counter()
+            for t, f in enumerate(host_frames[1:], 1):
+                vm.process_frame(f, t)   # ends with a stream sync (rtvm_frame_commit)
+            dropin = {"value": nd / (time.perf_counter() - td0), "unit": "frames/s", "frames": nd,
+                      "note": "Python VideMosaic.process_frame with host frames: PCIe copies and one host round trip "
+                              "per frame included"}
+            vm.close()
         cpu = None
         if args.cpu_frames > 0:
             frames_np = frames[:args.cpu_frames + 1].cpu().numpy()
@@ -243,7 +261,7 @@ def main():
                        "streams": world, "parallelism": "one stream per GPU",
                        "last_frame": {"status": st, "keypoints": nk, "matches": nm},
                        "host_enqueue_ms_per_step": (t_enq - t0) / K * 1e3},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "dropin_pcie_inclusive": dropin,
         }
         if args.kernel_table:
             rows = {k: {"launches": v[0], "total_ms": v[1], "avg_us": v[1] / v[0] * 1e3, "stream": v[2],

@@ -159,6 +159,26 @@ def test_hip_dt_bit_exact(ctxs):
 
 
 @pytest.mark.gpu
+def test_hip_dt_wide_and_tall_images():
+    """Rows wider than one workgroup pass of the row scan (2048 pixels), pitches that are not
+    multiples of 8, more than 16 and more than 32 chunks of 32 rows, sparse zeros far apart."""
+    rng = np.random.default_rng(5)
+    c = rtvm.Context(48, 64, 700, 5200)
+    try:
+        for (h, w) in [(40, 5000), (33, 4099), (3, 2049), (700, 61), (600, 40), (520, 515)]:
+            for p in (0.0005, 0.02, 0.7):
+                m = (rng.random((h, w)) >= p).astype(np.uint8) * 255
+                assert np.array_equal(c.distance_transform(m), orc.distance_transform(m)), (h, w, p)
+            m = np.full((h, w), 255, np.uint8)
+            m[h - 1, 0] = 0   # a single zero in a corner: every chunk and pass carries it across
+            assert np.array_equal(c.distance_transform(m), orc.distance_transform(m)), (h, w, "corner")
+            m[:] = 255        # no zero at all
+            assert np.array_equal(c.distance_transform(m), orc.distance_transform(m)), (h, w, "none")
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fixed", [0, 1])
 @pytest.mark.parametrize("name", sorted(HS))
 def test_hip_warp_perspective_exact(ctxs, fixed, name):
