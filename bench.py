@@ -221,10 +221,23 @@ def main():
         avg_s = total_ms / launches * 1e-3
         ab_frame = algorithmic_bytes(dominant, fh, fw, ch, cw, nf, roi_px, B)
         ab = ab_frame * K / launches if ab_frame else None   # per launch: K frames went through `launches` launches
+        # HBM traffic of the same kernel from the PMC counters of a separate rocprofv3 run (committed
+        # summary; the counters cannot be read from inside this process)
+        traffic, traffic_note = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fjs:
+                pmc = json.load(fjs)
+            ent = pmc["kernels"].get(dominant)
+            if ent and args.config == "720p_orb1000":
+                traffic = ent["hbm_bytes"] * (K / launches) / pmc["frames_per_launch"]
+                traffic_note = ("2*FETCH_SIZE + WRITE_SIZE of profiles/r1_pmc_traffic.json, scaled from %d to %.0f frames "
+                                "per launch" % (pmc["frames_per_launch"], K / launches))
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"kernel": dominant, "bound": "hbm", "launches": launches, "avg_us": avg_s * 1e6,
                 "achieved": (ab / avg_s / 1e9) if ab else None, "peak": 8000.0, "unit": "GB/s",
                 "frac": (ab / avg_s / 1e9 / 8000.0) if ab else None, "algorithmic_bytes": ab,
-                "algorithmic_bytes_per_frame": ab_frame, "frames_per_launch": K / launches, "traffic": None,
+                "algorithmic_bytes_per_frame": ab_frame, "frames_per_launch": K / launches, "traffic": traffic, "traffic_note": traffic_note,
                 "stream": "main (canvas half): the stream that bounds the frame rate",
                 "longest_kernel_any_stream": {"kernel": longest, "us_per_frame": table[longest][1] * 1e3 / probe,
                                               "stream": ["main", "detect+match", "ransac"][table[longest][2]]}}
