@@ -15,9 +15,9 @@
 // pixels, whose zero flags form one 32-bit word; a column of a chunk is 32 values
 // held in the registers of one lane.
 //   k_dt_bits    mask bytes -> one zero bit per pixel (32 pixels per lane)
-//   k_dt_diag_a  per (line, chunk): the 32 zero bits of the line inside the chunk,
-//                gathered from the bit rows; per (line, 16 chunks): which chunks
-//                hold a zero
+//   k_dt_diag_a  per (line, chunk): the 32 zero bits of the line inside the chunk, by
+//                32x32 bit-matrix transposes of windows of the bit rows; per (line,
+//                16 chunks): which chunks hold a zero
 //   k_dt_diag_b  per tile of 32 rows x 256 columns: steps to the nearest zero along
 //                both diagonals (bit scans inside the chunk, the chunk summaries
 //                beyond it), minimum of the two through LDS, one u16 plane out
@@ -101,7 +101,11 @@ __device__ __forceinline__ LineGeom line_geom(const DtJob& jb) {
 }
 
 // blockIdx.z = 2 * job + orientation; one wave = 64 lines of one chunk, one workgroup =
-// the 16 chunks of a group.
+// the 16 chunks of a group.  Bit r of line j's word is bit (x_top(j) +- r) of bit row r, and
+// x_top grows by one per line: with w_r = the 32 bits of row r starting at x_top(first line)
+// +- r, the words of 32 consecutive lines are the transpose of the 32x32 bit matrix (w_r).
+// Each half-wave does one such block: lane r loads its window (two words), 32 ballots
+// transpose it.
 __global__ __launch_bounds__(1024) void k_dt_diag_a(const DtJob* __restrict__ jobs, int n_first, int second) {
     const DtJob jb = jobs[job_index(blockIdx.z >> 1, n_first, second)];
     const int orient = blockIdx.z & 1;
@@ -112,21 +116,33 @@ __global__ __launch_bounds__(1024) void k_dt_diag_a(const DtJob* __restrict__ jo
     const int line = blockIdx.x * 64 + lane;
     const int c = blockIdx.y * GR + wave;
     uint32_t z = 0;
-    if (line < g.nlines && c < g.nch) {
+    if (c < g.nch) {  // wave-uniform
+        const int grp = lane >> 5, r = lane & 31;
         const int dx = orient ? -1 : 1;
-        const int xs = orient ? jb.x0 + line : jb.x0 - (g.H - 1) + line;
+        const int line0 = blockIdx.x * 64 + 32 * grp;
+        const int xs0 = orient ? jb.x0 + line0 : jb.x0 - (g.H - 1) + line0;
         const int ya = jb.y0 + c * CH;
-        const int xt = xs + dx * (ya - jb.y0);  // column of the line at the chunk's first row
-        uint32_t w[CH];
-#pragma unroll
-        for (int r = 0; r < CH; r++) {
-            const int y = ya + r, x = xt + dx * r;
-            const bool in = y < jb.y1 && x >= jb.x0 && x < jb.x1;
-            w[r] = in ? jb.B[(size_t)y * jb.wpitch + (x >> 5)] >> (x & 31) : 0u;
+        const int xstart = xs0 + dx * (ya - jb.y0) + dx * r;  // first column of row r's window
+        const int y = ya + r;
+        uint32_t w = 0;
+        if (y < jb.y1) {
+            const int wi = xstart >> 5, sh = xstart & 31, nw = jb.wpitch - 2;
+            const uint32_t* __restrict__ rowp = jb.B + (size_t)y * jb.wpitch;
+            const uint32_t lo = (wi >= 0 && wi < nw) ? rowp[wi] : 0u;
+            const uint32_t hi = (wi + 1 >= 0 && wi + 1 < nw) ? rowp[wi + 1] : 0u;
+            w = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> sh);
+            // columns outside the rectangle are walls (their bits may be stale)
+            const int j0 = jb.x0 - xstart, j1 = jb.x1 - xstart;  // window bits [j0, j1) are inside
+            if (j0 > 0) w &= j0 >= 32 ? 0u : 0xFFFFFFFFu << j0;
+            if (j1 < 32) w &= j1 <= 0 ? 0u : 0xFFFFFFFFu >> (32 - j1);
         }
 #pragma unroll
-        for (int r = 0; r < CH; r++) z |= (w[r] & 1u) << r;
-        jb.Z[((size_t)orient * jb.znch + c) * jb.zpitch + line] = z;
+        for (int j = 0; j < 32; j++) {
+            const unsigned long long b = __ballot((w >> j) & 1u);
+            const uint32_t half = grp ? (uint32_t)(b >> 32) : (uint32_t)b;
+            if (r == j) z = half;
+        }
+        if (line < g.nlines) jb.Z[((size_t)orient * jb.znch + c) * jb.zpitch + line] = z;
     }
     s_any[wave][lane] = z != 0 ? 1u : 0u;
     __syncthreads();

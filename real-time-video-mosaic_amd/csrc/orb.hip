@@ -51,37 +51,69 @@ __global__ __launch_bounds__(256) void k_gray(const FrameSlot* __restrict__ slot
     out[(size_t)y * pitch + x] = (uint8_t)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15);
 }
 
-// INTER_LINEAR_EXACT: 8.8 coefficients (xw/yw = weight of the second tap, 0xFFFF = clamped single tap)
+// INTER_LINEAR_EXACT: 8.8 coefficients (xw/yw = weight of the second tap, 0xFFFF = clamped
+// single tap, evaluated as weight 0 on a repeated tap: (256-0)*a + 0*a = a << 8).  One
+// workgroup per tile of 64 x 16 outputs: the source pixels the tile reads (about 80 x 22
+// at the pyramid's factor 1.2) are staged in LDS with aligned word loads; a lane computes 4
+// rows of one column.  A tile whose footprint does not fit the staging area reads global
+// memory directly.
 __global__ __launch_bounds__(256) void k_resize(const FrameSlot* __restrict__ slots, int sb, unsigned soff, int sp,
-                                                unsigned doff, int dw, int dh, int dp,
+                                                int sh, unsigned doff, int dw, int dh, int dp,
                                                 const uint16_t* __restrict__ xofs, const uint16_t* __restrict__ xw,
                                                 const uint16_t* __restrict__ yofs, const uint16_t* __restrict__ yw) {
+    constexpr int TR = 28, TC = 112;  // staged rows / columns
     const FrameSlot& S = slots[sb + blockIdx.z];
     const uint8_t* __restrict__ src = S.pyr + soff;
     uint8_t* __restrict__ dst = S.pyr + doff;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= dw || y >= dh) return;
-    const int xo = xofs[x], yo = yofs[y];
-    const unsigned cx = xw[x], cy = yw[y];
-    const uint8_t* r0 = src + (size_t)yo * sp;
-    unsigned h0, h1 = 0;
-    if (cx == 0xFFFFu)
-        h0 = (unsigned)r0[xo] << 8;
-    else
-        h0 = (256u - cx) * r0[xo] + cx * r0[xo + 1];
-    unsigned v;
-    if (cy == 0xFFFFu) {
-        v = h0 << 8;
-    } else {
-        const uint8_t* r1 = r0 + sp;
-        if (cx == 0xFFFFu)
-            h1 = (unsigned)r1[xo] << 8;
-        else
-            h1 = (256u - cx) * r1[xo] + cx * r1[xo + 1];
-        v = (256u - cy) * h0 + cy * h1;
+    __shared__ __align__(16) uint8_t t[TR][TC];
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 16;
+    const int tid = threadIdx.x;
+    // footprint of the tile in the source level (block-uniform)
+    const int xlast = min(tx0 + 63, dw - 1), ylast = min(ty0 + 15, dh - 1);
+    const int sx0 = (int)xofs[tx0] & ~3, sx1 = (int)xofs[xlast] + 1;   // inclusive last column
+    const int sy0 = yofs[ty0], sy1 = (int)yofs[ylast] + 1;           // inclusive last row
+    const bool staged = sx1 - sx0 < TC && sy1 - sy0 < TR;
+    if (staged) {
+        const int nq = (sx1 - sx0) / 4 + 1, nr = sy1 - sy0 + 1;
+        for (int i = tid; i < nr * nq; i += 256) {
+            const int r = i / nq, q = i % nq;
+            const int y = min(sy0 + r, sh - 1), x = min(sx0 + 4 * q, sp - 4);
+            *reinterpret_cast<uint32_t*>(&t[r][4 * q]) = *reinterpret_cast<const uint32_t*>(src + (size_t)y * sp + x);
+        }
     }
-    v = (v + 32768u) >> 16;
-    dst[(size_t)y * dp + x] = (uint8_t)(v > 255u ? 255u : v);
+    __syncthreads();
+    const int x = tx0 + (tid & 63);
+    if (x >= dw) return;
+    const int xo = xofs[x];
+    const unsigned cxr = xw[x];
+    const unsigned cx = cxr == 0xFFFFu ? 0u : cxr;
+    const int xo1 = cxr == 0xFFFFu ? xo : xo + 1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int y = ty0 + 4 * (tid >> 6) + i;
+        if (y >= dh) break;
+        const int yo = yofs[y];
+        const unsigned cyr = yw[y];
+        const unsigned cy = cyr == 0xFFFFu ? 0u : cyr;
+        const int yo1 = cyr == 0xFFFFu ? yo : yo + 1;
+        unsigned a00, a01, a10, a11;
+        if (staged) {
+            a00 = t[yo - sy0][xo - sx0];
+            a01 = t[yo - sy0][xo1 - sx0];
+            a10 = t[yo1 - sy0][xo - sx0];
+            a11 = t[yo1 - sy0][xo1 - sx0];
+        } else {
+            a00 = src[(size_t)yo * sp + xo];
+            a01 = src[(size_t)yo * sp + xo1];
+            a10 = src[(size_t)yo1 * sp + xo];
+            a11 = src[(size_t)yo1 * sp + xo1];
+        }
+        const unsigned h0 = (256u - cx) * a00 + cx * a01;
+        const unsigned h1 = (256u - cx) * a10 + cx * a11;
+        unsigned v = (256u - cy) * h0 + cy * h1;
+        v = (v + 32768u) >> 16;
+        dst[(size_t)y * dp + x] = (uint8_t)(v > 255u ? 255u : v);
+    }
 }
 
 // ------------------------------------------------------------------ FAST
@@ -673,8 +705,8 @@ int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
     RTVM_LAUNCH(c, k_gray, dim3((P.w[0] + 255) / 256, P.h[0], nb), dim3(256), 0, sl, sb, P.off[0], P.w[0], P.h[0],
                 P.pitch[0]);
     for (int l = 1; l < RTVM_NLEVELS; l++)
-        RTVM_LAUNCH(c, k_resize, dim3((P.w[l] + 255) / 256, P.h[l], nb), dim3(256), 0, sl, sb, P.off[l - 1],
-                    P.pitch[l - 1], P.off[l], P.w[l], P.h[l], P.pitch[l], c->d_xofs + P.xtab_off[l],
+        RTVM_LAUNCH(c, k_resize, dim3((P.w[l] + 63) / 64, (P.h[l] + 15) / 16, nb), dim3(256), 0, sl, sb, P.off[l - 1],
+                    P.pitch[l - 1], P.h[l - 1], P.off[l], P.w[l], P.h[l], P.pitch[l], c->d_xofs + P.xtab_off[l],
                     c->d_xw + P.xtab_off[l], c->d_yofs + P.ytab_off[l], c->d_yw + P.ytab_off[l]);
     if (P.tile_off[RTVM_NLEVELS] > 0) {
         RTVM_LAUNCH(c, k_fast, dim3(P.tile_off[RTVM_NLEVELS], nb), dim3(256), 0, P, sl, sb);

@@ -125,8 +125,33 @@ __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restric
     }
 }
 
-__device__ __forceinline__ int tap(const uint8_t* __restrict__ src, int fh, int fw, int y, int x, int c) {
-    return ((unsigned)x < (unsigned)fw && (unsigned)y < (unsigned)fh) ? src[((size_t)y * fw + x) * 3 + c] : 0;
+// The 2x2 taps at (ix, iy) .. (ix+1, iy+1), 3 channels each; taps outside the frame read 0
+// (BORDER_CONSTANT).  The loads are unconditional (clamped addresses) so that all twelve
+// are in flight together; t[tap][channel], tap = 2*dy + dx.
+__device__ __forceinline__ void taps4(const uint8_t* __restrict__ src, int fh, int fw, int iy, int ix, int t[4][3]) {
+    const bool vx0 = (unsigned)ix < (unsigned)fw, vx1 = (unsigned)(ix + 1) < (unsigned)fw;
+    const bool vy0 = (unsigned)iy < (unsigned)fh, vy1 = (unsigned)(iy + 1) < (unsigned)fh;
+    const int x0 = min(max(ix, 0), fw - 1), x1 = min(max(ix + 1, 0), fw - 1);
+    const int y0 = min(max(iy, 0), fh - 1), y1 = min(max(iy + 1, 0), fh - 1);
+    const uint8_t* __restrict__ p00 = src + ((size_t)y0 * fw + x0) * 3;
+    const uint8_t* __restrict__ p01 = src + ((size_t)y0 * fw + x1) * 3;
+    const uint8_t* __restrict__ p10 = src + ((size_t)y1 * fw + x0) * 3;
+    const uint8_t* __restrict__ p11 = src + ((size_t)y1 * fw + x1) * 3;
+    int r[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        r[0][c] = p00[c];
+        r[1][c] = p01[c];
+        r[2][c] = p10[c];
+        r[3][c] = p11[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        t[0][c] = (vy0 && vx0) ? r[0][c] : 0;
+        t[1][c] = (vy0 && vx1) ? r[1][c] : 0;
+        t[2][c] = (vy1 && vx0) ? r[2][c] : 0;
+        t[3][c] = (vy1 && vx1) ? r[3][c] : 0;
+    }
 }
 
 // cv2.warpPerspective(frame, H, (cw, ch), INTER_LINEAR), BORDER_CONSTANT 0, for the
@@ -169,10 +194,11 @@ __global__ __launch_bounds__(256) void k_warp(BatchPtrs srcs, const WarpParams* 
         const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32;
         const int w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
         if (inroi && sx >= -1 && sx < fw && sy >= -1 && sy < fh) {
+            int t[4][3];
+            taps4(src, fh, fw, sy, sx, t);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const int s = w00 * tap(src, fh, fw, sy, sx, c) + w01 * tap(src, fh, fw, sy, sx + 1, c) +
-                              w10 * tap(src, fh, fw, sy + 1, sx, c) + w11 * tap(src, fh, fw, sy + 1, sx + 1, c);
+                const int s = w00 * t[0][c] + w01 * t[1][c] + w10 * t[2][c] + w11 * t[3][c];
                 v[c] = (s + 16384) >> 15;
             }
         }
@@ -186,10 +212,12 @@ __global__ __launch_bounds__(256) void k_warp(BatchPtrs srcs, const WarpParams* 
             const float flx = floorf(sx), fly = floorf(sy);
             const int ix = (int)flx, iy = (int)fly;
             const float a = sx - flx, b = sy - fly;
+            int t[4][3];
+            taps4(src, fh, fw, iy, ix, t);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float p00 = (float)tap(src, fh, fw, iy, ix, c), p01 = (float)tap(src, fh, fw, iy, ix + 1, c);
-                const float p10 = (float)tap(src, fh, fw, iy + 1, ix, c), p11 = (float)tap(src, fh, fw, iy + 1, ix + 1, c);
+                const float p00 = (float)t[0][c], p01 = (float)t[1][c];
+                const float p10 = (float)t[2][c], p11 = (float)t[3][c];
                 const float v0 = p00 + (p01 - p00) * a;
                 const float v1 = p10 + (p11 - p10) * a;
                 const float r = v0 + (v1 - v0) * b;
