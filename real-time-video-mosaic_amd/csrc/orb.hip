@@ -126,39 +126,57 @@ __device__ __forceinline__ int tile_level(const OrbDev& P, int tile, int* local)
     return l;
 }
 
-// Corner score of cv::FAST (type 9_16, threshold 20) of the pixel at LDS position
-// (row, col): max over the 16 arcs of 9 contiguous ring pixels of min(v - p) (bright
-// centre) or min(p - v) (dark centre), minus 1; 0 when no arc clears the threshold.
+// cv::FAST (type 9_16, threshold 20) on a pixel tile in LDS, in two steps so that the
+// expensive one only runs on the few pixels that can be corners.
+// ring_diffs: v - p for the 16 ring pixels of the pixel at LDS position (row, col).
 template <int LP>
-__device__ __forceinline__ int fast_score_at(const uint8_t (*s)[LP], int row, int col) {
+__device__ __forceinline__ void ring_diffs(const uint8_t (*s)[LP], int row, int col, int* d) {
     const int v = s[row][col];
-    int d[16];
     d[0] = v - s[row + 3][col];
-    d[8] = v - s[row - 3][col];
-    // an arc of 9 contains one pixel of every opposite pair
-    if (!(max(d[0], d[8]) > FAST_T || min(d[0], d[8]) < -FAST_T)) return 0;
-    d[4] = v - s[row][col + 3];
-    d[12] = v - s[row][col - 3];
-    if (!(max(d[4], d[12]) > FAST_T || min(d[4], d[12]) < -FAST_T)) return 0;
     d[1] = v - s[row + 3][col + 1];
     d[2] = v - s[row + 2][col + 2];
     d[3] = v - s[row + 1][col + 3];
+    d[4] = v - s[row][col + 3];
     d[5] = v - s[row - 1][col + 3];
     d[6] = v - s[row - 2][col + 2];
     d[7] = v - s[row - 3][col + 1];
+    d[8] = v - s[row - 3][col];
     d[9] = v - s[row - 3][col - 1];
     d[10] = v - s[row - 2][col - 2];
     d[11] = v - s[row - 1][col - 3];
+    d[12] = v - s[row][col - 3];
     d[13] = v - s[row + 1][col - 3];
     d[14] = v - s[row + 2][col - 2];
     d[15] = v - s[row + 3][col - 1];
+}
+
+// Necessary condition for a corner: an arc of 9 contains one pixel of every opposite pair,
+// so every pair must have a member brighter (or every pair a member darker) than the
+// threshold allows.
+template <int LP>
+__device__ __forceinline__ bool fast_candidate(const uint8_t (*s)[LP], int row, int col) {
+    const int v = s[row][col];
+    const int d0 = v - s[row + 3][col], d8 = v - s[row - 3][col];
+    if (!(max(d0, d8) > FAST_T || min(d0, d8) < -FAST_T)) return false;
+    const int d4 = v - s[row][col + 3], d12 = v - s[row][col - 3];
+    if (!(max(d4, d12) > FAST_T || min(d4, d12) < -FAST_T)) return false;
+    int d[16];
+    ring_diffs<LP>(s, row, col, d);
     bool bright = true, dark = true;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         bright &= max(d[k], d[k + 8]) > FAST_T;
         dark &= min(d[k], d[k + 8]) < -FAST_T;
     }
-    if (!(bright || dark)) return 0;
+    return bright || dark;
+}
+
+// Corner score: max over the 16 arcs of 9 contiguous ring pixels of min(v - p) (bright
+// centre) or min(p - v) (dark centre), minus 1; 0 when no arc clears the threshold.
+template <int LP>
+__device__ __forceinline__ int fast_score_at(const uint8_t (*s)[LP], int row, int col) {
+    int d[16];
+    ring_diffs<LP>(s, row, col, d);
     int best = 0;
     // min over arcs of 9 by doubling: m2, m4, m8, then one more element
     int m2[16], m4[16], M2[16], M4[16];
@@ -203,19 +221,41 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P, const FrameSlot* __restr
     __shared__ uint8_t sc[34][68];
     __shared__ int s_hist[256];
     __shared__ uint32_t s_list[512];
-    __shared__ int s_cnt, s_base;
+    __shared__ uint16_t s_surv[34 * 66];
+    __shared__ int s_cnt, s_base, s_nsurv;
     const int tid = threadIdx.x;
     s_hist[tid] = 0;
-    if (tid == 0) s_cnt = 0;
+    if (tid == 0) s_cnt = 0, s_nsurv = 0;
     for (int i = tid; i < 40 * 20; i += 256) {
         const int r = i / 20, q = i % 20;
         const int y = min(ty0 - 4 + r, H - 1), x = min(tx0 - 7 + 4 * q, pitch - 4);
         *reinterpret_cast<uint32_t*>(&s[r][4 * q]) = *reinterpret_cast<const uint32_t*>(img + (size_t)y * pitch + x);
     }
     __syncthreads();
-    // score-tile position (r, c) is pixel (tx0 - 1 + c, ty0 - 1 + r) = LDS (r + 3, c + 6)
-    for (int i = tid; i < 34 * 66; i += 256) {
-        const int r = i / 66, c = i % 66;
+    // score-tile position (r, c) is pixel (tx0 - 1 + c, ty0 - 1 + r) = LDS (r + 3, c + 6).
+    // First the cheap necessary test on every position, survivors into a list ...
+    for (int i0 = 0; i0 < 34 * 66; i0 += 256) {
+        const int i = i0 + tid;
+        bool cand = false;
+        int r = 0, c = 0;
+        if (i < 34 * 66) {
+            r = i / 66, c = i % 66;
+            sc[r][c] = 0;
+            cand = fast_candidate<80>(s, r + 3, c + 6);
+        }
+        const unsigned long long m = __ballot(cand);
+        if (m) {
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&s_nsurv, __popcll(m));
+            base = __shfl(base, 0);
+            if (cand) s_surv[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)(r * 68 + c);
+        }
+    }
+    __syncthreads();
+    // ... then the arc scores of the survivors, one per lane
+    const int nsurv = s_nsurv;
+    for (int i = tid; i < nsurv; i += 256) {
+        const int pos = s_surv[i], r = pos / 68, c = pos % 68;
         sc[r][c] = (uint8_t)fast_score_at<80>(s, r + 3, c + 6);
     }
     __syncthreads();

@@ -318,25 +318,25 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
     float k[31];
 #pragma unroll
     for (int i = 0; i < 31; i++) k[i] = s_k[i];
-    float vn[36], vo[36];
+    // one plane after the other: half the live registers, twice the resident waves
 #pragma unroll
-    for (int q = 0; q < 9; q++) {
-        const float4 a = *reinterpret_cast<const float4*>(&s_n[wv][4 * lane + 4 * q]);
-        const float4 b = *reinterpret_cast<const float4*>(&s_o[wv][4 * lane + 4 * q]);
-        vn[4 * q] = a.x, vn[4 * q + 1] = a.y, vn[4 * q + 2] = a.z, vn[4 * q + 3] = a.w;
-        vo[4 * q] = b.x, vo[4 * q + 1] = b.y, vo[4 * q + 2] = b.z, vo[4 * q + 3] = b.w;
-    }
+    for (int plane = 0; plane < 2; plane++) {
+        const float* __restrict__ sp = plane ? s_o[wv] : s_n[wv];
+        float* __restrict__ outp = plane ? side.rbo : side.rbn;
+        float v[36];
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
-        if (x + o < rx0 || x + o >= rx1) continue;
-        float a = k[0] * vn[o], b = k[0] * vo[o];
-#pragma unroll
-        for (int i = 1; i < 31; i++) {
-            a += k[i] * vn[o + i];
-            b += k[i] * vo[o + i];
+        for (int q = 0; q < 9; q++) {
+            const float4 a = *reinterpret_cast<const float4*>(&sp[4 * lane + 4 * q]);
+            v[4 * q] = a.x, v[4 * q + 1] = a.y, v[4 * q + 2] = a.z, v[4 * q + 3] = a.w;
         }
-        side.rbn[row + x + o] = a;
-        side.rbo[row + x + o] = b;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            if (x + o < rx0 || x + o >= rx1) continue;
+            float a = k[0] * v[o];
+#pragma unroll
+            for (int i = 1; i < 31; i++) a += k[i] * v[o + i];
+            outp[row + x + o] = a;
+        }
     }
 }
 
@@ -362,28 +362,25 @@ __global__ __launch_bounds__(256) void k_blur_cols(const WarpParams* __restrict_
         any |= need[i];
     }
     if (!any) return;
-    float vn[34], vo[34];
-#pragma unroll
-    for (int j = 0; j < 34; j++) {
-        const size_t q = (size_t)reflect101(ya - 15 + j, ch) * cw + x;
-        vn[j] = side.rbn[q];
-        vo[j] = side.rbo[q];
-    }
     float k[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) k[i] = gk[15 + i];
+    // one plane after the other: half the live registers, twice the resident waves
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (!need[i]) continue;
-        float a = k[0] * vn[15 + i], b = k[0] * vo[15 + i];
+    for (int plane = 0; plane < 2; plane++) {
+        const float* __restrict__ rb = plane ? side.rbo : side.rbn;
+        float* __restrict__ outp = plane ? side.dist_old : side.dist_new;
+        float v[34];
 #pragma unroll
-        for (int t = 1; t <= 15; t++) {
-            a += k[t] * (vn[15 + i + t] + vn[15 + i - t]);
-            b += k[t] * (vo[15 + i + t] + vo[15 + i - t]);
+        for (int j = 0; j < 34; j++) v[j] = rb[(size_t)reflect101(ya - 15 + j, ch) * cw + x];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (!need[i]) continue;
+            float a = k[0] * v[15 + i];
+#pragma unroll
+            for (int t = 1; t <= 15; t++) a += k[t] * (v[15 + i + t] + v[15 + i - t]);
+            outp[(size_t)(ya + i) * cw + x] = a;
         }
-        const size_t p = (size_t)(ya + i) * cw + x;
-        side.dist_new[p] = a;
-        side.dist_old[p] = b;
     }
 }
 
