@@ -62,6 +62,15 @@ enum {
     RTVM_FRAME_PENDING = 8      /* not processed: an earlier frame of the same batch was skipped */
 };
 
+/* why frames of a batch were left RTVM_FRAME_PENDING (rtvm_batch_status_of) */
+enum {
+    RTVM_PENDING_NONE = 0,
+    RTVM_PENDING_SKIPPED_FRAME = 1, /* the frame before them was skipped: they were matched against it */
+    RTVM_PENDING_MASK = 2,          /* a blend cleared a canvas pixel: the canvas masks predicted for them are wrong;
+                                       their detection, matching and RANSAC results remain valid */
+    RTVM_PENDING_VOID = 3           /* the batch was queued behind one that left frames pending */
+};
+
 typedef struct rtvm_ctx rtvm_ctx;
 
 /* ---- life cycle ------------------------------------------------------- */
@@ -146,7 +155,7 @@ int rtvm_stream_begin(rtvm_ctx* ctx, const uint8_t* bgr_dev, int row_off, int co
  * match, RANSAC, validate, smooth, chain, warp+blend, state advance, all queued on
  * the context's stream without a host round trip.  Asynchronous. */
 int rtvm_process_frame(rtvm_ctx* ctx, const uint8_t* bgr_dev);
-/* Room for batches of up to n frames (1..32) in rtvm_process_batch: three sets of n
+/* Room for batches of up to n frames (1..32) in rtvm_process_batch: four sets of n
  * frame slots, so that three consecutive batches can be in flight.  Allocates. */
 int rtvm_reserve_batch(rtvm_ctx* ctx, int n);
 /* process_frame for n consecutive device-resident frames (bgr_dev: n device pointers
@@ -157,7 +166,7 @@ int rtvm_reserve_batch(rtvm_ctx* ctx, int n);
  * the caller resubmits the rest.  Asynchronous.
  * Consecutive calls overlap on the device: detection + matching and RANSAC of later
  * batches run on HIP streams of their own while an earlier batch is still being warped
- * and blended (up to three batches in flight).  The first frame of such a batch is matched against the last frame of the
+ * and blended (up to four batches in flight).  The first frame of such a batch is matched against the last frame of the
  * batch before it; when that frame turns out to be skipped, the whole later batch is
  * left RTVM_FRAME_PENDING (0 frames consumed).  Reading a batch's status ends the
  * overlap when it reports pending frames or a skipped last frame, so whatever is
@@ -174,6 +183,20 @@ int rtvm_batch_status(rtvm_ctx* ctx, int* n_done, int* status, int* n_matches, i
  * then waits for them too. */
 int rtvm_batch_status_at(rtvm_ctx* ctx, int back, int* n_done, int* status, int* n_matches,
                          int* n_keypoints, int cap);
+/* Ticket of the batch queued last (rtvm_process_batch, rtvm_process_frame or rtvm_batch_retry);
+ * tickets count up from 1 after rtvm_stream_begin. */
+long rtvm_batch_ticket(rtvm_ctx* ctx);
+/* rtvm_batch_status for one of the last 8 tickets, plus the reason (RTVM_PENDING_*) when
+ * frames were left pending.  Waits for that batch only. */
+int rtvm_batch_status_of(rtvm_ctx* ctx, long ticket, int* n_done, int* reason, int* status,
+                         int* n_matches, int* n_keypoints, int cap);
+/* Queues the canvas half again (validate / smooth / chain, warp, blend) for frames first ..
+ * first+count-1 of the batch `ticket` (queued with rtvm_process_batch, one of the last four),
+ * reusing its detection, matching and RANSAC results: for frames left pending with
+ * RTVM_PENDING_MASK, or for a RTVM_PENDING_VOID batch queued behind such frames, in frame
+ * order.  The retry is a batch of its own (rtvm_batch_ticket).  No counterpart in the
+ * reference: part of the batching scheme.  Asynchronous. */
+int rtvm_batch_retry(rtvm_ctx* ctx, long ticket, int first, int count);
 /* Status bits, match count and the absolute homography of the most recent
  * rtvm_process_frame (any may be NULL).  Syncs the stream. */
 int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_matches, double H_abs[9]);

@@ -17,6 +17,7 @@ DET_ORB, DET_SIFT_MATCH_ONLY = 0, 1
 FLAG_WARP_FIXED = 1
 FLAG_SINGLE_STREAM = 4
 FRAME_FEW_MATCHES, FRAME_NO_HOMOGRAPHY, FRAME_INVALID_H = 1, 2, 4
+PENDING_NONE, PENDING_SKIPPED_FRAME, PENDING_MASK, PENDING_VOID = 0, 1, 2, 3
 
 # name -> (restype, argtypes); also the list the symbol-export test walks
 _u8p = C.POINTER(C.c_uint8)
@@ -50,6 +51,9 @@ SIGNATURES = {
     "rtvm_process_batch": (C.c_int, [_vp, _vp, C.c_int]),
     "rtvm_batch_status": (C.c_int, [_vp, _intp, _vp, _vp, _vp, C.c_int]),
     "rtvm_batch_status_at": (C.c_int, [_vp, C.c_int, _intp, _vp, _vp, _vp, C.c_int]),
+    "rtvm_batch_ticket": (C.c_long, [_vp]),
+    "rtvm_batch_status_of": (C.c_int, [_vp, C.c_long, _intp, _intp, _vp, _vp, _vp, C.c_int]),
+    "rtvm_batch_retry": (C.c_int, [_vp, C.c_long, C.c_int, C.c_int]),
     "rtvm_first_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_frame_register": (C.c_int, [_vp, _vp, _intp, _intp, _vp]),
     "rtvm_frame_commit": (C.c_int, [_vp, _vp]),
@@ -295,7 +299,7 @@ class Context:
 
     def profile_stop(self):
         """Returns {kernel name: (launches, total_ms, stream)}; stream 0 = main (canvas half),
-        1 = detection + matching, 2 = RANSAC."""
+        1 = detection + matching, 2 = RANSAC search, 3 = RANSAC polish."""
         self._check(lib().rtvm_profile_stop(self._h))
         n = lib().rtvm_profile_report(self._h, None, 0)
         buf = C.create_string_buffer(n + 16)
@@ -332,37 +336,96 @@ class Context:
         self._check(lib().rtvm_batch_status_at(self._h, back, C.byref(done), ptr(st), ptr(nm), ptr(nk), n))
         return done.value, st, nm, nk
 
+    def batch_ticket(self):
+        """Ticket of the batch queued last."""
+        return int(lib().rtvm_batch_ticket(self._h))
+
+    def batch_status_of(self, ticket, n):
+        """(frames consumed, reason, status[n], matches[n], keypoints[n]) of the batch `ticket`
+        (one of the last 8).  reason: PENDING_* when frames were left pending."""
+        done, reason = C.c_int(0), C.c_int(0)
+        st = np.zeros(n, np.int32)
+        nm = np.zeros(n, np.int32)
+        nk = np.zeros(n, np.int32)
+        self._check(lib().rtvm_batch_status_of(self._h, ticket, C.byref(done), C.byref(reason), ptr(st), ptr(nm),
+                                               ptr(nk), n))
+        return done.value, reason.value, st, nm, nk
+
+    def batch_retry(self, ticket, first, count):
+        """Queues the canvas half again for frames first .. first+count-1 of the batch `ticket`;
+        returns the ticket of the retry."""
+        self._check(lib().rtvm_batch_retry(self._h, ticket, int(first), int(count)))
+        return self.batch_ticket()
+
+    def _retry_pending(self, ticket, start, k, first, status, stats):
+        """Frames first .. k-1 of the batch `ticket` (video frames start+first ..) came back pending
+        although their detection, matching and RANSAC results stand: queues their canvas half
+        again, one frame at first (such events come in runs), twice as many after every retry that
+        goes through whole.  Returns None when all k frames are consumed, else the video frame from
+        which a fresh submission is needed (a skipped frame invalidated the matching behind it)."""
+        m = 1
+        while first < k:
+            cnt = min(m, k - first)
+            t2 = self.batch_retry(ticket, first, cnt)
+            stats["retries"] += 1
+            stats["frames_retried"] += cnt
+            d2, reason, st2, _, _ = self.batch_status_of(t2, cnt)
+            status[start + first:start + first + d2] = st2[:d2]
+            first += d2
+            if d2 == cnt:
+                m = min(2 * m, k)
+            elif reason == PENDING_MASK:
+                m = 1
+            else:
+                return start + first
+        return None
+
     def process_video(self, bgr_dev_ptrs, batch=16):
         """process_frame over a whole list of device-resident frames in batches, three batches
-        in flight, resubmitting the frames a skipped frame left pending.  Returns the
-        per-frame status codes."""
+        in flight.  Frames come back pending (a) behind a frame the reference skips: they are
+        submitted again from there; (b) behind a blend that cleared a canvas pixel and so broke
+        the canvas masks predicted for the rest of its batch: only their canvas half is queued
+        again (rtvm_batch_retry), for them and for the batches that were in flight behind.
+        Returns the per-frame status codes; self.video_stats counts what was queued."""
         self.reserve_batch(batch)
         n = len(bgr_dev_ptrs)
         status = np.zeros(n, np.int32)
-        inflight = []   # (first frame, length) of the queued batches, oldest first
+        inflight = []   # (ticket, first frame, length) of the queued batches, oldest first
         nxt = 0         # next frame to queue
+        stats = {"frames": n, "batches_queued": 0, "frames_queued": 0, "batches_with_pending_frames": 0,
+                 "retries": 0, "frames_retried": 0}
         while nxt < n or inflight:
             while len(inflight) < 3 and nxt < n:
                 k = min(batch, n - nxt)
                 self.process_batch(bgr_dev_ptrs[nxt:nxt + k])
-                inflight.append((nxt, k))
+                stats["batches_queued"] += 1
+                stats["frames_queued"] += k
+                inflight.append((self.batch_ticket(), nxt, k))
                 nxt += k
-            start, k = inflight.pop(0)
-            done, st, _, _ = self.batch_status(k, back=len(inflight))
+            ticket, start, k = inflight.pop(0)
+            done, reason, st, _, _ = self.batch_status_of(ticket, k)
             status[start:start + done] = st[:done]
-            if done < k:
-                # a skipped frame left the rest of this batch pending, and with it whatever was
-                # queued behind: queue again from the first pending frame
+            if done == k:
+                if inflight and st[k - 1] & (FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY):
+                    # the last frame was skipped: a batch matched against it ahead of time comes
+                    # back pending as a whole (0 frames consumed), submit it again
+                    done2 = self.batch_status_of(inflight[0][0], inflight[0][2])[0]
+                    if done2 == 0:
+                        nxt = inflight[0][1]
+                        inflight.clear()
+                continue
+            stats["batches_with_pending_frames"] += 1
+            redo = start + done
+            if reason == PENDING_MASK:
+                # canvas half again for the rest of this batch, then for the batches behind it
+                redo = self._retry_pending(ticket, start, k, done, status, stats)
+                while redo is None and inflight:
+                    ticket, start, k = inflight.pop(0)
+                    redo = self._retry_pending(ticket, start, k, 0, status, stats)
+            if redo is not None:
                 inflight.clear()
-                nxt = start + done
-            elif inflight and st[k - 1] & (FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY):
-                # the last frame was skipped: a batch matched against it ahead of time comes
-                # back pending as a whole (0 frames consumed)
-                s2, k2 = inflight[0]
-                done2, _, _, _ = self.batch_status(k2, back=len(inflight) - 1)
-                if done2 == 0:
-                    inflight.clear()
-                    nxt = s2
+                nxt = redo
+        self.video_stats = stats
         return status
 
     def frame_status(self):

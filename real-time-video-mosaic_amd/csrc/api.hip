@@ -216,10 +216,13 @@ int alloc_all(rtvm_ctx* c) {
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_rep, c->h_rep, 0));
     for (int k = 0; k < RTVM_NSETS; k++) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_feat[k], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_search[k], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_front[k], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_back[k], hipEventDisableTiming));
     }
-    for (int k = 0; k < 4; k++) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
+    for (int k = 0; k < RTVM_REPORTS; k++) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
+    c->recs = (BatchRecord*)calloc(RTVM_RECORDS, sizeof(BatchRecord));
+    if (!c->recs) RTVM_FAIL(c, RTVM_E_NOMEM, "host allocation failed");
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     c->spec_tail = -1;
     c->h_slots = (FrameSlot*)calloc(RTVM_MAX_SLOTS + 1, sizeof(FrameSlot));
@@ -307,11 +310,13 @@ void free_all(rtvm_ctx* c) {
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (int k = 0; k < RTVM_NSETS; k++) {
         if (c->ev_feat[k]) (void)hipEventDestroy(c->ev_feat[k]);
+        if (c->ev_search[k]) (void)hipEventDestroy(c->ev_search[k]);
         if (c->ev_front[k]) (void)hipEventDestroy(c->ev_front[k]);
         if (c->ev_back[k]) (void)hipEventDestroy(c->ev_back[k]);
     }
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < RTVM_REPORTS; k++)
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+    free(c->recs);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
 }
 
@@ -353,11 +358,19 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
         delete c;
         return RTVM_E_HIP;
     }
+    if (hipStreamCreate(&c->stream_lm) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream_rs);
+        (void)hipStreamDestroy(c->stream_front);
+        (void)hipStreamDestroy(c->stream_main);
+        delete c;
+        return RTVM_E_HIP;
+    }
     c->stream = c->stream_main;
     int r = alloc_all(c);
     if (r != RTVM_OK) {
         fprintf(stderr, "rtvm_create: %s\n", c->err);
         free_all(c);
+        (void)hipStreamDestroy(c->stream_lm);
         (void)hipStreamDestroy(c->stream_rs);
         (void)hipStreamDestroy(c->stream_front);
         (void)hipStreamDestroy(c->stream_main);
@@ -373,9 +386,11 @@ extern "C" void rtvm_destroy(rtvm_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream_front);
     (void)hipStreamSynchronize(c->stream_rs);
+    (void)hipStreamSynchronize(c->stream_lm);
     (void)hipStreamSynchronize(c->stream_main);
     rtvm_prof_free(c);
     free_all(c);
+    (void)hipStreamDestroy(c->stream_lm);
     (void)hipStreamDestroy(c->stream_rs);
     (void)hipStreamDestroy(c->stream_front);
     (void)hipStreamDestroy(c->stream_main);

@@ -78,10 +78,10 @@ struct FrameSlot {
 };
 
 #define RTVM_MAX_BATCH 32
-// Three sets of batch slots (set k = slots k*RTVM_MAX_BATCH ...): while the canvas half of
-// one batch runs, RANSAC of the next batch and detection + matching of the one after it
-// work in the other two sets.
-#define RTVM_NSETS 3
+// Four sets of batch slots (set k = slots k*RTVM_MAX_BATCH ...): while the canvas half of
+// one batch runs, the RANSAC polish, the RANSAC search and detection + matching of the
+// three batches after it work in the other sets.
+#define RTVM_NSETS 4
 #define RTVM_MAX_SLOTS (RTVM_NSETS * RTVM_MAX_BATCH)
 #define RTVM_STAGE_SLOT RTVM_MAX_SLOTS   // slot used by the host-buffer matcher / RANSAC entry points
 
@@ -150,11 +150,22 @@ struct StreamState {
 
 // What the caller reads back about one batch; written by the device into pinned host memory.
 struct BatchReport {
-    int n_done, abort, tail_ok, pad;
+    int n_done, abort, tail_ok;
+    int reason;   // why n_done < n: RTVM_PENDING_*
     int status[RTVM_MAX_BATCH];
     int matches[RTVM_MAX_BATCH];
     int kp[RTVM_MAX_BATCH];
 };
+
+// What the library remembers about a queued batch, so that its canvas half can be queued
+// again for the frames that came back pending.
+struct BatchRecord {
+    long ticket;     // 0 = empty
+    int set, sb, n;  // slot set, first slot, frames
+    const uint8_t* ptrs[RTVM_MAX_BATCH];
+};
+#define RTVM_RECORDS 64
+#define RTVM_REPORTS 8
 
 // frame pointers of a batch, passed to the binding kernel by value
 struct BatchPtrs {
@@ -166,11 +177,13 @@ struct rtvm_ctx {
     hipStream_t stream;        // stream the launch macros use right now
     hipStream_t stream_main;   // canvas half, host-buffer entry points, read-backs
     hipStream_t stream_front;  // detection + matching of a batch queued ahead of the canvas half
-    hipStream_t stream_rs;     // RANSAC of a batch queued ahead of the canvas half
+    hipStream_t stream_rs;     // RANSAC hypothesis search of a batch queued ahead of the canvas half
+    hipStream_t stream_lm;     // RANSAC polish (least squares + Levenberg-Marquardt) of such a batch
+    hipEvent_t ev_search[RTVM_NSETS]; // RANSAC search of the batch in slot set k is complete
     hipEvent_t ev_feat[RTVM_NSETS];   // detection + matching of the batch in slot set k is complete
-    hipEvent_t ev_front[RTVM_NSETS];  // RANSAC of the batch in slot set k is complete
+    hipEvent_t ev_front[RTVM_NSETS];  // RANSAC polish of the batch in slot set k is complete
     hipEvent_t ev_back[RTVM_NSETS];   // canvas half of the batch that used slot set k is complete
-    hipEvent_t ev_done[4];     // batch number (seq & 3) is complete
+    hipEvent_t ev_done[RTVM_REPORTS];  // batch number (seq % RTVM_REPORTS) is complete
     hipEvent_t ev_main;
     int back_rec[RTVM_NSETS];  // ev_back[k] has been recorded
     int set_next;              // slot set of the next pipelined batch
@@ -178,7 +191,9 @@ struct rtvm_ctx {
                                // the next batch is matched against feat_prev after a full wait
     long seq;                  // batches queued since the stream began
     int n_set1;                // allocated slots of each of the sets 1 .. RTVM_NSETS-1
-    BatchReport* h_rep;        // [4] pinned, indexed by seq & 3
+    BatchReport* h_rep;        // [RTVM_REPORTS] pinned, indexed by seq % RTVM_REPORTS
+    BatchRecord* recs;         // [RTVM_RECORDS], indexed by ticket % RTVM_RECORDS
+    long set_owner[RTVM_NSETS]; // ticket of the batch whose detection results the slot set holds
     BatchReport* d_rep;        // device view of h_rep
     int fh, fw, ch, cw;
     int detector, nfeatures, flags;
@@ -301,6 +316,8 @@ int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int with_orb);  // api.h
 size_t rtvm_ransac_state_bytes();
 void rtvm_ransac_raw_table(uint32_t* raw, int n);
 int rtvm_launch_ransac(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence);
+int rtvm_launch_ransac_search(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence);
+int rtvm_launch_ransac_refine(rtvm_ctx* c, int sb, int nb, double thresh);
 int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim, int32_t* d_idx,
                         float* d_dist, float* d_norms, int* d_flag);
 

@@ -15,7 +15,7 @@ struct Prof {
     std::vector<std::string> names;
     std::vector<double> sum_ms;
     std::vector<long> count;
-    std::vector<int> stream;   // 0 main, 1 detection + matching, 2 RANSAC
+    std::vector<int> stream;   // 0 main, 1 detection + matching, 2 RANSAC search, 3 RANSAC polish
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
 };
@@ -48,7 +48,7 @@ int rtvm_prof_begin(rtvm_ctx* c, const char* name) {
         p->count.push_back(0);
         p->stream.push_back(0);
     }
-    p->stream[idx] = c->stream == c->stream_front ? 1 : c->stream == c->stream_rs ? 2 : 0;
+    p->stream[idx] = c->stream == c->stream_front ? 1 : c->stream == c->stream_rs ? 2 : c->stream == c->stream_lm ? 3 : 0;
     Rec r{idx, take_event(p), take_event(p)};
     if (!r.e0 || !r.e1) return -1;
     (void)hipEventRecord(r.e0, c->stream);
@@ -94,6 +94,7 @@ extern "C" int rtvm_profile_stop(rtvm_ctx* c) {
     c->prof_mode = 0;
     HIP_TRY(c, hipStreamSynchronize(c->stream_front));
     HIP_TRY(c, hipStreamSynchronize(c->stream_rs));
+    HIP_TRY(c, hipStreamSynchronize(c->stream_lm));
     HIP_TRY(c, hipStreamSynchronize(c->stream_main));
     Prof* p = get(c);
     for (auto& r : p->recs) {
@@ -110,7 +111,7 @@ extern "C" int rtvm_profile_stop(rtvm_ctx* c) {
 }
 
 // One line per kernel: "name count total_ms stream" (stream: 0 = main, 1 = detection +
-// matching, 2 = RANSAC; the stream of the kernel's last launch).  Returns the number of
+// matching, 2 = RANSAC search, 3 = RANSAC polish; the stream of the kernel's last launch).  Returns the number of
 // bytes needed.
 extern "C" int rtvm_profile_report(rtvm_ctx* c, char* buf, int buflen) {
     if (!c) return RTVM_E_ARG;

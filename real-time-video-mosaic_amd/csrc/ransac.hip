@@ -762,10 +762,11 @@ void rtvm_ransac_raw_table(uint32_t* raw, int n) {
     }
 }
 
-// Queues the whole of findHomography(RANSAC) for slots sb .. sb+nb-1: point pairs in
-// slot.rs_src / rs_dst (count in slot.rs_count); results in slot.rs_H (9 doubles),
-// slot.rs_mask (count bytes), slot.rs_found.
-int rtvm_launch_ransac(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence) {
+// findHomography(RANSAC) for slots sb .. sb+nb-1 in two parts: the search for the best
+// 4-point hypothesis, then the polish (inlier mask, least squares on the inliers,
+// Levenberg-Marquardt).  Point pairs in slot.rs_src / rs_dst (count in slot.rs_count);
+// results in slot.rs_H (9 doubles), slot.rs_mask (count bytes), slot.rs_found.
+int rtvm_launch_ransac_search(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence) {
     if (max_iters > RTVM_RANSAC_MAX_ITERS)
         RTVM_FAIL(c, RTVM_E_ARG, "findHomography: maxIters above %d is not supported", RTVM_RANSAC_MAX_ITERS);
     if (max_iters < 1) max_iters = 1;
@@ -782,7 +783,19 @@ int rtvm_launch_ransac(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters
         RTVM_LAUNCH(c, k_rs_hyp, dim3(max_iters - b0, nb), dim3(64), 0, sl, sb, b0, max_iters, thr);
         RTVM_LAUNCH(c, k_rs_replay, dim3(nb), dim3(64), 0, sl, sb, b0, max_iters, confidence, 1);
     }
-    RTVM_LAUNCH(c, k_rs_refine, dim3(nb), dim3(64), 0, sl, sb, thr);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
+}
+
+int rtvm_launch_ransac_refine(rtvm_ctx* c, int sb, int nb, double thresh) {
+    const float thr = (float)(thresh * thresh);
+    RTVM_LAUNCH(c, k_rs_refine, dim3(nb), dim3(64), 0, c->d_slots, sb, thr);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}
+
+int rtvm_launch_ransac(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence) {
+    int r = rtvm_launch_ransac_search(c, sb, nb, thresh, max_iters, confidence);
+    if (r != RTVM_OK) return r;
+    return rtvm_launch_ransac_refine(c, sb, nb, thresh);
 }

@@ -15,10 +15,11 @@
 // the later frames of the batch are left untouched (RTVM_FRAME_PENDING) for the
 // caller to resubmit, so the result is the reference's for any batch size.
 //
-// Three streams: rtvm_process_batch queues detection + matching of a batch on the front
-// stream, its RANSAC on a second stream and the back half on the main stream, cycling
-// through three sets of frame slots, so detection of batch k+2 and RANSAC of batch k+1
-// (small grids, latency bound) overlap the back half of batch k (bandwidth bound).  The
+// Four streams: rtvm_process_batch queues detection + matching of a batch on the front
+// stream, its RANSAC search and RANSAC polish on two more streams and the back half on the
+// main stream, cycling through four sets of frame slots, so detection of batch k+3 and the
+// RANSAC stages of batches k+2 and k+1 (small grids, latency bound) overlap the back half
+// of batch k (bandwidth bound).  The
 // first frame of a batch is then matched against the last frame of the batch before it
 // before that frame is known to be accepted; when it was not, the later batch is left
 // pending as a whole, exactly like the rest of a batch after a skipped frame.
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
         st->abort = abort ? 1 : 0;
         st->n_done = n_done;
         st->last_good = last_good;
-        st->tail_ok = (!abort && last_good == n - 1) ? 1 : 0;
+        // did the last frame that was consumed advance the state?  (unchanged by a void batch)
+        if (n_done > 0) st->tail_ok = (!abort && last_good == n - 1) ? 1 : 0;
     }
     __syncthreads();
     {
@@ -214,6 +216,7 @@ __global__ void k_batch_finish(StreamState* __restrict__ st, const StreamState* 
                                BatchReport* __restrict__ rep) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int bad = st->bad_frame;
+    int reason = RTVM_PENDING_NONE;
     bool later = false;
     if (bad >= 0 && bad < n - 1)
         for (int j = bad + 1; j < n; j++) later |= st->b_status[j] != RTVM_FRAME_PENDING;
@@ -224,15 +227,19 @@ __global__ void k_batch_finish(StreamState* __restrict__ st, const StreamState* 
             st->b_matches[j] = 0;
             st->b_kp[j] = 0;
         }
-        st->abort = 1;
+        st->abort = 1;  // whatever is queued behind this batch is void
         st->n_done = bad + 1;
         st->last_good = bad;
-        st->tail_ok = 0;
+        st->tail_ok = 1;  // the last frame that was consumed advanced the state
+        reason = RTVM_PENDING_MASK;
+    } else if (st->n_done < n) {
+        reason = st->n_done == 0 ? RTVM_PENDING_VOID : RTVM_PENDING_SKIPPED_FRAME;
     }
     st->bad_frame = 0x7FFFFFFF;
     rep->n_done = st->n_done;
     rep->abort = st->abort;
     rep->tail_ok = st->tail_ok;
+    rep->reason = reason;
     for (int j = 0; j < n; j++) {
         rep->status[j] = st->b_status[j];
         rep->matches[j] = st->b_matches[j];
@@ -357,10 +364,16 @@ int queue_first_frame(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_of
 }
 
 // glue + warp/blend of every frame + kp_prev/des_prev update, on the main stream
-int queue_back_half(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, int ahead) {
+int queue_back_half(rtvm_ctx* c, int set, int sb, const uint8_t* const* ptrs, int n, int ahead) {
     int r;
     c->seq += 1;
-    const int slot = (int)(c->seq & 3);
+    const int slot = (int)(c->seq % RTVM_REPORTS);
+    BatchRecord& rec = c->recs[c->seq % RTVM_RECORDS];
+    rec.ticket = c->seq;
+    rec.set = set;
+    rec.sb = sb;
+    rec.n = n;
+    for (int j = 0; j < n; j++) rec.ptrs[j] = ptrs[j];
     RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
                 50.0, 0.3, ahead, c->d_snap);
     if ((r = rtvm_launch_warp_prep(c, c->d_H, c->d_skip, n))) return r;
@@ -391,10 +404,12 @@ int queue_batch_serial(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
     c->spec_tail = -1;
     if ((r = bind_batch(c, 0, ptrs, n, c->feat_prev))) return r;
     if ((r = queue_front_half(c, 0, n))) return r;
-    return queue_back_half(c, 0, ptrs, n, 0);
+    c->set_owner[0] = c->seq + 1;
+    return queue_back_half(c, 0, 0, ptrs, n, 0);
 }
 
-// One batch with detection + matching on the front stream and RANSAC on the RANSAC stream.
+// One batch with detection + matching on the front stream, the RANSAC search and the RANSAC
+// polish on streams of their own.
 int queue_batch_overlapped(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
     int r;
     if (n < 1 || n > c->n_batch || n > c->n_set1)
@@ -419,11 +434,18 @@ int queue_batch_overlapped(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
     HIP_TRY(c, hipStreamWaitEvent(c->stream_rs, c->ev_feat[set], 0));
     {
         StreamScope fs(c, c->stream_rs);
-        if ((r = rtvm_launch_ransac(c, sb, n, 2.0, 2000, 0.995))) return r;
-        HIP_TRY(c, hipEventRecord(c->ev_front[set], c->stream_rs));
+        if ((r = rtvm_launch_ransac_search(c, sb, n, 2.0, 2000, 0.995))) return r;
+        HIP_TRY(c, hipEventRecord(c->ev_search[set], c->stream_rs));
+    }
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_lm, c->ev_search[set], 0));
+    {
+        StreamScope fs(c, c->stream_lm);
+        if ((r = rtvm_launch_ransac_refine(c, sb, n, 2.0))) return r;
+        HIP_TRY(c, hipEventRecord(c->ev_front[set], c->stream_lm));
     }
     HIP_TRY(c, hipStreamWaitEvent(c->stream_main, c->ev_front[set], 0));
-    if ((r = queue_back_half(c, sb, ptrs, n, ahead))) return r;
+    c->set_owner[set] = c->seq + 1;
+    if ((r = queue_back_half(c, set, sb, ptrs, n, ahead))) return r;
     HIP_TRY(c, hipEventRecord(c->ev_back[set], c->stream_main));
     c->back_rec[set] = 1;
     c->spec_tail = sb + n - 1;
@@ -498,19 +520,21 @@ static int read_state(rtvm_ctx* c, StreamState** hs_out) {
     return RTVM_OK;
 }
 
-// back = 0: the batch queued last; back = 1, 2: the ones before it (waits for that batch
-// only, so the caller can keep two batches in flight while it reads the outcome of a third).
-extern "C" int rtvm_batch_status_at(rtvm_ctx* c, int back, int* n_done, int* status, int* n_matches,
-                                    int* n_keypoints, int cap) {
+extern "C" long rtvm_batch_ticket(rtvm_ctx* c) { return c ? c->seq : 0; }
+
+extern "C" int rtvm_batch_status_of(rtvm_ctx* c, long ticket, int* n_done, int* reason, int* status,
+                                    int* n_matches, int* n_keypoints, int cap) {
     if (!c) return RTVM_E_ARG;
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "batch_status: no stream");
-    if (back < 0 || back > 2 || c->seq - back < 1)
-        RTVM_FAIL(c, RTVM_E_STATE, "batch_status: no batch %d before the last one (%ld queued)", back, c->seq);
+    if (ticket < 1 || ticket > c->seq || c->seq - ticket >= RTVM_REPORTS)
+        RTVM_FAIL(c, RTVM_E_STATE, "batch_status: ticket %ld is not one of the last %d (%ld queued)", ticket,
+                  RTVM_REPORTS, c->seq);
     HIP_TRY(c, hipSetDevice(c->device));
-    const int slot = (int)((c->seq - back) & 3);
+    const int slot = (int)(ticket % RTVM_REPORTS);
     HIP_TRY(c, hipEventSynchronize(c->ev_done[slot]));
     const BatchReport* rep = c->h_rep + slot;
     if (n_done) *n_done = rep->n_done;
+    if (reason) *reason = rep->reason;
     for (int j = 0; j < cap && j < RTVM_MAX_BATCH; j++) {
         if (status) status[j] = rep->status[j];
         if (n_matches) n_matches[j] = rep->matches[j];
@@ -527,8 +551,41 @@ extern "C" int rtvm_batch_status_at(rtvm_ctx* c, int back, int* n_done, int* sta
     return RTVM_OK;
 }
 
+// back = 0: the batch queued last; back = 1, 2: the ones before it (waits for that batch
+// only, so the caller can keep two batches in flight while it reads the outcome of a third).
+extern "C" int rtvm_batch_status_at(rtvm_ctx* c, int back, int* n_done, int* status, int* n_matches,
+                                    int* n_keypoints, int cap) {
+    if (!c) return RTVM_E_ARG;
+    if (back < 0 || back > 2 || c->seq - back < 1)
+        RTVM_FAIL(c, RTVM_E_STATE, "batch_status: no batch %d before the last one (%ld queued)", back, c->seq);
+    return rtvm_batch_status_of(c, c->seq - back, n_done, nullptr, status, n_matches, n_keypoints, cap);
+}
+
 extern "C" int rtvm_batch_status(rtvm_ctx* c, int* n_done, int* status, int* n_matches, int* n_keypoints, int cap) {
     return rtvm_batch_status_at(c, 0, n_done, status, n_matches, n_keypoints, cap);
+}
+
+extern "C" int rtvm_batch_retry(rtvm_ctx* c, long ticket, int first, int count) {
+    if (!c) return RTVM_E_ARG;
+    if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "batch_retry: no stream");
+    if (ticket < 1 || ticket > c->seq || c->seq - ticket >= RTVM_RECORDS)
+        RTVM_FAIL(c, RTVM_E_STATE, "batch_retry: unknown ticket %ld", ticket);
+    const BatchRecord rec = c->recs[ticket % RTVM_RECORDS];
+    if (rec.ticket != ticket || c->set_owner[rec.set] != ticket)
+        RTVM_FAIL(c, RTVM_E_STATE, "batch_retry: the detection results of batch %ld are no longer held", ticket);
+    if (first < 0 || count < 1 || first + count > rec.n)
+        RTVM_FAIL(c, RTVM_E_ARG, "batch_retry: frames %d..%d of a batch of %d", first, first + count - 1, rec.n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    // The frame before `first` is the last one that advanced the state (the glue checks it):
+    // frame first-1 of this batch, or the last frame of the batch before it.
+    int r = queue_back_half(c, rec.set, rec.sb + first, rec.ptrs + first, count, 1);
+    if (r) return r;
+    // whoever refills this slot set waits for the retry as well
+    HIP_TRY(c, hipEventRecord(c->ev_back[rec.set], c->stream_main));
+    c->back_rec[rec.set] = 1;
+    // a batch queued next is matched against the last frame of this one
+    c->spec_tail = rec.sb + first + count - 1;
+    return RTVM_OK;
 }
 
 extern "C" int rtvm_frame_status(rtvm_ctx* c, int* status, int* n_keypoints, int* n_matches, double H_abs[9]) {

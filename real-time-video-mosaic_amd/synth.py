@@ -69,6 +69,30 @@ def camera_path(n_frames, cx, cy, seed=2, **kw):
     return out
 
 
+def bounded_path(n_frames, fh, fw, seed=2, margin=150):
+    """Camera path for long videos that keeps every frame inside a canvas of 2 fh x 1.2 fw whose
+    first frame sits at the bottom centre (the reference's layout, main.py:80-90): the camera
+    climbs and descends over 0.8 fh (triangular wave, 2.5 px/frame), sways +-0.07 fw sideways,
+    rotates +-0.5 degrees and zooms +-1 %, plus +-0.5 px of jitter.  Returns (G list, world
+    height, world width) with frame_t(p) = world(G_t p)."""
+    rng = np.random.default_rng(seed)
+    ay, ax = 0.8 * fh, 0.07 * fw
+    wh, ww = int(fh + ay + 2 * margin), int(fw + 2 * ax + 2 * margin)
+    cx, cy = margin + ax, wh - fh - margin
+    out = []
+    for t in range(n_frames):
+        j = rng.uniform(-0.5, 0.5, 2) if t > 0 else (0.0, 0.0)
+        u = 2.5 * t / ay
+        tri = 2.0 * abs(u / 2.0 - np.floor(u / 2.0 + 0.5))           # 0 -> 1 -> 0, period 2
+        th = np.deg2rad(0.5 * np.sin(2 * np.pi * t / 400.0))
+        s = 1.0 + 0.01 * np.sin(2 * np.pi * t / 700.0)
+        c, sn = np.cos(th) * s, np.sin(th) * s
+        out.append(np.array([[c, -sn, cx + ax * np.sin(2 * np.pi * t / 360.0) + j[0]],
+                             [sn, c, cy - ay * tri + j[1]],
+                             [0.0, 0.0, 1.0]]))
+    return out, wh, ww
+
+
 def render_frame(world, G, fh, fw):
     """frame(p) = bilinear world(G p), u8, clamped to [1, 255] inside the world."""
     H, W = world.shape[:2]

@@ -257,3 +257,52 @@ def test_batch_with_pixels_that_blend_to_zero():
     assert np.array_equal(canvas, om.canvas)
     assert (canvas[om.canvas.any(axis=2)].size > 0)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_batch_retry_queues_only_the_canvas_half_again():
+    """rtvm_batch_retry: frames left pending because a blend cleared a canvas pixel keep their
+    detection, matching and RANSAC results; their canvas half alone is queued again, for them and
+    for the batch that was in flight behind them."""
+    import torch
+    F = rtvm._ffi
+    frames, _ = video(9, seed=9)
+    frames = [f.copy() for f in frames]
+    for f in frames:
+        f[90:150, 200:280] = 1
+    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=500)
+    om = OracleMosaic(frames[0], nfeatures=500, glue="explicit")
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+    ctx.reserve_batch(4)
+    ctx.stream_begin(dev[0].data_ptr(), om.w_offset, om.h_offset)
+    ctx.process_batch([d.data_ptr() for d in dev[1:5]])
+    t1 = ctx.batch_ticket()
+    ctx.process_batch([d.data_ptr() for d in dev[5:9]])
+    t2 = ctx.batch_ticket()
+    assert t2 == t1 + 1
+    done, reason, st, _, _ = ctx.batch_status_of(t1, 4)
+    assert 1 <= done < 4 and reason == F.PENDING_MASK and st[done:].tolist() == [8] * (4 - done)
+    done2, reason2, st2, _, _ = ctx.batch_status_of(t2, 4)
+    assert done2 == 0 and reason2 == F.PENDING_VOID and st2.tolist() == [8] * 4
+    retries = 0
+    for ticket in (t1, t2):
+        first = done if ticket == t1 else 0
+        while first < 4:
+            t = ctx.batch_retry(ticket, first, 4 - first)
+            retries += 1
+            d, r, s_, _, _ = ctx.batch_status_of(t, 4 - first)
+            assert d >= 1 and s_[:d].tolist() == [0] * d and (d == 4 - first or r == F.PENDING_MASK)
+            first += d
+    assert retries >= 3
+    for f in frames[1:]:
+        om.process_frame(f)
+        assert om.status == 0
+    st, nk, nm, H = ctx.frame_status()
+    assert np.array_equal(H, om.H)
+    assert np.array_equal(ctx.canvas_read(), om.canvas)
+    with pytest.raises(RuntimeError):
+        ctx.batch_retry(t2 + 100, 0, 1)
+    with pytest.raises(RuntimeError):
+        ctx.batch_retry(t1, 3, 2)
+    ctx.close()
