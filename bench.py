@@ -216,7 +216,10 @@ def main():
         launches, total_ms = dom[0], dom[1]
         avg_s = total_ms / launches * 1e-3
         ab_frame = algorithmic_bytes(dominant, fh, fw, ch, cw, nf, roi_px, B)
-        ab = ab_frame * K / launches if ab_frame else None   # per launch: K frames went through `launches` launches
+        # frames that went through the canvas-half kernels: those of the batches that were not void,
+        # plus the ones whose canvas half was queued again
+        K_back = vstats["frames_queued"] - vstats["frames_void"] + vstats["frames_retried"]
+        ab = ab_frame * K_back / launches if ab_frame else None   # mean per launch
         # HBM traffic of the same kernel from the PMC counters of a separate rocprofv3 run (committed
         # summary; the counters cannot be read from inside this process)
         traffic, traffic_note = None, None
@@ -225,15 +228,15 @@ def main():
                 pmc = json.load(fjs)
             ent = pmc["kernels"].get(dominant)
             if ent and args.config == "720p_orb1000":
-                traffic = ent["hbm_bytes"] * (K / launches) / pmc["frames_per_launch"]
-                traffic_note = ("2*FETCH_SIZE + WRITE_SIZE of profiles/r1_pmc_traffic.json, scaled from %d to %.0f frames "
-                                "per launch" % (pmc["frames_per_launch"], K / launches))
+                traffic = ent["hbm_bytes"] * (K_back / launches) / pmc["frames_per_launch"]
+                traffic_note = ("2*FETCH_SIZE + WRITE_SIZE of profiles/r1_pmc_traffic.json, scaled from %d to %.1f frames "
+                                "per launch" % (pmc["frames_per_launch"], K_back / launches))
         except (OSError, KeyError, ValueError):
             pass
         roof = {"kernel": dominant, "bound": "hbm", "launches": launches, "avg_us": avg_s * 1e6,
                 "achieved": (ab / avg_s / 1e9) if ab else None, "peak": 8000.0, "unit": "GB/s",
                 "frac": (ab / avg_s / 1e9 / 8000.0) if ab else None, "algorithmic_bytes": ab,
-                "algorithmic_bytes_per_frame": ab_frame, "frames_per_launch": K / launches, "traffic": traffic, "traffic_note": traffic_note,
+                "algorithmic_bytes_per_frame": ab_frame, "frames_per_launch": K_back / launches, "traffic": traffic, "traffic_note": traffic_note,
                 "stream": "main (canvas half): the stream that bounds the frame rate",
                 "longest_kernel_any_stream": {"kernel": longest, "us_per_frame": table[longest][1] * 1e3 / probe,
                                               "stream": ["main", "detect+match", "ransac search", "ransac polish"][table[longest][2]]}}
@@ -271,7 +274,8 @@ def main():
                        "last_frame": {"status": st, "keypoints": nk, "matches": nm},
                        "frames_queued": vstats["frames_queued"], "batches_queued": vstats["batches_queued"],
                        "batches_with_pending_frames": vstats["batches_with_pending_frames"],
-                       "canvas_half_retries": vstats["retries"], "frames_retried": vstats["frames_retried"]},
+                       "canvas_half_retries": vstats["retries"], "frames_retried": vstats["frames_retried"],
+                       "frames_void": vstats["frames_void"]},
             "roofline": roof, "cpu_baseline": cpu, "dropin_pcie_inclusive": dropin,
         }
         if args.kernel_table:

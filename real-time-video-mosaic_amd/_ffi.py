@@ -393,7 +393,7 @@ class Context:
         inflight = []   # (ticket, first frame, length) of the queued batches, oldest first
         nxt = 0         # next frame to queue
         stats = {"frames": n, "batches_queued": 0, "frames_queued": 0, "batches_with_pending_frames": 0,
-                 "retries": 0, "frames_retried": 0}
+                 "retries": 0, "frames_retried": 0, "frames_void": 0}
         while nxt < n or inflight:
             while len(inflight) < 3 and nxt < n:
                 k = min(batch, n - nxt)
@@ -421,6 +421,7 @@ class Context:
                 redo = self._retry_pending(ticket, start, k, done, status, stats)
                 while redo is None and inflight:
                     ticket, start, k = inflight.pop(0)
+                    stats["frames_void"] += k   # queued behind the failed batch: its canvas half did nothing
                     redo = self._retry_pending(ticket, start, k, 0, status, stats)
             if redo is not None:
                 inflight.clear()
