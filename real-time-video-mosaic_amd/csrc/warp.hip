@@ -157,20 +157,12 @@ __device__ __forceinline__ void taps4(const uint8_t* __restrict__ src, int fh, i
 // cv2.warpPerspective(frame, H, (cw, ch), INTER_LINEAR), BORDER_CONSTANT 0, for the
 // pixels of the region of interest.  FIXED: 1/32-pixel fixed point (OpenCV <= 4.10),
 // else float32 (OpenCV >= 4.11).  Also writes mask_new = any channel > 0.
-// blockIdx.z = frame of the batch: source srcs.p[z], parameters wp[z], output planes
-// sides[z] (or `out_only`, without mask, for the stage entry point), bit rows of jobs_new[z].
+// One tile of 64 x 4 canvas pixels at (bx, by), bx a multiple of 64.
 template <bool FIXED>
-__global__ __launch_bounds__(256) void k_warp(BatchPtrs srcs, const WarpParams* __restrict__ wps,
-                                              const SideDev* __restrict__ sides, uint8_t* __restrict__ out_only,
-                                              const DtJob* __restrict__ jobs_new, int fh, int fw, int ch, int cw) {
-    const uint8_t* __restrict__ src = srcs.p[blockIdx.z];
-    const WarpParams* __restrict__ wp = wps + blockIdx.z;
-    uint8_t* __restrict__ out = out_only ? out_only : sides[blockIdx.z].warped;
-    uint8_t* __restrict__ mask_new = out_only ? nullptr : sides[blockIdx.z].mask_new;
-    const DtJob* __restrict__ job_new = jobs_new ? jobs_new + blockIdx.z : nullptr;
+__device__ __forceinline__ void warp_tile(const uint8_t* __restrict__ src, const WarpParams* __restrict__ wp,
+                                          uint8_t* __restrict__ out, uint8_t* __restrict__ mask_new,
+                                          const DtJob* __restrict__ job_new, int fh, int fw, int cw, int bx, int by) {
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
-    const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
-    if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 4 <= ry0) return;
     const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
     if (y < ry0 || y >= ry1) return;  // a wave is 64 pixels of one row
     const bool inroi = x >= rx0 && x < rx1;
@@ -245,6 +237,28 @@ __global__ __launch_bounds__(256) void k_warp(BatchPtrs srcs, const WarpParams* 
     }
 }
 
+// blockIdx.z = frame of the batch: source srcs.p[z], parameters wp[z], output planes
+// sides[z] (or `out_only`, without mask, for the stage entry point), bit rows of jobs_new[z].
+// The grid is sized for a region of interest of about the frame's size and walks the
+// tiles of the actual one (tile (0,0) holds the ROI's first pixel).
+template <bool FIXED>
+__global__ __launch_bounds__(256) void k_warp(BatchPtrs srcs, const WarpParams* __restrict__ wps,
+                                              const SideDev* __restrict__ sides, uint8_t* __restrict__ out_only,
+                                              const DtJob* __restrict__ jobs_new, int fh, int fw, int ch, int cw) {
+    const uint8_t* __restrict__ src = srcs.p[blockIdx.z];
+    const WarpParams* __restrict__ wp = wps + blockIdx.z;
+    uint8_t* __restrict__ out = out_only ? out_only : sides[blockIdx.z].warped;
+    uint8_t* __restrict__ mask_new = out_only ? nullptr : sides[blockIdx.z].mask_new;
+    const DtJob* __restrict__ job_new = jobs_new ? jobs_new + blockIdx.z : nullptr;
+    const int rx1 = wp->rx1, ry1 = wp->ry1;
+    const int ox = wp->rx0 & ~63, oy = wp->ry0 & ~3;
+#pragma unroll 1
+    for (int by = oy + 4 * (int)blockIdx.y; by < ry1; by += 4 * (int)gridDim.y)
+#pragma unroll 1
+        for (int bx = ox + 64 * (int)blockIdx.x; bx < rx1; bx += 64 * (int)gridDim.x)
+            warp_tile<FIXED>(src, wp, out, mask_new, job_new, fh, fw, cw, bx, by);
+}
+
 // The canvas mask each frame of a batch will meet, as zero bit rows, assuming that a pixel
 // of the canvas is non-zero after a frame iff it was non-zero before or the warped frame is
 // non-zero there (a blend of two non-zero pixels stays non-zero; the commit kernel reports
@@ -276,17 +290,12 @@ __global__ __launch_bounds__(256) void k_pred_bits(const uint32_t* __restrict__ 
 // BORDER_REFLECT_101 at the canvas edge.  dn is zero outside the ROI.  One wave =
 // 256 consecutive pixels of one row staged through LDS, 4 outputs per lane from a
 // window of 34 staged values; a workgroup takes 4 rows; blockIdx.z = frame of the batch.
-__global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
-                                                   const SideDev* __restrict__ sides, int cw) {
-    const WarpParams* __restrict__ wp = wps + blockIdx.z;
+__device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
+                                               const SideDev& side, int cw, int bx, int by, float (*s_n)[288],
+                                               float (*s_o)[288], float* s_k) {
     const int rx0 = wp->rx0, rx1 = wp->rx1, wy0 = wp->wy0, wy1 = wp->wy1;
-    const int bx = blockIdx.x * 256, by = blockIdx.y * 4;
-    if (by >= wy1 || by + 4 <= wy0 || bx >= rx1 || bx + 256 <= rx0) return;
-    const SideDev side = sides[blockIdx.z];
     const float* __restrict__ dn = side.dist_new;
     const float* __restrict__ dold = side.dist_old;
-    __shared__ __align__(16) float s_n[4][288], s_o[4][288];
-    __shared__ float s_k[32];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int y = by + wv;
     const bool row_ok = y >= wy0 && y < wy1;
@@ -340,20 +349,45 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
     }
 }
 
+// blockIdx.z = frame of the batch.  Tiles of 256 x 4 pixels of the frame's region (rows of
+// the blend window, columns of the ROI), tile (0,0) holding the region's first pixel.
+// REST = false: one tile per workgroup, the grid (ex x ey tiles) sized for a region of about
+// the frame's size.  REST = true: a small grid that loops over the tiles beyond ex x ey, for
+// regions larger than expected (normally none).
+template <bool REST>
+__global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
+                                                   const SideDev* __restrict__ sides, int cw, int ex, int ey) {
+    const WarpParams* __restrict__ wp = wps + blockIdx.z;
+    const SideDev side = sides[blockIdx.z];
+    __shared__ __align__(16) float s_n[4][288], s_o[4][288];
+    __shared__ float s_k[32];
+    const int rx1 = wp->rx1, wy1 = wp->wy1;
+    const int ox = wp->rx0 & ~3, oy = wp->wy0;
+    if (!REST) {
+        const int bx = ox + 256 * (int)blockIdx.x, by = oy + 4 * (int)blockIdx.y;
+        if (bx < rx1 && by < wy1) blur_rows_tile(wp, gk, side, cw, bx, by, s_n, s_o, s_k);
+        return;
+    }
+    const int ntx = rx1 > ox ? (rx1 - ox + 255) / 256 : 0, nty = wy1 > oy ? (wy1 - oy + 3) / 4 : 0;
+    if (ntx <= ex && nty <= ey) return;
+    for (int ty = blockIdx.y; ty < nty; ty += gridDim.y)
+        for (int tx = blockIdx.x; tx < ntx; tx += gridDim.x) {
+            if (tx < ex && ty < ey) continue;  // done by the one-tile-per-workgroup launch
+            blur_rows_tile(wp, gk, side, cw, ox + 256 * tx, oy + 4 * ty, s_n, s_o, s_k);
+            __syncthreads();  // the staging area is reused by the next tile
+        }
+}
+
 // Column pass of the blur (centre tap, then symmetric pairs outwards) for the pixels of the
 // ROI the warped frame covers: the final blend weights of the frame and of the canvas
 // (main.py:897-898), stored over the distance planes.  A lane takes 4 consecutive rows of
 // one column: a window of 34 row-blurred weights serves the 4 column sums.  blockIdx.z =
 // frame of the batch.
-__global__ __launch_bounds__(256) void k_blur_cols(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
-                                                   const SideDev* __restrict__ sides, int ch, int cw) {
-    const WarpParams* __restrict__ wp = wps + blockIdx.z;
+__device__ __forceinline__ void blur_cols_tile(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
+                                               const SideDev& side, int ch, int cw, int bx, int by) {
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
-    const int bx = blockIdx.x * 64, by = blockIdx.y * 16;
-    if (bx >= rx1 || bx + 64 <= rx0 || by >= ry1 || by + 16 <= ry0) return;
     const int x = bx + (threadIdx.x & 63), ya = by + 4 * (threadIdx.x >> 6);
     if (x < rx0 || x >= rx1 || ya >= ry1 || ya + 4 <= ry0) return;
-    const SideDev side = sides[blockIdx.z];
     bool need[4], any = false;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -382,6 +416,28 @@ __global__ __launch_bounds__(256) void k_blur_cols(const WarpParams* __restrict_
             outp[(size_t)(ya + i) * cw + x] = a;
         }
     }
+}
+
+// blockIdx.z = frame of the batch.  Tiles of 64 x 16 pixels of the ROI; REST as in k_blur_rows.
+template <bool REST>
+__global__ __launch_bounds__(256) void k_blur_cols(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
+                                                   const SideDev* __restrict__ sides, int ch, int cw, int ex, int ey) {
+    const WarpParams* __restrict__ wp = wps + blockIdx.z;
+    const SideDev side = sides[blockIdx.z];
+    const int rx1 = wp->rx1, ry1 = wp->ry1;
+    const int ox = wp->rx0 & ~63, oy = wp->ry0;
+    if (!REST) {
+        const int bx = ox + 64 * (int)blockIdx.x, by = oy + 16 * (int)blockIdx.y;
+        if (bx < rx1 && by < ry1) blur_cols_tile(wp, gk, side, ch, cw, bx, by);
+        return;
+    }
+    const int ntx = rx1 > ox ? (rx1 - ox + 63) / 64 : 0, nty = ry1 > oy ? (ry1 - oy + 15) / 16 : 0;
+    if (ntx <= ex && nty <= ey) return;
+    for (int ty = blockIdx.y; ty < nty; ty += gridDim.y)
+        for (int tx = blockIdx.x; tx < ntx; tx += gridDim.x) {
+            if (tx < ex && ty < ey) continue;
+            blur_cols_tile(wp, gk, side, ch, cw, ox + 64 * tx, oy + 16 * ty);
+        }
 }
 
 // Blend and commit of all frames of a batch (main.py:905-927).  With the blend weights
@@ -488,6 +544,14 @@ __global__ __launch_bounds__(256) void k_canvas_paste(const uint8_t* __restrict_
 
 }  // namespace
 
+// Grid extent for kernels that walk the tiles of a frame's region of interest: enough
+// tiles for a region of `expect` pixels (plus one for the alignment of the first tile),
+// never more than the canvas has.  Larger regions are covered by the kernels' loops.
+static unsigned roi_tiles(int canvas, int expect, int tile) {
+    const int all = (canvas + tile - 1) / tile + 1, want = (expect + tile - 1) / tile + 1;
+    return (unsigned)(want < all ? want : all);
+}
+
 // cv::getGaussianKernel(31, 0, CV_32F): sigma = 0.3*((31-1)*0.5 - 1) + 0.8
 int rtvm_warp_setup(rtvm_ctx* c) {
     const int n = 31;
@@ -563,7 +627,7 @@ int rtvm_launch_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n) {
     BatchPtrs bp;
     memset(&bp, 0, sizeof(bp));
     for (int j = 0; j < n; j++) bp.p[j] = d_bgr[j];
-    const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4, n);
+    const dim3 grid(roi_tiles(c->cw, c->fw + c->fh / 2, 64), roi_tiles(c->ch, c->fh + c->fw / 2, 4), n);
     if (c->flags & RTVM_FLAG_WARP_FIXED)
         RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, bp, c->d_wp, c->d_side, (uint8_t*)nullptr, c->d_jobs, c->fh,
                     c->fw, c->ch, c->cw);
@@ -577,10 +641,21 @@ int rtvm_launch_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n) {
 
 // Blend weights of the n frames: dn / (dn + do + eps) and its 31x31 Gaussian blur.
 int rtvm_launch_weights(rtvm_ctx* c, int n) {
-    RTVM_LAUNCH(c, k_blur_rows, dim3((c->cw + 255) / 256, (c->ch + 3) / 4, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side,
-                c->cw);
-    RTVM_LAUNCH(c, k_blur_cols, dim3((c->cw + 63) / 64, (c->ch + 15) / 16, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side,
-                c->ch, c->cw);
+    const int bw = c->fw + c->fh / 2, bh = c->fh + c->fw / 2;  // a region of about the frame's size
+    {
+        const unsigned ex = roi_tiles(c->cw, bw, 256), ey = roi_tiles(c->ch, bh + 30, 4);
+        RTVM_LAUNCH(c, k_blur_rows<false>, dim3(ex, ey, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
+                    (int)ey);
+        RTVM_LAUNCH(c, k_blur_rows<true>, dim3(4, 16, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
+                    (int)ey);
+    }
+    {
+        const unsigned ex = roi_tiles(c->cw, bw, 64), ey = roi_tiles(c->ch, bh, 16);
+        RTVM_LAUNCH(c, k_blur_cols<false>, dim3(ex, ey, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw,
+                    (int)ex, (int)ey);
+        RTVM_LAUNCH(c, k_blur_cols<true>, dim3(8, 8, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw, (int)ex,
+                    (int)ey);
+    }
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }

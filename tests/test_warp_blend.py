@@ -210,6 +210,31 @@ def test_hip_warp_blend_sequence_exact(ctxs, fixed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixed", [0, 1])
+def test_hip_warp_blend_region_much_larger_than_the_frame(fixed):
+    """The launch grids of the warp / blur kernels are sized for a region of about the frame's size;
+    a frame magnified 3.5 times covers many more tiles (taken by the kernels' loops and overflow
+    launches)."""
+    fh, fw, ch, cw = 48, 64, 400, 1100
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(1, 256, (fh, fw, 3), dtype=np.uint8) for _ in range(3)]
+    c = rtvm.Context(fh, fw, ch, cw, flags=rtvm._ffi.FLAG_WARP_FIXED if fixed else 0)
+    try:
+        c.canvas_init(frames[0], 100, 300)
+        ref = np.zeros((ch, cw, 3), np.uint8)
+        ref[100:100 + fh, 300:300 + fw] = frames[0]
+        for f, H in [(frames[1], np.array([[3.5, 0.1, 250.0], [-0.05, 3.4, 60.0], [0, 0, 1]])),
+                     (frames[2], np.array([[16.0, 0.0, 20.0], [0.0, 7.5, 15.0], [0, 0, 1]])),
+                     (frames[1], np.array([[1.0, 0.0, 310.0], [0.0, 1.0, 110.0], [0, 0, 1]]))]:
+            c.warp_blend(f, H)
+            ref = orc.warp_blend(ref, f, H, fixed)
+            got = c.canvas_read()
+            assert np.array_equal(got, ref), "%d pixels differ" % int((got != ref).any(axis=2).sum())
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_hip_warp_blend_no_overlap(ctxs):
     frames, _ = frames_small(2, zeros=False)
     c = ctxs[1]
