@@ -371,55 +371,116 @@ __device__ void dt_row(const DtJob& jb, int y, uint32_t* s_w) {
         }
         return;
     }
-    // several passes: forward results go through R, the backward sweep folds into them
-    uint32_t carry = INF32;
-    for (int p = 0; p < P; p++) {
-        const int xr = (p * 256 + t) * 8, x = xo + xr;
-        uint32_t E[8];
-        if (xr < span)
-            load_e8(jb, row, x, E);
-        else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) E[i] = INF32;
+    // wider rows are scanned by k_dt_rows_wide
+}
+
+// The 8 step values starting at x as four words (0xFFFF outside the rectangle).
+__device__ __forceinline__ uint4 load_s8(const DtJob& jb, size_t row, int x) {
+    if ((jb.pitch & 7) == 0 && x >= 0 && x + 8 <= jb.pitch) return *reinterpret_cast<const uint4*>(jb.S + row + x);
+    uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (int i = 0; i < 8; i++)
+        if (x + i >= jb.x0 && x + i < jb.x1) {
+            const uint32_t v = jb.S[row + x + i];
+            w[i >> 1] = (i & 1) ? (w[i >> 1] & 0x0000FFFFu) | (v << 16) : (w[i >> 1] & 0xFFFF0000u) | v;
         }
-        uint32_t mf = INF32;
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint32_t e_of_s8(const DtJob& jb, const uint4& sv, int x, int i) {
+    const uint32_t w = i < 2 ? sv.x : i < 4 ? sv.y : i < 6 ? sv.z : sv.w;
+    const uint32_t sx = (i & 1) ? w >> 16 : w & 0xFFFFu;
+    return (x + i >= jb.x0 && x + i < jb.x1) ? e_of(sx) : INF32;
+}
+
+// Rows wider than one workgroup pass of dt_row (2048 pixels): thread t owns the 8 pixels at
+// 8*(256 p + t) of every pass p.  The wave scans of all passes run side by side and one
+// exchange through LDS gives every (pass, wave) the minima of everything before / after it;
+// the passes that hold pixels of the output window are then loaded again and finished.
+// One workgroup per row of the output window; blockIdx.y = job.
+__global__ __launch_bounds__(256) void k_dt_rows_wide(const DtJob* __restrict__ jobs, int n_first, int second) {
+    const DtJob jb = jobs[job_index(blockIdx.y, n_first, second)];
+    const int W = jb.x1 - jb.x0, H = jb.y1 - jb.y0;
+    const int y = jb.oy0 + blockIdx.x;
+    if (W <= 0 || H <= 0 || y >= jb.oy1) return;
+    const int xo = jb.x0 & ~7;
+    const int span = jb.x1 - xo;
+    const int P = (span + 2047) / 2048;
+    if (P == 1) return;  // done by k_dt_scan
+    constexpr int PM = 9;  // 16384 pixels + alignment slack
+    const uint32_t XR = (uint32_t)(P * 2048 - 1);
+    const size_t row = (size_t)y * jb.pitch;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ uint32_t s_f[PM * 4], s_b[PM * 4];  // totals of (pass, wave): forward / backward keys
+    uint32_t pf[PM], pb[PM];
 #pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (E[i] != INF32) mf = min(mf, E[i] + DT_A * (XR - (uint32_t)(xr + i)));
-        uint32_t tot;
-        uint32_t run = wg_prefix_min_excl(mf, s_w, carry, &tot);
-        carry = tot;
+    for (int p = 0; p < PM; p++) {
+        uint32_t mf = INF32, mb = INF32;
+        const int xr = (p * 256 + t) * 8, x = xo + xr;
+        if (p < P && xr < span) {
+            const uint4 sv = load_s8(jb, row, x);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (E[i] != INF32) run = min(run, E[i] + DT_A * (XR - (uint32_t)(xr + i)));
-            const uint32_t f = run == INF32 ? INF32 : run - DT_A * (XR - (uint32_t)(xr + i));
-            if (x + i >= jb.ox0 && x + i < jb.ox1) jb.R[row + x + i] = f;
+            for (int i = 0; i < 8; i++) {
+                const uint32_t e = e_of_s8(jb, sv, x, i);
+                if (e != INF32) {
+                    mf = min(mf, e + DT_A * (XR - (uint32_t)(xr + i)));
+                    mb = min(mb, e + DT_A * (uint32_t)(xr + i));
+                }
+            }
+        }
+        pf[p] = mf;
+        pb[p] = mb;
+    }
+    // inclusive wave scans of all passes at once
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int p = 0; p < PM; p++) {
+            const uint32_t uf = __shfl_up(pf[p], o), ub = __shfl_down(pb[p], o);
+            if (lane >= o) pf[p] = min(pf[p], uf);
+            if (lane + o < 64) pb[p] = min(pb[p], ub);
         }
     }
-    carry = INF32;
-    for (int p = P - 1; p >= 0; p--) {
+#pragma unroll
+    for (int p = 0; p < PM; p++) {
+        if (lane == 63) s_f[p * 4 + wave] = pf[p];
+        if (lane == 0) s_b[p * 4 + wave] = pb[p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PM; p++) {
         const int xr = (p * 256 + t) * 8, x = xo + xr;
-        uint32_t E[8];
-        if (xr < span)
-            load_e8(jb, row, x, E);
-        else {
+        // minima of everything before (forward) / after (backward) this thread's pixels in its wave
+        uint32_t runf = __shfl_up(pf[p], 1), runb = __shfl_down(pb[p], 1);
+        if (p < P && xr < span && x + 8 > jb.ox0 && x < jb.ox1) {  // some of the window is here
+            if (lane == 0) runf = INF32;
+            if (lane == 63) runb = INF32;
+            for (int q = 0; q < PM * 4; q++) {
+                if (q < p * 4 + wave) runf = min(runf, s_f[q]);
+                if (q > p * 4 + wave) runb = min(runb, s_b[q]);
+            }
+            const uint4 sv = load_s8(jb, row, x);
+            uint32_t F[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) E[i] = INF32;
-        }
-        uint32_t mb = INF32;
+            for (int i = 0; i < 8; i++) {
+                const uint32_t e = e_of_s8(jb, sv, x, i);
+                if (e != INF32) runf = min(runf, e + DT_A * (XR - (uint32_t)(xr + i)));
+                F[i] = runf == INF32 ? INF32 : runf - DT_A * (XR - (uint32_t)(xr + i));
+            }
 #pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (E[i] != INF32) mb = min(mb, E[i] + DT_A * (uint32_t)(xr + i));
-        uint32_t tot;
-        uint32_t run = wg_suffix_min_excl(mb, s_w, carry, &tot);
-        carry = tot;
+            for (int i = 7; i >= 0; i--) {
+                const uint32_t e = e_of_s8(jb, sv, x, i);
+                if (e != INF32) runb = min(runb, e + DT_A * (uint32_t)(xr + i));
+                const uint32_t bk = runb == INF32 ? INF32 : runb - DT_A * (uint32_t)(xr + i);
+                const uint32_t v = min(F[i], bk);
+                F[i] = v > DT_MAX ? DT_MAX : v;
+            }
+            if ((jb.pitch & 3) == 0 && x >= jb.ox0 && x + 8 <= jb.ox1) {
+                uint4* o = reinterpret_cast<uint4*>(jb.R + row + x);
+                o[0] = make_uint4(F[0], F[1], F[2], F[3]);
+                o[1] = make_uint4(F[4], F[5], F[6], F[7]);
+            } else {
 #pragma unroll
-        for (int i = 7; i >= 0; i--) {
-            if (E[i] != INF32) run = min(run, E[i] + DT_A * (uint32_t)(xr + i));
-            const uint32_t b = run == INF32 ? INF32 : run - DT_A * (uint32_t)(xr + i);
-            if (x + i >= jb.ox0 && x + i < jb.ox1) {
-                const uint32_t v = min(jb.R[row + x + i], b);
-                jb.R[row + x + i] = v > DT_MAX ? DT_MAX : v;
+                for (int i = 0; i < 8; i++)
+                    if (x + i >= jb.ox0 && x + i < jb.ox1) jb.R[row + x + i] = F[i];
             }
         }
     }
@@ -566,6 +627,8 @@ int rtvm_launch_dt2(rtvm_ctx* c, const DtJob* d_jobs, int n_first, int second, i
     RTVM_LAUNCH(c, k_dt_diag_b, dim3(max_w / TW + 2, nch, njobs), dim3(320), 0, d_jobs, n_first, second);
     RTVM_LAUNCH(c, k_dt_scan, dim3(max_h + ncol_x * ((nch + 3) / 4), njobs), dim3(256), 0, d_jobs, n_first, second, max_h,
                 ncol_x);
+    if (max_w + 7 > 2048)  // rows that take more than one pass of the row scan
+        RTVM_LAUNCH(c, k_dt_rows_wide, dim3(max_h, njobs), dim3(256), 0, d_jobs, n_first, second);
     RTVM_LAUNCH(c, k_dt_cols, dim3(ncol_x, nch + 1, njobs), dim3(64), 0, d_jobs, n_first, second);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
