@@ -197,6 +197,17 @@ int rtvm_batch_status_of(rtvm_ctx* ctx, long ticket, int* n_done, int* reason, i
  * order.  The retry is a batch of its own (rtvm_batch_ticket).  No counterpart in the
  * reference: part of the batching scheme.  Asynchronous. */
 int rtvm_batch_retry(rtvm_ctx* ctx, long ticket, int first, int count);
+/* The two halves of rtvm_process_batch as separate calls, for callers that keep detection
+ * running ahead while they deal with pending frames.  rtvm_batch_detect queues detection,
+ * matching and RANSAC of n frames (matched against the frames queued before them, like
+ * rtvm_process_batch) and returns at once; the batch gets a ticket (rtvm_batch_ticket) but no
+ * status of its own.  rtvm_batch_retry(ticket, first, count) then queues the canvas half of
+ * its frames, in frame order across batches.  The batch keeps one of the four slot sets until
+ * rtvm_batch_release(ticket); rtvm_batch_detect fails with RTVM_E_STATE when no set is free.
+ * After a skipped frame (RTVM_PENDING_SKIPPED_FRAME, or a skipped last frame) the batches
+ * detected behind it were matched against the wrong frame: release them and detect again. */
+int rtvm_batch_detect(rtvm_ctx* ctx, const uint8_t* const* bgr_dev, int n);
+int rtvm_batch_release(rtvm_ctx* ctx, long ticket);
 /* Status bits, match count and the absolute homography of the most recent
  * rtvm_process_frame (any may be NULL).  Syncs the stream. */
 int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_matches, double H_abs[9]);

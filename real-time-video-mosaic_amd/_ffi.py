@@ -54,6 +54,8 @@ SIGNATURES = {
     "rtvm_batch_ticket": (C.c_long, [_vp]),
     "rtvm_batch_status_of": (C.c_int, [_vp, C.c_long, _intp, _intp, _vp, _vp, _vp, C.c_int]),
     "rtvm_batch_retry": (C.c_int, [_vp, C.c_long, C.c_int, C.c_int]),
+    "rtvm_batch_detect": (C.c_int, [_vp, _vp, C.c_int]),
+    "rtvm_batch_release": (C.c_int, [_vp, C.c_long]),
     "rtvm_first_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_frame_register": (C.c_int, [_vp, _vp, _intp, _intp, _vp]),
     "rtvm_frame_commit": (C.c_int, [_vp, _vp]),
@@ -357,12 +359,23 @@ class Context:
         self._check(lib().rtvm_batch_retry(self._h, ticket, int(first), int(count)))
         return self.batch_ticket()
 
-    def _retry_pending(self, ticket, start, k, first, status, stats):
-        """Frames first .. k-1 of the batch `ticket` (video frames start+first ..) came back pending
-        although their detection, matching and RANSAC results stand: queues their canvas half
-        again, one frame at first (such events come in runs), twice as many after every retry that
-        goes through whole.  Returns None when all k frames are consumed, else the video frame from
-        which a fresh submission is needed (a skipped frame invalidated the matching behind it)."""
+    def batch_detect(self, bgr_dev_ptrs):
+        """Queues detection, matching and RANSAC of a batch (no canvas half); returns its ticket."""
+        n = len(bgr_dev_ptrs)
+        arr = (C.c_void_p * n)(*[C.c_void_p(p) for p in bgr_dev_ptrs])
+        self._check(lib().rtvm_batch_detect(self._h, arr, n))
+        return self.batch_ticket()
+
+    def batch_release(self, ticket):
+        self._check(lib().rtvm_batch_release(self._h, ticket))
+
+    def _stitch_rest(self, ticket, start, k, first, status, stats):
+        """Frames first .. k-1 of the detected batch `ticket` (video frames start+first ..) came back
+        pending although their detection, matching and RANSAC results stand: queues their canvas
+        half again, one frame at first (such events come in runs), twice as many after every retry
+        that goes through whole.  Returns None when all k frames are consumed, else the video frame
+        from which detection has to start again (a skipped frame invalidated the matching behind
+        it)."""
         m = 1
         while first < k:
             cnt = min(m, k - first)
@@ -373,6 +386,8 @@ class Context:
             status[start + first:start + first + d2] = st2[:d2]
             first += d2
             if d2 == cnt:
+                if st2[cnt - 1] & (FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY):
+                    return start + first if start + first < len(status) else None
                 m = min(2 * m, k)
             elif reason == PENDING_MASK:
                 m = 1
@@ -381,51 +396,71 @@ class Context:
         return None
 
     def process_video(self, bgr_dev_ptrs, batch=16):
-        """process_frame over a whole list of device-resident frames in batches, three batches
-        in flight.  Frames come back pending (a) behind a frame the reference skips: they are
-        submitted again from there; (b) behind a blend that cleared a canvas pixel and so broke
-        the canvas masks predicted for the rest of its batch: only their canvas half is queued
-        again (rtvm_batch_retry), for them and for the batches that were in flight behind.
+        """process_frame over a whole list of device-resident frames.  Detection, matching and
+        RANSAC run up to three batches ahead (rtvm_batch_detect) of the canvas half, which is
+        queued batch by batch, two in flight (rtvm_batch_retry).  Frames come back pending (a)
+        behind a blend that cleared a canvas pixel and so broke the canvas masks predicted for the
+        rest of its batch: their canvas half is queued again, in small steps, while detection
+        keeps running ahead; (b) behind a frame the reference skips: the frames detected behind it
+        were matched against the wrong frame, detection starts again from there.
         Returns the per-frame status codes; self.video_stats counts what was queued."""
         self.reserve_batch(batch)
         n = len(bgr_dev_ptrs)
         status = np.zeros(n, np.int32)
-        inflight = []   # (ticket, first frame, length) of the queued batches, oldest first
-        nxt = 0         # next frame to queue
+        det = []     # detected, canvas half not queued yet: (detect ticket, first frame, length)
+        inb = []     # canvas half queued: (detect ticket, canvas-half ticket, first frame, length)
+        nxt = 0      # next frame to detect
         stats = {"frames": n, "batches_queued": 0, "frames_queued": 0, "batches_with_pending_frames": 0,
-                 "retries": 0, "frames_retried": 0, "frames_void": 0}
-        while nxt < n or inflight:
-            while len(inflight) < 3 and nxt < n:
+                 "retries": 0, "frames_retried": 0, "frames_void": 0, "frames_detected_again": 0}
+
+        def start_over(frame):
+            # a skipped frame: everything detected behind it is void
+            nonlocal nxt
+            for rec in det:
+                self.batch_release(rec[0])
+            for rec in inb:
+                self.batch_release(rec[0])
+            stats["frames_detected_again"] += nxt - frame
+            det.clear()
+            inb.clear()
+            nxt = frame
+
+        while nxt < n or det or inb:
+            while len(det) + len(inb) < 4 and nxt < n:
                 k = min(batch, n - nxt)
-                self.process_batch(bgr_dev_ptrs[nxt:nxt + k])
+                t = self.batch_detect(bgr_dev_ptrs[nxt:nxt + k])
                 stats["batches_queued"] += 1
                 stats["frames_queued"] += k
-                inflight.append((self.batch_ticket(), nxt, k))
+                det.append((t, nxt, k))
                 nxt += k
-            ticket, start, k = inflight.pop(0)
-            done, reason, st, _, _ = self.batch_status_of(ticket, k)
+            while len(inb) < 2 and det:
+                t, start, k = det.pop(0)
+                inb.append((t, self.batch_retry(t, 0, k), start, k))
+            dt, bt, start, k = inb.pop(0)
+            done, reason, st, _, _ = self.batch_status_of(bt, k)
             status[start:start + done] = st[:done]
             if done == k:
-                if inflight and st[k - 1] & (FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY):
-                    # the last frame was skipped: a batch matched against it ahead of time comes
-                    # back pending as a whole (0 frames consumed), submit it again
-                    done2 = self.batch_status_of(inflight[0][0], inflight[0][2])[0]
-                    if done2 == 0:
-                        nxt = inflight[0][1]
-                        inflight.clear()
+                self.batch_release(dt)
+                if st[k - 1] & (FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY) and start + k < n:
+                    if inb:
+                        self.batch_status_of(inb[0][1], inb[0][3])   # void: drain it
+                    start_over(start + k)
                 continue
             stats["batches_with_pending_frames"] += 1
-            redo = start + done
-            if reason == PENDING_MASK:
-                # canvas half again for the rest of this batch, then for the batches behind it
-                redo = self._retry_pending(ticket, start, k, done, status, stats)
-                while redo is None and inflight:
-                    ticket, start, k = inflight.pop(0)
-                    stats["frames_void"] += k   # queued behind the failed batch: its canvas half did nothing
-                    redo = self._retry_pending(ticket, start, k, 0, status, stats)
+            if reason != PENDING_MASK:
+                self.batch_release(dt)
+                start_over(start + done)
+                continue
+            # canvas half again for the rest of this batch, then for the one queued behind it
+            redo = self._stitch_rest(dt, start, k, done, status, stats)
+            self.batch_release(dt)
+            while redo is None and inb:
+                dt, bt, start, k = inb.pop(0)
+                stats["frames_void"] += k   # queued behind the failed batch: its canvas half did nothing
+                redo = self._stitch_rest(dt, start, k, 0, status, stats)
+                self.batch_release(dt)
             if redo is not None:
-                inflight.clear()
-                nxt = redo
+                start_over(redo)
         self.video_stats = stats
         return status
 

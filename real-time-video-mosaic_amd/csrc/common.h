@@ -136,7 +136,7 @@ struct StreamState {
     int n_matches;
     int n_kp;
     int frame_index;
-    int abort;         // a frame in the middle of a batch was skipped: later frames stay pending
+    int abort;         // later frames stay pending: 1 = a canvas mask was mispredicted, 2 = a frame was skipped
     int n_done;        // frames of the last batch that were consumed (stitched or skipped)
     int last_good;     // batch index of the last frame that advanced the state, -1 if none
     int tail_ok;       // the last frame of the last batch advanced the state (a batch whose front
@@ -162,6 +162,7 @@ struct BatchReport {
 struct BatchRecord {
     long ticket;     // 0 = empty
     int set, sb, n;  // slot set, first slot, frames
+    int ahead;       // its first frame was matched against the frame queued before it (not feat_prev)
     const uint8_t* ptrs[RTVM_MAX_BATCH];
 };
 #define RTVM_RECORDS 64
@@ -194,6 +195,7 @@ struct rtvm_ctx {
     BatchReport* h_rep;        // [RTVM_REPORTS] pinned, indexed by seq % RTVM_REPORTS
     BatchRecord* recs;         // [RTVM_RECORDS], indexed by ticket % RTVM_RECORDS
     long set_owner[RTVM_NSETS]; // ticket of the batch whose detection results the slot set holds
+    int set_live[RTVM_NSETS];   // the set holds a batch queued with rtvm_batch_detect and not yet released
     BatchReport* d_rep;        // device view of h_rep
     int fh, fw, ch, cw;
     int detector, nfeatures, flags;

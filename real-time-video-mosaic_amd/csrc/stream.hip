@@ -104,11 +104,13 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
     __syncthreads();
     StreamState* st = &S;
     int n_done = 0, last_good = -1;
-    bool abort = false;  // lane 0's
+    // lane 0's: 0 = go on; 1 = a mispredicted canvas mask upstream (detection results stand);
+    // 2 = a skipped frame upstream (the frames behind it were matched against the wrong frame)
+    int abort = 0;
     if (lane == 0) {
-        abort = st->abort != 0;
+        abort = st->abort;
         // matched ahead of time against a frame that did not advance the state
-        if (ahead && !st->tail_ok) abort = true;
+        if (ahead && !st->tail_ok) abort = 2;
     }
     for (int j = 0; j < n; j++) {
         if (lane == 0) {
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
                     status = RTVM_FRAME_NO_HOMOGRAPHY;
                 if (status) {
                     st->status = st->b_status[j] = status;
-                    if (j < n - 1) abort = true;  // the later frames were matched against this one
+                    if (j < n - 1) abort = 2;  // the later frames were matched against this one
                 } else {
                     double Hr[9];
                     for (int i = 0; i < 9; i++) Hr[i] = s_H[j][i];
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
         __syncthreads();
     }
     if (lane == 0) {
-        st->abort = abort ? 1 : 0;
+        st->abort = abort;
         st->n_done = n_done;
         st->last_good = last_good;
         // did the last frame that was consumed advance the state?  (unchanged by a void batch)
@@ -352,6 +354,7 @@ int queue_first_frame(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_of
     int r;
     c->spec_tail = -1;
     c->seq = 0;
+    for (int k = 0; k < RTVM_NSETS; k++) c->set_live[k] = 0, c->set_owner[k] = 0;
     if ((r = bind_batch(c, 0, &d_bgr, 1, c->feat_prev))) return r;
     if ((r = rtvm_launch_orb(c, 0, 1))) return r;
     RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
@@ -373,6 +376,7 @@ int queue_back_half(rtvm_ctx* c, int set, int sb, const uint8_t* const* ptrs, in
     rec.set = set;
     rec.sb = sb;
     rec.n = n;
+    rec.ahead = ahead;
     for (int j = 0; j < n; j++) rec.ptrs[j] = ptrs[j];
     RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
                 50.0, 0.3, ahead, c->d_snap);
@@ -401,6 +405,7 @@ int queue_batch_serial(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
     if (n < 1 || n > c->n_batch)
         RTVM_FAIL(c, RTVM_E_ARG, "batch of %d frames: reserve it first (rtvm_reserve_batch), at most %d", n,
                   RTVM_MAX_BATCH);
+    if (c->set_live[0]) RTVM_FAIL(c, RTVM_E_STATE, "slot set 0 holds a batch that was not released (rtvm_batch_release)");
     c->spec_tail = -1;
     if ((r = bind_batch(c, 0, ptrs, n, c->feat_prev))) return r;
     if ((r = queue_front_half(c, 0, n))) return r;
@@ -408,14 +413,20 @@ int queue_batch_serial(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
     return queue_back_half(c, 0, 0, ptrs, n, 0);
 }
 
-// One batch with detection + matching on the front stream, the RANSAC search and the RANSAC
-// polish on streams of their own.
-int queue_batch_overlapped(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
+// Detection + matching of a batch on the front stream, the RANSAC search and the RANSAC polish
+// on streams of their own, in the next slot set.  Returns the set; *ahead_out tells whether the
+// first frame was matched against the last frame queued before (not yet known to be accepted).
+int queue_detect(rtvm_ctx* c, const uint8_t* const* ptrs, int n, int* set_out, int* ahead_out) {
     int r;
     if (n < 1 || n > c->n_batch || n > c->n_set1)
         RTVM_FAIL(c, RTVM_E_ARG, "batch of %d frames: reserve it first (rtvm_reserve_batch), at most %d", n,
                   RTVM_MAX_BATCH);
-    const int set = c->set_next, sb = set * RTVM_MAX_BATCH;
+    int set = c->set_next;
+    for (int k = 0; k < RTVM_NSETS && c->set_live[set]; k++) set = (set + 1) % RTVM_NSETS;
+    if (c->set_live[set])
+        RTVM_FAIL(c, RTVM_E_STATE, "all %d slot sets hold batches that were not released (rtvm_batch_release)",
+                  RTVM_NSETS);
+    const int sb = set * RTVM_MAX_BATCH;
     const int ahead = c->spec_tail >= 0 ? 1 : 0;
     if (ahead) {
         // the batch that used this slot set before must have left it
@@ -443,13 +454,22 @@ int queue_batch_overlapped(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
         if ((r = rtvm_launch_ransac_refine(c, sb, n, 2.0))) return r;
         HIP_TRY(c, hipEventRecord(c->ev_front[set], c->stream_lm));
     }
-    HIP_TRY(c, hipStreamWaitEvent(c->stream_main, c->ev_front[set], 0));
-    c->set_owner[set] = c->seq + 1;
-    if ((r = queue_back_half(c, set, sb, ptrs, n, ahead))) return r;
-    HIP_TRY(c, hipEventRecord(c->ev_back[set], c->stream_main));
-    c->back_rec[set] = 1;
     c->spec_tail = sb + n - 1;
     c->set_next = (set + 1) % RTVM_NSETS;
+    *set_out = set;
+    *ahead_out = ahead;
+    return RTVM_OK;
+}
+
+// One batch: detection etc. on the side streams, then the canvas half on the main stream.
+int queue_batch_overlapped(rtvm_ctx* c, const uint8_t* const* ptrs, int n) {
+    int r, set = 0, ahead = 0;
+    if ((r = queue_detect(c, ptrs, n, &set, &ahead))) return r;
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_main, c->ev_front[set], 0));
+    c->set_owner[set] = c->seq + 1;
+    if ((r = queue_back_half(c, set, set * RTVM_MAX_BATCH, ptrs, n, ahead))) return r;
+    HIP_TRY(c, hipEventRecord(c->ev_back[set], c->stream_main));
+    c->back_rec[set] = 1;
     return RTVM_OK;
 }
 
@@ -542,11 +562,20 @@ extern "C" int rtvm_batch_status_of(rtvm_ctx* c, long ticket, int* n_done, int* 
     }
     if (rep->abort || !rep->tail_ok) {
         // Frames were left pending, or the last frame did not advance the state: whatever
-        // was queued after this batch is pending as a whole.  Drain it; the caller now
-        // knows, and what it submits next is matched against the last accepted frame.
+        // canvas half was queued after this batch is pending as a whole.  Drain it; the
+        // caller now knows.
         HIP_TRY(c, hipStreamSynchronize(c->stream_main));
         HIP_TRY(c, hipMemsetAsync(&c->d_state->abort, 0, sizeof(int), c->stream_main));
-        c->spec_tail = -1;
+        // After a skipped frame the frames detected behind it were matched against the wrong
+        // frame: what is detected next is matched against the last accepted frame.  A
+        // mispredicted mask leaves the detection results intact; a caller that keeps detected
+        // batches (rtvm_batch_detect) goes on from them, any other is expected to submit the
+        // pending frames again, which are then matched against the last accepted frame too.
+        bool live = false;
+        for (int k = 0; k < RTVM_NSETS; k++) live |= c->set_live[k] != 0;
+        if (!live || rep->abort == 2 || rep->reason == RTVM_PENDING_SKIPPED_FRAME ||
+            (rep->n_done > 0 && !rep->tail_ok))
+            c->spec_tail = -1;
     }
     return RTVM_OK;
 }
@@ -576,15 +605,45 @@ extern "C" int rtvm_batch_retry(rtvm_ctx* c, long ticket, int first, int count) 
     if (first < 0 || count < 1 || first + count > rec.n)
         RTVM_FAIL(c, RTVM_E_ARG, "batch_retry: frames %d..%d of a batch of %d", first, first + count - 1, rec.n);
     HIP_TRY(c, hipSetDevice(c->device));
-    // The frame before `first` is the last one that advanced the state (the glue checks it):
-    // frame first-1 of this batch, or the last frame of the batch before it.
-    int r = queue_back_half(c, rec.set, rec.sb + first, rec.ptrs + first, count, 1);
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_main, c->ev_front[rec.set], 0));  // detection .. RANSAC of the batch
+    // The frame before `first` must be the last one that advanced the state (the glue checks
+    // it), unless the batch's first frame was matched against feat_prev.
+    int r = queue_back_half(c, rec.set, rec.sb + first, rec.ptrs + first, count, first == 0 ? rec.ahead : 1);
     if (r) return r;
     // whoever refills this slot set waits for the retry as well
     HIP_TRY(c, hipEventRecord(c->ev_back[rec.set], c->stream_main));
     c->back_rec[rec.set] = 1;
-    // a batch queued next is matched against the last frame of this one
-    c->spec_tail = rec.sb + first + count - 1;
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_batch_detect(rtvm_ctx* c, const uint8_t* const* bgr_dev, int n) {
+    if (!c) return RTVM_E_ARG;
+    if (!bgr_dev) RTVM_FAIL(c, RTVM_E_ARG, "batch_detect: null argument");
+    int r = need_stream_ctx(c, "batch_detect");
+    if (r) return r;
+    if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "batch_detect: call rtvm_stream_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int set = 0, ahead = 0;
+    if ((r = queue_detect(c, bgr_dev, n, &set, &ahead))) return r;
+    c->seq += 1;
+    BatchRecord& rec = c->recs[c->seq % RTVM_RECORDS];
+    rec.ticket = c->seq;
+    rec.set = set;
+    rec.sb = set * RTVM_MAX_BATCH;
+    rec.n = n;
+    rec.ahead = ahead;
+    for (int j = 0; j < n; j++) rec.ptrs[j] = bgr_dev[j];
+    c->set_owner[set] = c->seq;
+    c->set_live[set] = 1;
+    // no canvas half, no report: the event of this ticket's report slot is simply due now
+    HIP_TRY(c, hipEventRecord(c->ev_done[c->seq % RTVM_REPORTS], c->stream_main));
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_batch_release(rtvm_ctx* c, long ticket) {
+    if (!c) return RTVM_E_ARG;
+    for (int k = 0; k < RTVM_NSETS; k++)
+        if (c->set_owner[k] == ticket) c->set_live[k] = 0;
     return RTVM_OK;
 }
 

@@ -306,3 +306,34 @@ def test_batch_retry_queues_only_the_canvas_half_again():
     with pytest.raises(RuntimeError):
         ctx.batch_retry(t1, 3, 2)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_detection_queued_ahead_of_the_canvas_half():
+    """rtvm_batch_detect / rtvm_batch_retry / rtvm_batch_release: four batches detected ahead, their
+    canvas halves queued afterwards in frame order; a fifth detection needs a released slot set."""
+    import torch
+    frames, _ = video(13, seed=12)
+    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=500)
+    om = OracleMosaic(frames[0], nfeatures=500, glue="explicit")
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+    ctx.reserve_batch(3)
+    ctx.stream_begin(dev[0].data_ptr(), om.w_offset, om.h_offset)
+    tickets = [ctx.batch_detect([d.data_ptr() for d in dev[1 + 3 * b:4 + 3 * b]]) for b in range(4)]
+    with pytest.raises(RuntimeError):
+        ctx.batch_detect([dev[1].data_ptr()])
+    for t in tickets:
+        bt = ctx.batch_retry(t, 0, 3)
+        done, reason, st, nm, nk = ctx.batch_status_of(bt, 3)
+        assert done == 3 and reason == 0 and st.tolist() == [0, 0, 0] and (nm > 20).all()
+        ctx.batch_release(t)
+    for f in frames[1:13]:
+        om.process_frame(f)
+    st, nk, nm, H = ctx.frame_status()
+    assert np.array_equal(H, om.H)
+    assert np.array_equal(ctx.canvas_read(), om.canvas)
+    # released: detection can go on, and the plain batch call still works after it
+    t = ctx.batch_detect([dev[1].data_ptr()])
+    ctx.batch_release(t)
+    ctx.close()
