@@ -186,24 +186,29 @@ void gauss31(float* k) {
 }  // namespace
 
 // main.py:897-898: cv2.GaussianBlur(w.astype(float32), (31,31), 0), separable,
-// BORDER_REFLECT_101, float32 accumulation.  Row pass: taps added left to right;
-// column pass: centre tap, then symmetric pairs outwards (the order of OpenCV's
-// generic row filter and symmetric column filter).
-extern "C" void rtvm_oracle_gaussian_blur31(const float* src, int h, int w, float* dst) {
+// BORDER_REFLECT_101, float32 accumulation with fused multiply-adds, as OpenCV's
+// vector filters run on a CPU with FMA3 (its AVX2 code path): the generic row filter
+// s = k0*x0, then s = fma(x_i, k_i, s) left to right; the symmetric column filter
+// s = k15*r0, then s = fma(r[+i] + r[-i], k[15+i], s) outwards.
+// One clone of the function is compiled for FMA3 hardware; the other calls libm's fmaf,
+// which gives the same correctly rounded result.
+extern "C" __attribute__((target_clones("fma", "default"))) void rtvm_oracle_gaussian_blur31(const float* src, int h,
+                                                                                              int w, float* dst) {
     float k[31];
     gauss31(k);
     std::vector<float> rows((size_t)h * w);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             float s = k[0] * src[(size_t)y * w + reflect101(x - 15, w)];
-            for (int i = 1; i < 31; i++) s += k[i] * src[(size_t)y * w + reflect101(x - 15 + i, w)];
+            for (int i = 1; i < 31; i++) s = __builtin_fmaf(src[(size_t)y * w + reflect101(x - 15 + i, w)], k[i], s);
             rows[(size_t)y * w + x] = s;
         }
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             float s = k[15] * rows[(size_t)y * w + x];
             for (int i = 1; i <= 15; i++)
-                s += k[15 + i] * (rows[(size_t)reflect101(y + i, h) * w + x] + rows[(size_t)reflect101(y - i, h) * w + x]);
+                s = __builtin_fmaf(rows[(size_t)reflect101(y + i, h) * w + x] + rows[(size_t)reflect101(y - i, h) * w + x],
+                                   k[15 + i], s);
             dst[(size_t)y * w + x] = s;
         }
 }

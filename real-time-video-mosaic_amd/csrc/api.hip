@@ -137,7 +137,7 @@ struct SidePlanes {
 
 static void carve_side(const rtvm_ctx* c, Carver& k, SideDev& sd, SidePlanes p[2]) {
     const size_t n_px = (size_t)c->ch * c->cw;
-    sd.warped = k.take<uint8_t>(n_px * 3);
+    sd.warped = k.take<uint32_t>(n_px);
     sd.mask_new = k.take<uint8_t>(n_px);
     for (int kind = 0; kind < 2; kind++) {
         p[kind].S = k.take<uint16_t>(n_px + 64);
@@ -150,8 +150,7 @@ static void carve_side(const rtvm_ctx* c, Carver& k, SideDev& sd, SidePlanes p[2
     }
     sd.dist_new = p[0].dist;
     sd.dist_old = p[1].dist;
-    sd.rbn = k.take<float>(n_px);
-    sd.rbo = k.take<float>(n_px);
+    sd.rb = k.take<f32x2>(n_px);
 }
 
 void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int side, int kind, int pitch, int h, int w) {
@@ -606,7 +605,7 @@ extern "C" int rtvm_warp_perspective(rtvm_ctx* c, const uint8_t* bgr, const doub
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
     if ((r = upload_H(c, H))) return r;
-    if ((r = rtvm_launch_warp_only(c, c->d_bgr, c->d_H, c->h_side[0].warped))) return r;
+    if ((r = rtvm_launch_warp_only(c, c->d_bgr, c->d_H, (uint8_t*)c->h_side[0].warped))) return r;
     HIP_TRY(c, hipMemcpyAsync(out, c->h_side[0].warped, (size_t)c->ch * c->cw * 3, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RTVM_OK;

@@ -102,17 +102,62 @@ struct DtJob {
     int wpitch, znch, zg, zpitch, cpitch;
 };
 
+// A pointer read from a structure in memory is a generic pointer to the compiler (flat loads,
+// 64-bit address arithmetic per lane); every such pointer of this library is device memory:
+// as_global says so (global loads, scalar base + lane offset).
+template <class T>
+using gptr = __attribute__((address_space(1))) T*;
+template <class T>
+__device__ __forceinline__ gptr<T> as_global(T* p) {
+    return (gptr<T>)p;
+}
+
+// 16-byte accesses through a device-memory pointer (HIP's uint4 is a class whose members want
+// generic pointers).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ uint4 load_u4(gptr<T> p) {
+    const u32x4 v = *reinterpret_cast<gptr<const u32x4>>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <class T>
+__device__ __forceinline__ void store_u4(gptr<T> p, const uint4& v) {
+    *reinterpret_cast<gptr<u32x4>>(p) = u32x4{v.x, v.y, v.z, v.w};
+}
+
+// DtJob as the kernels use it: the same fields, the pointers typed as device memory.
+struct DtJobG {
+    gptr<const uint8_t> mask;
+    int pitch;
+    int x0, y0, x1, y1;
+    int ox0, oy0, ox1, oy1;
+    gptr<uint16_t> S;
+    gptr<uint32_t> R;
+    gptr<float> dist;
+    gptr<uint32_t> B, Z, Z16, CS;
+    int wpitch, znch, zg, zpitch, cpitch;
+    __device__ explicit DtJobG(const DtJob& j)
+        : mask(as_global(j.mask)), pitch(j.pitch), x0(j.x0), y0(j.y0), x1(j.x1), y1(j.y1), ox0(j.ox0), oy0(j.oy0),
+          ox1(j.ox1), oy1(j.oy1), S(as_global(j.S)), R(as_global(j.R)), dist(as_global(j.dist)), B(as_global(j.B)),
+          Z(as_global(j.Z)), Z16(as_global(j.Z16)), CS(as_global(j.CS)), wpitch(j.wpitch), znch(j.znch), zg(j.zg),
+          zpitch(j.zpitch), cpitch(j.cpitch) {}
+};
+
+// Two floats handled as one packed operand (v_pk_fma_f32 and friends).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // The planes one frame of a batch is warped into and measured on, besides the canvas.
 // Every frame of a batch has its own set, so that the warps and the distance transforms
 // of a whole batch run as single launches.
 struct SideDev {
-    uint8_t* warped;     // ch*cw*3: the frame in canvas coordinates (ROI only)
-    uint8_t* mask_new;   // ch*cw: warped pixel has a non-zero channel
+    uint32_t* warped;    // ch*cw words: the frame in canvas coordinates (ROI only), per pixel B, G, R
+                         // and the mask byte (255 when a channel is non-zero)
+    uint8_t* mask_new;   // ch*cw: a mask plane for the stage entry points (the batch kernels use the
+                         // mask byte of `warped`)
     float* dist_new;     // distance transform of mask_new; after the blur: blend weight of the frame
     float* dist_old;     // distance transform of the canvas mask as it is before this frame; after
                          // the blur: blend weight of the canvas
-    float* rbn;          // row-blurred weights
-    float* rbo;
+    f32x2* rb;           // row-blurred blend weights, {of the frame, of the canvas} per pixel
 };
 
 // Per-frame warp parameters, written on the device by k_warp_prep.

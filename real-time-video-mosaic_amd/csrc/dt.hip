@@ -61,16 +61,16 @@ __device__ __forceinline__ uint32_t zero_nibble(uint32_t v) {
 // One lane per 32 pixels of a row of the rectangle: bit i of word w of row y is set iff
 // pixel (32 w + i, y) lies inside the rectangle and is zero.
 __global__ __launch_bounds__(256) void k_dt_bits(const DtJob* __restrict__ jobs, int n_first, int second) {
-    const DtJob jb = jobs[job_index(blockIdx.z, n_first, second)];
+    const DtJobG jb(jobs[job_index(blockIdx.z, n_first, second)]);
     const int w0 = jb.x0 >> 5;
     const int w = w0 + blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = jb.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (y >= jb.y1 || w * 32 >= jb.x1) return;
     const int xa = w * 32;
-    const uint8_t* __restrict__ row = jb.mask + (size_t)y * jb.pitch;
+    const auto row = jb.mask + (size_t)y * jb.pitch;
     uint32_t bits = 0;
-    if (xa + 32 <= jb.pitch && ((reinterpret_cast<uintptr_t>(row + xa) & 3) == 0)) {
-        const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(row + xa);
+    if (xa + 32 <= jb.pitch && (((uintptr_t)(row + xa) & 3) == 0)) {
+        const auto p = reinterpret_cast<gptr<const uint32_t>>(row + xa);
         uint32_t v[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] = p[i];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_dt_bits(const DtJob* __restrict__ jobs,
 struct LineGeom {
     int W, H, nlines, nch;
 };
-__device__ __forceinline__ LineGeom line_geom(const DtJob& jb) {
+__device__ __forceinline__ LineGeom line_geom(const DtJobG& jb) {
     LineGeom g;
     g.W = jb.x1 - jb.x0;
     g.H = jb.y1 - jb.y0;
@@ -107,7 +107,7 @@ __device__ __forceinline__ LineGeom line_geom(const DtJob& jb) {
 // Each half-wave does one such block: lane r loads its window (two words), 32 ballots
 // transpose it.
 __global__ __launch_bounds__(1024) void k_dt_diag_a(const DtJob* __restrict__ jobs, int n_first, int second) {
-    const DtJob jb = jobs[job_index(blockIdx.z >> 1, n_first, second)];
+    const DtJobG jb(jobs[job_index(blockIdx.z >> 1, n_first, second)]);
     const int orient = blockIdx.z & 1;
     const LineGeom g = line_geom(jb);
     if (g.W <= 0 || g.H <= 0 || (int)blockIdx.x * 64 >= g.nlines || (int)blockIdx.y * GR >= g.nch) return;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void k_dt_diag_a(const DtJob* __restrict__ jo
         uint32_t w = 0;
         if (y < jb.y1) {
             const int wi = xstart >> 5, sh = xstart & 31, nw = jb.wpitch - 2;
-            const uint32_t* __restrict__ rowp = jb.B + (size_t)y * jb.wpitch;
+            const auto rowp = jb.B + (size_t)y * jb.wpitch;
             const uint32_t lo = (wi >= 0 && wi < nw) ? rowp[wi] : 0u;
             const uint32_t hi = (wi + 1 >= 0 && wi + 1 < nw) ? rowp[wi + 1] : 0u;
             w = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> sh);
@@ -157,10 +157,10 @@ __global__ __launch_bounds__(1024) void k_dt_diag_a(const DtJob* __restrict__ jo
 // Steps to the nearest zero along one line for the 32 rows of chunk c, written into the
 // LDS tile (first == true) or combined with what the other orientation left there.
 template <bool FIRST>
-__device__ __forceinline__ void diag_steps(const DtJob& jb, const LineGeom& g, int orient, int c, int line, int col0,
+__device__ __forceinline__ void diag_steps(const DtJobG& jb, const LineGeom& g, int orient, int c, int line, int col0,
                                            int dcol, uint16_t (*T)[TW]) {
-    const uint32_t* __restrict__ Z = jb.Z + (size_t)orient * jb.znch * jb.zpitch + line;
-    const uint32_t* __restrict__ Z16 = jb.Z16 + (size_t)orient * jb.zg * jb.zpitch + line;
+    const auto Z = jb.Z + (size_t)orient * jb.znch * jb.zpitch + line;
+    const auto Z16 = jb.Z16 + (size_t)orient * jb.zg * jb.zpitch + line;
     const uint32_t z = Z[(size_t)c * jb.zpitch];
     // nearest chunk with a zero above / below this one
     const int gi = c / GR, ci = c % GR, ng = (g.nch + GR - 1) / GR;
@@ -216,7 +216,7 @@ __device__ __forceinline__ void diag_steps(const DtJob& jb, const LineGeom& g, i
 // rows of a tile are 16-byte aligned when the pitch is a multiple of 8).  Tiles that touch
 // neither the rows nor the columns of the output window are never read and are skipped.
 __global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ jobs, int n_first, int second) {
-    const DtJob jb = jobs[job_index(blockIdx.z, n_first, second)];
+    const DtJobG jb(jobs[job_index(blockIdx.z, n_first, second)]);
     const LineGeom g = line_geom(jb);
     const int c = blockIdx.y;
     const int X = ((jb.x0 / TW) + (int)blockIdx.x) * TW;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ job
             const int r = e / (TW / 8), q = e % (TW / 8);
             const int x = X + q * 8;
             if (x + 8 <= jb.x0 || x >= jb.x1) continue;
-            *reinterpret_cast<uint4*>(jb.S + (size_t)(ya + r) * jb.pitch + x) = *reinterpret_cast<const uint4*>(&T[r][q * 8]);
+            store_u4(jb.S + (size_t)(ya + r) * jb.pitch + x, *reinterpret_cast<const uint4*>(&T[r][q * 8]));
         }
     } else {
         for (int e = i; e < nrows * TW; e += 320) {
@@ -305,10 +305,10 @@ __device__ __forceinline__ uint32_t wg_suffix_min_excl(uint32_t v, uint32_t* s_w
 }
 
 // E of the 8 pixels starting at x (8-aligned relative to the plane when the pitch allows)
-__device__ __forceinline__ void load_e8(const DtJob& jb, size_t row, int x, uint32_t* E) {
+__device__ __forceinline__ void load_e8(const DtJobG& jb, size_t row, int x, uint32_t* E) {
     uint16_t s[8];
     if ((jb.pitch & 7) == 0 && x >= 0 && x + 8 <= jb.pitch) {
-        const uint4 v = *reinterpret_cast<const uint4*>(jb.S + row + x);
+        const uint4 v = load_u4(jb.S + row + x);
         s[0] = v.x & 0xFFFF, s[1] = v.x >> 16, s[2] = v.y & 0xFFFF, s[3] = v.y >> 16;
         s[4] = v.z & 0xFFFF, s[5] = v.z >> 16, s[6] = v.w & 0xFFFF, s[7] = v.w >> 16;
     } else {
@@ -319,7 +319,7 @@ __device__ __forceinline__ void load_e8(const DtJob& jb, size_t row, int x, uint
     for (int i = 0; i < 8; i++) E[i] = (x + i >= jb.x0 && x + i < jb.x1) ? e_of(s[i]) : INF32;
 }
 
-__device__ void dt_row(const DtJob& jb, int y, uint32_t* s_w) {
+__device__ void dt_row(const DtJobG& jb, int y, uint32_t* s_w) {
     const int xo = jb.x0 & ~7;                          // origin of the relative coordinate
     const int span = jb.x1 - xo;
     const int P = (span + 2047) / 2048;                 // passes
@@ -360,9 +360,9 @@ __device__ void dt_row(const DtJob& jb, int y, uint32_t* s_w) {
         }
         if (xr < span && x + 8 > jb.ox0 && x < jb.ox1) {
             if ((jb.pitch & 3) == 0 && x >= jb.ox0 && x + 8 <= jb.ox1) {
-                uint4* o = reinterpret_cast<uint4*>(jb.R + row + x);
-                o[0] = make_uint4(F[0], F[1], F[2], F[3]);
-                o[1] = make_uint4(F[4], F[5], F[6], F[7]);
+                const auto o = jb.R + row + x;
+                store_u4(o, make_uint4(F[0], F[1], F[2], F[3]));
+                store_u4(o + 4, make_uint4(F[4], F[5], F[6], F[7]));
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; i++)
@@ -375,8 +375,8 @@ __device__ void dt_row(const DtJob& jb, int y, uint32_t* s_w) {
 }
 
 // The 8 step values starting at x as four words (0xFFFF outside the rectangle).
-__device__ __forceinline__ uint4 load_s8(const DtJob& jb, size_t row, int x) {
-    if ((jb.pitch & 7) == 0 && x >= 0 && x + 8 <= jb.pitch) return *reinterpret_cast<const uint4*>(jb.S + row + x);
+__device__ __forceinline__ uint4 load_s8(const DtJobG& jb, size_t row, int x) {
+    if ((jb.pitch & 7) == 0 && x >= 0 && x + 8 <= jb.pitch) return load_u4(jb.S + row + x);
     uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     for (int i = 0; i < 8; i++)
         if (x + i >= jb.x0 && x + i < jb.x1) {
@@ -385,7 +385,7 @@ __device__ __forceinline__ uint4 load_s8(const DtJob& jb, size_t row, int x) {
         }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
-__device__ __forceinline__ uint32_t e_of_s8(const DtJob& jb, const uint4& sv, int x, int i) {
+__device__ __forceinline__ uint32_t e_of_s8(const DtJobG& jb, const uint4& sv, int x, int i) {
     const uint32_t w = i < 2 ? sv.x : i < 4 ? sv.y : i < 6 ? sv.z : sv.w;
     const uint32_t sx = (i & 1) ? w >> 16 : w & 0xFFFFu;
     return (x + i >= jb.x0 && x + i < jb.x1) ? e_of(sx) : INF32;
@@ -397,7 +397,7 @@ __device__ __forceinline__ uint32_t e_of_s8(const DtJob& jb, const uint4& sv, in
 // the passes that hold pixels of the output window are then loaded again and finished.
 // One workgroup per row of the output window; blockIdx.y = job.
 __global__ __launch_bounds__(256) void k_dt_rows_wide(const DtJob* __restrict__ jobs, int n_first, int second) {
-    const DtJob jb = jobs[job_index(blockIdx.y, n_first, second)];
+    const DtJobG jb(jobs[job_index(blockIdx.y, n_first, second)]);
     const int W = jb.x1 - jb.x0, H = jb.y1 - jb.y0;
     const int y = jb.oy0 + blockIdx.x;
     if (W <= 0 || H <= 0 || y >= jb.oy1) return;
@@ -474,9 +474,9 @@ __global__ __launch_bounds__(256) void k_dt_rows_wide(const DtJob* __restrict__ 
                 F[i] = v > DT_MAX ? DT_MAX : v;
             }
             if ((jb.pitch & 3) == 0 && x >= jb.ox0 && x + 8 <= jb.ox1) {
-                uint4* o = reinterpret_cast<uint4*>(jb.R + row + x);
-                o[0] = make_uint4(F[0], F[1], F[2], F[3]);
-                o[1] = make_uint4(F[4], F[5], F[6], F[7]);
+                const auto o = jb.R + row + x;
+                store_u4(o, make_uint4(F[0], F[1], F[2], F[3]));
+                store_u4(o + 4, make_uint4(F[4], F[5], F[6], F[7]));
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; i++)
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_dt_rows_wide(const DtJob* __restrict__ 
 }
 
 // E of the 32 rows of a chunk of column x (INF below the rectangle)
-__device__ __forceinline__ void load_chunk_e(const DtJob& jb, int x, int ya, uint32_t* E) {
+__device__ __forceinline__ void load_chunk_e(const DtJobG& jb, int x, int ya, uint32_t* E) {
     uint16_t s[CH];
 #pragma unroll
     for (int r = 0; r < CH; r++) {
@@ -500,7 +500,7 @@ __device__ __forceinline__ void load_chunk_e(const DtJob& jb, int x, int ya, uin
 
 // Per (column, chunk): fe = value at the chunk's last row from the chunk's own pixels
 // (going down), be = value at its first row (going up).  Only columns of the output window.
-__device__ void dt_col_summary(const DtJob& jb, int x, int c) {
+__device__ void dt_col_summary(const DtJobG& jb, int x, int c) {
     uint32_t E[CH];
     load_chunk_e(jb, x, jb.y0 + c * CH, E);
     uint32_t fe = INF32, be = INF32;
@@ -517,7 +517,7 @@ __device__ void dt_col_summary(const DtJob& jb, int x, int c) {
 // each; the others take 64 columns x 4 chunks of the column summaries.
 __global__ __launch_bounds__(256) void k_dt_scan(const DtJob* __restrict__ jobs, int n_first, int second, int nrow_blocks,
                                                  int ncol_x) {
-    const DtJob jb = jobs[job_index(blockIdx.y, n_first, second)];
+    const DtJobG jb(jobs[job_index(blockIdx.y, n_first, second)]);
     const int W = jb.x1 - jb.x0, H = jb.y1 - jb.y0;
     if (W <= 0 || H <= 0) return;
     __shared__ uint32_t s_w[4];
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void k_dt_scan(const DtJob* __restrict__ jobs,
 // Final column scan of the chunks that intersect the output window, in registers;
 // d = min(column scan, row scan), clamped to DIST_MAX, as float / 65536.
 __global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs, int n_first, int second) {
-    const DtJob jb = jobs[job_index(blockIdx.z, n_first, second)];
+    const DtJobG jb(jobs[job_index(blockIdx.z, n_first, second)]);
     const int H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
     const int x = jb.ox0 + blockIdx.x * 64 + threadIdx.x;
     const int c = (jb.oy0 - jb.y0) / CH + blockIdx.y;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs, 
     // at the last row from below (chunk k's summary travels 32*|c-k| - 31 rows)
     uint32_t cf = INF32, cb = INF32;
     {
-        const uint32_t* __restrict__ fe = jb.CS + x;
+        const auto fe = jb.CS + x;
         int k = 0;
         for (; k + 4 <= c; k += 4) {
             uint32_t v[4];
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs, 
             for (int u = 0; u < 4; u++) cf = min(cf, sat_add(v[u], DT_A * (uint32_t)(CH * (c - k - u) - (CH - 1))));
         }
         for (; k < c; k++) cf = min(cf, sat_add(fe[(size_t)k * jb.cpitch], DT_A * (uint32_t)(CH * (c - k) - (CH - 1))));
-        const uint32_t* __restrict__ be = jb.CS + plane + x;
+        const auto be = jb.CS + plane + x;
         k = c + 1;
         for (; k + 4 <= nch; k += 4) {
             uint32_t v[4];

@@ -15,10 +15,13 @@
 
 namespace {
 
+// BORDER_REFLECT_101 index, without a loop: fold |p| into one period 2n-2 of the mirror.
 __device__ __forceinline__ int reflect101(int p, int n) {
     if (n == 1) return 0;
-    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
-    return p;
+    const int period = 2 * n - 2;
+    p = p < 0 ? -p : p;
+    if (p >= period) p %= period;
+    return p < n ? p : period - p;
 }
 
 // One thread per frame (blockIdx.x = index in the batch): M = H^-1 (cv::invert's 3x3
@@ -156,12 +159,13 @@ __device__ __forceinline__ void taps4(const uint8_t* __restrict__ src, int fh, i
 
 // cv2.warpPerspective(frame, H, (cw, ch), INTER_LINEAR), BORDER_CONSTANT 0, for the
 // pixels of the region of interest.  FIXED: 1/32-pixel fixed point (OpenCV <= 4.10),
-// else float32 (OpenCV >= 4.11).  Also writes mask_new = any channel > 0.
+// else float32 (OpenCV >= 4.11).  Output: 3 bytes per pixel into out3, or, for the frames of
+// a batch, one word per pixel into out4: B, G, R and the mask byte (any channel > 0).
 // One tile of 64 x 4 canvas pixels at (bx, by), bx a multiple of 64.
 template <bool FIXED>
 __device__ __forceinline__ void warp_tile(const uint8_t* __restrict__ src, const WarpParams* __restrict__ wp,
-                                          uint8_t* __restrict__ out, uint8_t* __restrict__ mask_new,
-                                          const DtJob* __restrict__ job_new, int fh, int fw, int cw, int bx, int by) {
+                                          gptr<uint8_t> out3, gptr<uint32_t> out4, const DtJob* __restrict__ job_new,
+                                          int fh, int fw, int cw, int bx, int by) {
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
     const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
     if (y < ry0 || y >= ry1) return;  // a wave is 64 pixels of one row
@@ -221,16 +225,19 @@ __device__ __forceinline__ void warp_tile(const uint8_t* __restrict__ src, const
     const bool zero = (v[0] | v[1] | v[2]) == 0;
     if (inroi) {
         const size_t p = (size_t)y * cw + x;
-        out[3 * p] = (uint8_t)v[0];
-        out[3 * p + 1] = (uint8_t)v[1];
-        out[3 * p + 2] = (uint8_t)v[2];
-        if (mask_new) mask_new[p] = zero ? 0 : 255;
+        if (out4) {  // the pixel and its mask byte (main.py:878-879) in one word
+            out4[p] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | (zero ? 0u : 0xFF000000u);
+        } else {
+            out3[3 * p] = (uint8_t)v[0];
+            out3[3 * p + 1] = (uint8_t)v[1];
+            out3[3 * p + 2] = (uint8_t)v[2];
+        }
     }
     if (job_new) {
         // zero bit rows of the new mask for the distance transform (zero pixels of the ROI)
         const unsigned long long bal = __ballot(inroi && zero);
         if ((threadIdx.x & 63) == 0) {
-            uint32_t* B = job_new->B + (size_t)y * job_new->wpitch + (bx >> 5);
+            const auto B = as_global(job_new->B) + (size_t)y * job_new->wpitch + (bx >> 5);
             B[0] = (uint32_t)bal;
             B[1] = (uint32_t)(bal >> 32);
         }
@@ -238,7 +245,7 @@ __device__ __forceinline__ void warp_tile(const uint8_t* __restrict__ src, const
 }
 
 // blockIdx.z = frame of the batch: source srcs.p[z], parameters wp[z], output planes
-// sides[z] (or `out_only`, without mask, for the stage entry point), bit rows of jobs_new[z].
+// sides[z] (or `out_only`, 3 bytes per pixel, for the stage entry point), bit rows of jobs_new[z].
 // The grid is sized for a region of interest of about the frame's size and walks the
 // tiles of the actual one (tile (0,0) holds the ROI's first pixel).
 template <bool FIXED>
@@ -247,8 +254,8 @@ __global__ __launch_bounds__(256) void k_warp(BatchPtrs srcs, const WarpParams* 
                                               const DtJob* __restrict__ jobs_new, int fh, int fw, int ch, int cw) {
     const uint8_t* __restrict__ src = srcs.p[blockIdx.z];
     const WarpParams* __restrict__ wp = wps + blockIdx.z;
-    uint8_t* __restrict__ out = out_only ? out_only : sides[blockIdx.z].warped;
-    uint8_t* __restrict__ mask_new = out_only ? nullptr : sides[blockIdx.z].mask_new;
+    const gptr<uint8_t> out3 = as_global(out_only);
+    const gptr<uint32_t> out4 = out_only ? nullptr : as_global(sides[blockIdx.z].warped);
     const DtJob* __restrict__ job_new = jobs_new ? jobs_new + blockIdx.z : nullptr;
     const int rx1 = wp->rx1, ry1 = wp->ry1;
     const int ox = wp->rx0 & ~63, oy = wp->ry0 & ~3;
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256) void k_warp(BatchPtrs srcs, const WarpParams* 
     for (int by = oy + 4 * (int)blockIdx.y; by < ry1; by += 4 * (int)gridDim.y)
 #pragma unroll 1
         for (int bx = ox + 64 * (int)blockIdx.x; bx < rx1; bx += 64 * (int)gridDim.x)
-            warp_tile<FIXED>(src, wp, out, mask_new, job_new, fh, fw, cw, bx, by);
+            warp_tile<FIXED>(src, wp, out3, out4, job_new, fh, fw, cw, bx, by);
 }
 
 // The canvas mask each frame of a batch will meet, as zero bit rows, assuming that a pixel
@@ -286,16 +293,16 @@ __global__ __launch_bounds__(256) void k_pred_bits(const uint32_t* __restrict__ 
 
 // weight_new = dn / (dn + do + 1e-6), weight_old = do / (...)  (main.py:892-894),
 // evaluated while staging, then the row pass of cv2.GaussianBlur(w, (31,31), 0)
-// (main.py:897-898) for both weights: 31 taps added left to right in float32,
-// BORDER_REFLECT_101 at the canvas edge.  dn is zero outside the ROI.  One wave =
-// 256 consecutive pixels of one row staged through LDS, 4 outputs per lane from a
-// window of 34 staged values; a workgroup takes 4 rows; blockIdx.z = frame of the batch.
+// (main.py:897-898) for both weights: s = k0*x0, then s = fma(x_i, k_i, s) left to right in
+// float32, BORDER_REFLECT_101 at the canvas edge.  dn is zero outside the ROI.  The two
+// weights of a pixel travel as one pair {new, old}, so every tap is one packed fma.  One
+// wave = 256 consecutive pixels of one row staged through LDS, 4 outputs per lane from a
+// window of 34 staged pairs; a workgroup takes 4 rows; blockIdx.z = frame of the batch.
 __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
-                                               const SideDev& side, int cw, int bx, int by, float (*s_n)[288],
-                                               float (*s_o)[288], float* s_k) {
+                                               const SideDev& side, int cw, int bx, int by, f32x2 (*s_w)[288]) {
     const int rx0 = wp->rx0, rx1 = wp->rx1, wy0 = wp->wy0, wy1 = wp->wy1;
-    const float* __restrict__ dn = side.dist_new;
-    const float* __restrict__ dold = side.dist_old;
+    const auto dn = as_global<const float>(side.dist_new);
+    const auto dold = as_global<const float>(side.dist_old);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int y = by + wv;
     const bool row_ok = y >= wy0 && y < wy1;
@@ -315,38 +322,37 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
                     wo = b / sum;
                 }
             }
-            s_n[wv][i] = wn;
-            s_o[wv][i] = wo;
+            s_w[wv][i] = f32x2{wn, wo};
         }
     }
-    if (threadIdx.x < 31) s_k[threadIdx.x] = gk[threadIdx.x];
     __syncthreads();
     if (!row_ok) return;
     const int x = bx + 4 * lane;
     if (x + 4 <= rx0 || x >= rx1) return;
-    float k[31];
+    f32x2 v[36];
 #pragma unroll
-    for (int i = 0; i < 31; i++) k[i] = s_k[i];
-    // one plane after the other: half the live registers, twice the resident waves
-#pragma unroll
-    for (int plane = 0; plane < 2; plane++) {
-        const float* __restrict__ sp = plane ? s_o[wv] : s_n[wv];
-        float* __restrict__ outp = plane ? side.rbo : side.rbn;
-        float v[36];
-#pragma unroll
-        for (int q = 0; q < 9; q++) {
-            const float4 a = *reinterpret_cast<const float4*>(&sp[4 * lane + 4 * q]);
-            v[4 * q] = a.x, v[4 * q + 1] = a.y, v[4 * q + 2] = a.z, v[4 * q + 3] = a.w;
-        }
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            if (x + o < rx0 || x + o >= rx1) continue;
-            float a = k[0] * v[o];
-#pragma unroll
-            for (int i = 1; i < 31; i++) a += k[i] * v[o + i];
-            outp[row + x + o] = a;
-        }
+    for (int q = 0; q < 18; q++) {
+        const float4 a = *reinterpret_cast<const float4*>(&s_w[wv][4 * lane + 2 * q]);
+        v[2 * q] = f32x2{a.x, a.y};
+        v[2 * q + 1] = f32x2{a.z, a.w};
     }
+    const auto outp = as_global(side.rb) + row + x;
+    // the four sums advance tap by tap side by side: no packed operation waits for the one before it
+    f32x2 a[4];
+    {
+        const float k0 = gk[0];
+#pragma unroll
+        for (int o = 0; o < 4; o++) a[o] = f32x2{k0, k0} * v[o];
+    }
+#pragma unroll
+    for (int i = 1; i < 31; i++) {
+        const float ki = gk[i];
+#pragma unroll
+        for (int o = 0; o < 4; o++) a[o] = __builtin_elementwise_fma(v[o + i], f32x2{ki, ki}, a[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+        if (x + o >= rx0 && x + o < rx1) outp[o] = a[o];
 }
 
 // blockIdx.z = frame of the batch.  Tiles of 256 x 4 pixels of the frame's region (rows of
@@ -359,13 +365,12 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
                                                    const SideDev* __restrict__ sides, int cw, int ex, int ey) {
     const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const SideDev side = sides[blockIdx.z];
-    __shared__ __align__(16) float s_n[4][288], s_o[4][288];
-    __shared__ float s_k[32];
+    __shared__ __align__(16) f32x2 s_w[4][288];
     const int rx1 = wp->rx1, wy1 = wp->wy1;
     const int ox = wp->rx0 & ~3, oy = wp->wy0;
     if (!REST) {
         const int bx = ox + 256 * (int)blockIdx.x, by = oy + 4 * (int)blockIdx.y;
-        if (bx < rx1 && by < wy1) blur_rows_tile(wp, gk, side, cw, bx, by, s_n, s_o, s_k);
+        if (bx < rx1 && by < wy1) blur_rows_tile(wp, gk, side, cw, bx, by, s_w);
         return;
     }
     const int ntx = rx1 > ox ? (rx1 - ox + 255) / 256 : 0, nty = wy1 > oy ? (wy1 - oy + 3) / 4 : 0;
@@ -373,16 +378,49 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
     for (int ty = blockIdx.y; ty < nty; ty += gridDim.y)
         for (int tx = blockIdx.x; tx < ntx; tx += gridDim.x) {
             if (tx < ex && ty < ey) continue;  // done by the one-tile-per-workgroup launch
-            blur_rows_tile(wp, gk, side, cw, ox + 256 * tx, oy + 4 * ty, s_n, s_o, s_k);
+            blur_rows_tile(wp, gk, side, cw, ox + 256 * tx, oy + 4 * ty, s_w);
             __syncthreads();  // the staging area is reused by the next tile
         }
 }
 
-// Column pass of the blur (centre tap, then symmetric pairs outwards) for the pixels of the
-// ROI the warped frame covers: the final blend weights of the frame and of the canvas
-// (main.py:897-898), stored over the distance planes.  A lane takes 4 consecutive rows of
-// one column: a window of 34 row-blurred weights serves the 4 column sums.  blockIdx.z =
-// frame of the batch.
+// Column pass of the blur (s = k15*r0, then s = fma(r[+t] + r[-t], k[15+t], s) outwards) for
+// the pixels of the ROI the warped frame covers: the final blend weights of the frame and of
+// the canvas (main.py:897-898), stored over the distance planes.  A lane takes 4 consecutive
+// rows of one column: a window of 34 row-blurred weight pairs serves the 4 column sums, both
+// weights in one packed operation.  blockIdx.z = frame of the batch.
+template <bool EDGE>
+__device__ __forceinline__ void blur_cols_window(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
+                                                 const SideDev& side, int ch, int cw, int x, int ya,
+                                                 const bool (&need)[4]) {
+    const auto rb = as_global<const f32x2>(side.rb);
+    const auto out_n = as_global(side.dist_new), out_o = as_global(side.dist_old);
+    f32x2 v[34];
+#pragma unroll
+    for (int j = 0; j < 34; j++) {
+        const int y = EDGE ? reflect101(ya - 15 + j, ch) : ya - 15 + j;
+        v[j] = rb[(size_t)y * cw + x];
+    }
+    f32x2 a[4];
+    {
+        const float k0 = gk[15];
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = f32x2{k0, k0} * v[15 + i];
+    }
+#pragma unroll
+    for (int t = 1; t <= 15; t++) {
+        const float kt = gk[15 + t];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            a[i] = __builtin_elementwise_fma(v[15 + i + t] + v[15 + i - t], f32x2{kt, kt}, a[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (need[i]) {
+            out_n[(size_t)(ya + i) * cw + x] = a[i].x;
+            out_o[(size_t)(ya + i) * cw + x] = a[i].y;
+        }
+}
+
 __device__ __forceinline__ void blur_cols_tile(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
                                                const SideDev& side, int ch, int cw, int bx, int by) {
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
@@ -392,30 +430,15 @@ __device__ __forceinline__ void blur_cols_tile(const WarpParams* __restrict__ wp
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int y = ya + i;
-        need[i] = y >= ry0 && y < ry1 && side.mask_new[(size_t)y * cw + x];
+        need[i] = y >= ry0 && y < ry1 && (as_global<const uint32_t>(side.warped)[(size_t)y * cw + x] >> 24);
         any |= need[i];
     }
     if (!any) return;
-    float k[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) k[i] = gk[15 + i];
-    // one plane after the other: half the live registers, twice the resident waves
-#pragma unroll
-    for (int plane = 0; plane < 2; plane++) {
-        const float* __restrict__ rb = plane ? side.rbo : side.rbn;
-        float* __restrict__ outp = plane ? side.dist_old : side.dist_new;
-        float v[34];
-#pragma unroll
-        for (int j = 0; j < 34; j++) v[j] = rb[(size_t)reflect101(ya - 15 + j, ch) * cw + x];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (!need[i]) continue;
-            float a = k[0] * v[15 + i];
-#pragma unroll
-            for (int t = 1; t <= 15; t++) a += k[t] * (v[15 + i + t] + v[15 + i - t]);
-            outp[(size_t)(ya + i) * cw + x] = a;
-        }
-    }
+    // only the tiles at the top and bottom of the canvas reflect rows (the same for the whole workgroup)
+    if (by - 15 >= 0 && by + 16 + 15 <= ch)
+        blur_cols_window<false>(wp, gk, side, ch, cw, x, ya, need);
+    else
+        blur_cols_window<true>(wp, gk, side, ch, cw, x, ya, need);
 }
 
 // blockIdx.z = frame of the batch.  Tiles of 64 x 16 pixels of the ROI; REST as in k_blur_rows.
@@ -491,26 +514,42 @@ __global__ __launch_bounds__(256) void k_commit(const WarpParams* __restrict__ w
         }
     }
     bool changed = REDO;
-    for (int j = 0; j <= last; j++) {
-        const WarpParams* __restrict__ wp = wps + j;
-        if (y < wp->ry0 || y >= wp->ry1 || bx >= wp->rx1 || bx + 64 <= wp->rx0) continue;  // wave-uniform
-        if (!oncanvas || x < wp->rx0 || x >= wp->rx1) continue;
-        const SideDev& side = sides[j];
-        if (!side.mask_new[p]) continue;
-        const int w0 = side.warped[3 * p], w1 = side.warped[3 * p + 1], w2 = side.warped[3 * p + 2];
-        changed = true;
-        if (!mo) {
-            c0 = w0, c1 = w1, c2 = w2;
-            mo = 255;
-        } else {
-            const float a = side.dist_new[p], b = side.dist_old[p];
-            c0 = (int)((float)c0 * b + (float)w0 * a) & 255;  // astype(uint8) truncates
-            c1 = (int)((float)c1 * b + (float)w1 * a) & 255;
-            c2 = (int)((float)c2 * b + (float)w2 * a) & 255;
-            mo = (c0 | c1 | c2) ? 255 : 0;
-            // two non-zero pixels blended to zero: the masks predicted for the later frames of
-            // the batch do not hold
-            if (!REDO && !mo) atomicMin(&st->bad_frame, j);
+    // four frames at a time: their pixels and weights are requested together, then blended in order
+    constexpr int G = 4;
+    for (int j0 = 0; j0 <= last; j0 += G) {
+        uint32_t px[G];
+        float wa[G], wb[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const int j = j0 + u;
+            px[u] = 0;
+            wa[u] = wb[u] = 0.f;
+            if (j > last) continue;
+            const WarpParams* __restrict__ wp = wps + j;
+            if (y < wp->ry0 || y >= wp->ry1 || bx >= wp->rx1 || bx + 64 <= wp->rx0) continue;  // wave-uniform
+            if (!oncanvas || x < wp->rx0 || x >= wp->rx1) continue;
+            px[u] = as_global<const uint32_t>(sides[j].warped)[p];
+            wa[u] = as_global<const float>(sides[j].dist_new)[p];
+            wb[u] = as_global<const float>(sides[j].dist_old)[p];
+        }
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            if (!(px[u] >> 24)) continue;  // outside the frame's mask (or its region)
+            const int w0 = px[u] & 255, w1 = (px[u] >> 8) & 255, w2 = (px[u] >> 16) & 255;
+            changed = true;
+            if (!mo) {
+                c0 = w0, c1 = w1, c2 = w2;
+                mo = 255;
+            } else {
+                const float a = wa[u], b = wb[u];
+                c0 = (int)((float)c0 * b + (float)w0 * a) & 255;  // astype(uint8) truncates
+                c1 = (int)((float)c1 * b + (float)w1 * a) & 255;
+                c2 = (int)((float)c2 * b + (float)w2 * a) & 255;
+                mo = (c0 | c1 | c2) ? 255 : 0;
+                // two non-zero pixels blended to zero: the masks predicted for the later frames of
+                // the batch do not hold
+                if (!REDO && !mo) atomicMin(&st->bad_frame, j0 + u);
+            }
         }
     }
     if (oncanvas && changed) {
