@@ -78,7 +78,8 @@ typedef struct rtvm_ctx rtvm_ctx;
 int rtvm_version(void);
 
 /* Replaces VideMosaic.__init__'s detector/matcher/canvas set-up (main.py:29-37, 80-81).
- * frame_h/frame_w: size of every frame of the stream; canvas_h/canvas_w: mosaic
+ * frame_h/frame_w: size of every frame of the stream (0 x 0 for a context that only
+ * matches or fits; otherwise at least 2 x 2); canvas_h/canvas_w: mosaic
  * canvas (main.py:80-81 computes int(oh*H) x int(ow*W)); nfeatures: ORB_create(n)
  * (main.py:36).  All device memory the context will ever use is allocated here. */
 int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w, int canvas_h, int canvas_w,

@@ -328,6 +328,8 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
     if (!out) return RTVM_E_ARG;
     *out = nullptr;
     if (frame_h < 0 || frame_w < 0 || canvas_h < 0 || canvas_w < 0 || nfeatures < 0) return RTVM_E_ARG;
+    // the warp reads the two taps of a row with one 8-byte load that must fit inside the frame
+    if ((frame_h > 0 || frame_w > 0) && (frame_h < 2 || frame_w < 2)) return RTVM_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
         return RTVM_E_HIP;

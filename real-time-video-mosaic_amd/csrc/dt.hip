@@ -515,7 +515,7 @@ __device__ void dt_col_summary(const DtJobG& jb, int x, int c) {
 
 // blockIdx.y = job.  The first `nrow_blocks` workgroups scan one row of the output window
 // each; the others take 64 columns x 4 chunks of the column summaries.
-__global__ __launch_bounds__(256) void k_dt_scan(const DtJob* __restrict__ jobs, int n_first, int second, int nrow_blocks,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dt_scan(const DtJob* __restrict__ jobs, int n_first, int second, int nrow_blocks,
                                                  int ncol_x) {
     const DtJobG jb(jobs[job_index(blockIdx.y, n_first, second)]);
     const int W = jb.x1 - jb.x0, H = jb.y1 - jb.y0;
@@ -534,6 +534,36 @@ __global__ __launch_bounds__(256) void k_dt_scan(const DtJob* __restrict__ jobs,
     dt_col_summary(jb, x, c);
 }
 
+// Scan over the chunks of a column, in place over the chunk summaries: plane 0 of CS becomes
+// what reaches each chunk's first row from the chunks above it, plane 1 what reaches its last
+// row from the chunks below (chunk k's summary travels 32*|c-k| - 31 rows to chunk c).
+// blockIdx.x = 64 columns of the output window, blockIdx.y = job, blockIdx.z = plane.
+__global__ __launch_bounds__(64) void k_dt_chunks(const DtJob* __restrict__ jobs, int n_first, int second) {
+    const DtJobG jb(jobs[job_index(blockIdx.y, n_first, second)]);
+    const int H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
+    const int x = jb.ox0 + blockIdx.x * 64 + threadIdx.x;
+    if (H <= 0 || x >= jb.ox1) return;
+    const bool down = blockIdx.z == 0;
+    const auto cs = jb.CS + (down ? 0 : (size_t)jb.znch * jb.cpitch) + x;
+    uint32_t run = INF32;
+    for (int i0 = 0; i0 < nch; i0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u, k = down ? i : nch - 1 - i;
+            v[u] = i < nch ? cs[(size_t)k * jb.cpitch] : INF32;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u, k = down ? i : nch - 1 - i;
+            if (i < nch) {
+                cs[(size_t)k * jb.cpitch] = run;
+                run = min(sat_add(run, DT_A * (uint32_t)CH), sat_add(v[u], DT_A));
+            }
+        }
+    }
+}
+
 // Final column scan of the chunks that intersect the output window, in registers;
 // d = min(column scan, row scan), clamped to DIST_MAX, as float / 65536.
 __global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs, int n_first, int second) {
@@ -544,38 +574,16 @@ __global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs, 
     if (H <= 0 || c >= nch || x >= jb.ox1) return;
     const int ya = jb.y0 + c * CH;
     if (ya >= jb.oy1) return;
-    const size_t plane = (size_t)jb.znch * jb.cpitch;
     uint32_t E[CH], F[CH], Rv[CH];
+    // values arriving from the other chunks of the column: at the first row from above,
+    // at the last row from below
+    const uint32_t cf = jb.CS[(size_t)c * jb.cpitch + x];
+    const uint32_t cb = jb.CS[((size_t)jb.znch + c) * jb.cpitch + x];
     load_chunk_e(jb, x, ya, E);
 #pragma unroll
     for (int r = 0; r < CH; r++) {
         const int y = ya + r;
         Rv[r] = (y >= jb.oy0 && y < jb.oy1) ? jb.R[(size_t)y * jb.pitch + x] : INF32;
-    }
-    // values arriving from the other chunks of the column: at the first row from above,
-    // at the last row from below (chunk k's summary travels 32*|c-k| - 31 rows)
-    uint32_t cf = INF32, cb = INF32;
-    {
-        const auto fe = jb.CS + x;
-        int k = 0;
-        for (; k + 4 <= c; k += 4) {
-            uint32_t v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = fe[(size_t)(k + u) * jb.cpitch];
-#pragma unroll
-            for (int u = 0; u < 4; u++) cf = min(cf, sat_add(v[u], DT_A * (uint32_t)(CH * (c - k - u) - (CH - 1))));
-        }
-        for (; k < c; k++) cf = min(cf, sat_add(fe[(size_t)k * jb.cpitch], DT_A * (uint32_t)(CH * (c - k) - (CH - 1))));
-        const auto be = jb.CS + plane + x;
-        k = c + 1;
-        for (; k + 4 <= nch; k += 4) {
-            uint32_t v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = be[(size_t)(k + u) * jb.cpitch];
-#pragma unroll
-            for (int u = 0; u < 4; u++) cb = min(cb, sat_add(v[u], DT_A * (uint32_t)(CH * (k + u - c) - (CH - 1))));
-        }
-        for (; k < nch; k++) cb = min(cb, sat_add(be[(size_t)k * jb.cpitch], DT_A * (uint32_t)(CH * (k - c) - (CH - 1))));
     }
     uint32_t run = cf;
 #pragma unroll
@@ -629,6 +637,7 @@ int rtvm_launch_dt2(rtvm_ctx* c, const DtJob* d_jobs, int n_first, int second, i
                 ncol_x);
     if (max_w + 7 > 2048)  // rows that take more than one pass of the row scan
         RTVM_LAUNCH(c, k_dt_rows_wide, dim3(max_h, njobs), dim3(256), 0, d_jobs, n_first, second);
+    RTVM_LAUNCH(c, k_dt_chunks, dim3(ncol_x, njobs, 2), dim3(64), 0, d_jobs, n_first, second);
     RTVM_LAUNCH(c, k_dt_cols, dim3(ncol_x, nch + 1, njobs), dim3(64), 0, d_jobs, n_first, second);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;

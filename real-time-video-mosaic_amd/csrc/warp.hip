@@ -129,31 +129,32 @@ __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restric
 }
 
 // The 2x2 taps at (ix, iy) .. (ix+1, iy+1), 3 channels each; taps outside the frame read 0
-// (BORDER_CONSTANT).  The loads are unconditional (clamped addresses) so that all twelve
-// are in flight together; t[tap][channel], tap = 2*dy + dx.
+// (BORDER_CONSTANT); t[tap][channel], tap = 2*dy + dx.  The two taps of a row are six
+// consecutive bytes: one unaligned 8-byte load per row, from an address clamped so that it
+// stays inside the frame (at least 8 bytes and 2 columns, checked by the caller).
 __device__ __forceinline__ void taps4(const uint8_t* __restrict__ src, int fh, int fw, int iy, int ix, int t[4][3]) {
     const bool vx0 = (unsigned)ix < (unsigned)fw, vx1 = (unsigned)(ix + 1) < (unsigned)fw;
     const bool vy0 = (unsigned)iy < (unsigned)fh, vy1 = (unsigned)(iy + 1) < (unsigned)fh;
-    const int x0 = min(max(ix, 0), fw - 1), x1 = min(max(ix + 1, 0), fw - 1);
+    const int xlo = min(max(ix, 0), fw - 2);  // column of the first of the six bytes
     const int y0 = min(max(iy, 0), fh - 1), y1 = min(max(iy + 1, 0), fh - 1);
-    const uint8_t* __restrict__ p00 = src + ((size_t)y0 * fw + x0) * 3;
-    const uint8_t* __restrict__ p01 = src + ((size_t)y0 * fw + x1) * 3;
-    const uint8_t* __restrict__ p10 = src + ((size_t)y1 * fw + x0) * 3;
-    const uint8_t* __restrict__ p11 = src + ((size_t)y1 * fw + x1) * 3;
-    int r[4][3];
+    const size_t last = (size_t)fh * fw * 3 - 8;
+    const size_t a0 = ((size_t)y0 * fw + xlo) * 3, a1 = ((size_t)y1 * fw + xlo) * 3;
+    const size_t b0 = min(a0, last), b1 = min(a1, last);
+    uint64_t r0, r1;
+    __builtin_memcpy(&r0, src + b0, 8);
+    __builtin_memcpy(&r1, src + b1, 8);
+    r0 >>= 8 * (int)(a0 - b0);  // at most 2 bytes: the six needed ones stay
+    r1 >>= 8 * (int)(a1 - b1);
+    // tap ix is pixel (ix - xlo) of the six bytes, tap ix+1 the next one (when inside the frame)
+    const int s0 = 24 * min(max(ix - xlo, 0), 2), s1 = 24 * min(max(ix + 1 - xlo, 0), 2);
+    const uint32_t p00 = (vy0 && vx0) ? (uint32_t)(r0 >> s0) : 0u, p01 = (vy0 && vx1) ? (uint32_t)(r0 >> s1) : 0u;
+    const uint32_t p10 = (vy1 && vx0) ? (uint32_t)(r1 >> s0) : 0u, p11 = (vy1 && vx1) ? (uint32_t)(r1 >> s1) : 0u;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        r[0][c] = p00[c];
-        r[1][c] = p01[c];
-        r[2][c] = p10[c];
-        r[3][c] = p11[c];
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        t[0][c] = (vy0 && vx0) ? r[0][c] : 0;
-        t[1][c] = (vy0 && vx1) ? r[1][c] : 0;
-        t[2][c] = (vy1 && vx0) ? r[2][c] : 0;
-        t[3][c] = (vy1 && vx1) ? r[3][c] : 0;
+        t[0][c] = (p00 >> (8 * c)) & 255;
+        t[1][c] = (p01 >> (8 * c)) & 255;
+        t[2][c] = (p10 >> (8 * c)) & 255;
+        t[3][c] = (p11 >> (8 * c)) & 255;
     }
 }
 
@@ -303,26 +304,36 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
     const int rx0 = wp->rx0, rx1 = wp->rx1, wy0 = wp->wy0, wy1 = wp->wy1;
     const auto dn = as_global<const float>(side.dist_new);
     const auto dold = as_global<const float>(side.dist_old);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int y = by + wv;
     const bool row_ok = y >= wy0 && y < wy1;
     const size_t row = (size_t)y * cw;
     if (row_ok) {
         const bool row_in_roi = y >= wp->ry0 && y < wp->ry1;
-        for (int i = lane; i < 288; i += 64) {
+        const int wx0 = wp->wx0, wx1 = wp->wx1;
+        // all distances of the lane requested first, the divisions after: one wait, not five
+        float a[5], b[5];
+        bool ok[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const int i = lane + 64 * q;
+            const int xs = reflect101(bx - 15 + i, cw);
+            // distances exist on [wx0, wx1); columns this row pass never needs may lie outside
+            ok[q] = i < 256 + 30 && xs >= wx0 && xs < wx1;
+            const int xc = min(max(xs, wx0), wx1 - 1);
+            b[q] = dold[row + xc];
+            a[q] = (row_in_roi && xs >= rx0 && xs < rx1) ? dn[row + xc] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const int i = lane + 64 * q;
             float wn = 0.f, wo = 0.f;
-            if (i < 256 + 30) {
-                const int xs = reflect101(bx - 15 + i, cw);
-                // distances exist on [wx0, wx1); columns this row pass never needs may lie outside
-                if (xs >= wp->wx0 && xs < wp->wx1) {
-                    const float a = (row_in_roi && xs >= rx0 && xs < rx1) ? dn[row + xs] : 0.f;
-                    const float b = dold[row + xs];
-                    const float sum = (a + b) + 1e-6f;
-                    wn = a / sum;
-                    wo = b / sum;
-                }
+            if (ok[q]) {
+                const float sum = (a[q] + b[q]) + 1e-6f;
+                wn = a[q] / sum;
+                wo = b[q] / sum;
             }
-            s_w[wv][i] = f32x2{wn, wo};
+            if (i < 288) s_w[wv][i] = f32x2{wn, wo};
         }
     }
     __syncthreads();
@@ -424,16 +435,15 @@ __device__ __forceinline__ void blur_cols_window(const WarpParams* __restrict__ 
 __device__ __forceinline__ void blur_cols_tile(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
                                                const SideDev& side, int ch, int cw, int bx, int by) {
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
-    const int x = bx + (threadIdx.x & 63), ya = by + 4 * (threadIdx.x >> 6);
+    // a wave is 64 columns of 4 rows: the row is the same for all its lanes, and saying so keeps
+    // the row addresses in scalar registers
+    const int x = bx + (threadIdx.x & 63), ya = by + 4 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (x < rx0 || x >= rx1 || ya >= ry1 || ya + 4 <= ry0) return;
-    bool need[4], any = false;
+    // every pixel of the ROI gets its weights (only those under the frame's mask are ever read):
+    // asking the mask first would put one more memory round trip in front of the window loads
+    bool need[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int y = ya + i;
-        need[i] = y >= ry0 && y < ry1 && (as_global<const uint32_t>(side.warped)[(size_t)y * cw + x] >> 24);
-        any |= need[i];
-    }
-    if (!any) return;
+    for (int i = 0; i < 4; i++) need[i] = ya + i >= ry0 && ya + i < ry1;
     // only the tiles at the top and bottom of the canvas reflect rows (the same for the whole workgroup)
     if (by - 15 >= 0 && by + 16 + 15 <= ch)
         blur_cols_window<false>(wp, gk, side, ch, cw, x, ya, need);
@@ -443,7 +453,7 @@ __device__ __forceinline__ void blur_cols_tile(const WarpParams* __restrict__ wp
 
 // blockIdx.z = frame of the batch.  Tiles of 64 x 16 pixels of the ROI; REST as in k_blur_rows.
 template <bool REST>
-__global__ __launch_bounds__(256) void k_blur_cols(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_blur_cols(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
                                                    const SideDev* __restrict__ sides, int ch, int cw, int ex, int ey) {
     const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const SideDev side = sides[blockIdx.z];
