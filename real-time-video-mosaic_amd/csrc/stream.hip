@@ -72,8 +72,9 @@ __device__ bool validate_h(const double* H, double trans_thr, double scale_thr) 
 // validate, smooth (weighted mean of at most five relative homographies),
 // H = H_old @ H_smoothed, H_old = H.  Writes the absolute homography and the
 // "do not stitch" flag of every frame, and a copy of the state after every frame.
-// One wave: the state and the per-frame inputs are brought into LDS by all lanes, lane 0
-// runs the chain, all lanes copy the snapshots out.
+// One wave: the state and the per-frame inputs are brought into LDS by all lanes; lane e < 9
+// carries element e of the 3x3 matrices through the chain (the decisions are taken by all
+// lanes alike), lane 0 keeps the scalars, all lanes copy the snapshots out.
 __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__ slots, int sb, int n,
                                                    StreamState* __restrict__ st_g, const double* __restrict__ wtab,
                                                    double* __restrict__ H_out, int* __restrict__ skip,
@@ -82,9 +83,9 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
     __shared__ StreamState S;
     __shared__ int s_m[RTVM_MAX_BATCH], s_found[RTVM_MAX_BATCH], s_kp[RTVM_MAX_BATCH], s_skip[RTVM_MAX_BATCH];
     __shared__ double s_H[RTVM_MAX_BATCH][9], s_Habs[RTVM_MAX_BATCH][9];
-    __shared__ double s_w[30];
-    __shared__ int s_snap;
+    __shared__ double s_w[30], s_Hs[9];
     const int lane = threadIdx.x;
+    const int e = lane < 9 ? lane : 0;  // the matrix element of this lane
     constexpr int WORDS = (int)(sizeof(StreamState) / sizeof(uint32_t));
     static_assert(sizeof(StreamState) % sizeof(uint32_t) == 0, "StreamState is copied word by word");
     {
@@ -104,85 +105,88 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
     __syncthreads();
     StreamState* st = &S;
     int n_done = 0, last_good = -1;
-    // lane 0's: 0 = go on; 1 = a mispredicted canvas mask upstream (detection results stand);
+    // 0 = go on; 1 = a mispredicted canvas mask upstream (detection results stand);
     // 2 = a skipped frame upstream (the frames behind it were matched against the wrong frame)
-    int abort = 0;
-    if (lane == 0) {
-        abort = st->abort;
-        // matched ahead of time against a frame that did not advance the state
-        if (ahead && !st->tail_ok) abort = 2;
-    }
+    int abort = st->abort;
+    // matched ahead of time against a frame that did not advance the state
+    if (ahead && !st->tail_ok) abort = 2;
     for (int j = 0; j < n; j++) {
-        if (lane == 0) {
-            s_snap = 0;
-            if (abort) {
+        bool snapshot = false;
+        if (abort) {
+            if (lane == 0) {
                 st->b_status[j] = RTVM_FRAME_PENDING;
                 st->b_matches[j] = 0;
                 st->b_kp[j] = 0;
-            } else {
-                s_snap = 1;
-                n_done = j + 1;
+            }
+        } else {
+            snapshot = true;
+            n_done = j + 1;
+            const int m = s_m[j];
+            int status = 0;
+            if (m < 4)
+                status = RTVM_FRAME_FEW_MATCHES;
+            else if (!s_found[j])
+                status = RTVM_FRAME_NO_HOMOGRAPHY;
+            if (lane == 0) {
                 st->frame_index += 1;
-                const int m = s_m[j];
                 st->n_matches = st->b_matches[j] = m;
                 st->n_kp = st->b_kp[j] = s_kp[j];
-                int status = 0;
-                if (m < 4)
-                    status = RTVM_FRAME_FEW_MATCHES;
-                else if (!s_found[j])
-                    status = RTVM_FRAME_NO_HOMOGRAPHY;
-                if (status) {
-                    st->status = st->b_status[j] = status;
-                    if (j < n - 1) abort = 2;  // the later frames were matched against this one
-                } else {
-                    double Hr[9];
-                    for (int i = 0; i < 9; i++) Hr[i] = s_H[j][i];
-                    if (!validate_h(Hr, trans_thr, scale_thr)) {
-                        for (int i = 0; i < 9; i++) Hr[i] = (i % 4 == 0) ? 1. : 0.;
-                        status |= RTVM_FRAME_INVALID_H;
-                    } else {
-                        for (int i = 0; i < 9; i++) st->last_valid_H[i] = Hr[i];
-                    }
-                    // smooth_homography
-                    int k = st->hist_len;
-                    if (k == 5) {
-                        for (int a = 0; a < 4; a++)
-                            for (int i = 0; i < 9; i++) st->hist[a][i] = st->hist[a + 1][i];
-                        k = 4;
-                    }
-                    for (int i = 0; i < 9; i++) st->hist[k][i] = Hr[i];
-                    k++;
+            }
+            if (status) {
+                if (lane == 0) st->status = st->b_status[j] = status;
+                if (j < n - 1) abort = 2;  // the later frames were matched against this one
+            } else {
+                double Hr[9];
+                for (int i = 0; i < 9; i++) Hr[i] = s_H[j][i];
+                const bool ok = validate_h(Hr, trans_thr, scale_thr);
+                if (!ok) status |= RTVM_FRAME_INVALID_H;
+                const double Hr_e = ok ? Hr[e] : ((e % 4 == 0) ? 1. : 0.);
+                // smooth_homography: the history of element e
+                int k = st->hist_len;
+                double h[5];
+                for (int a = 0; a < 5; a++) h[a] = st->hist[a][e];
+                const double Ho0 = st->H_old[(e / 3) * 3], Ho1 = st->H_old[(e / 3) * 3 + 1], Ho2 = st->H_old[(e / 3) * 3 + 2];
+                __syncthreads();  // everything read before anything of this frame is written
+                if (k == 5) {
+                    for (int a = 0; a < 4; a++) h[a] = h[a + 1];
+                    k = 4;
+                }
+                for (int a = 0; a < 5; a++)
+                    if (a == k) h[a] = Hr_e;
+                k++;
+                double Hs_e = Hr_e;
+                if (k >= 2) {
+                    double acc = 0.;
+                    for (int a = 0; a < 5; a++)
+                        if (a < k) acc += s_w[k * 5 + a] * h[a];
+                    Hs_e = acc;
+                }
+                if (lane < 9) {
+                    if (ok) st->last_valid_H[e] = Hr_e;
+                    for (int a = 0; a < 5; a++)
+                        if (a < k) st->hist[a][e] = h[a];
+                    s_Hs[e] = Hs_e;
+                }
+                __syncthreads();
+                // self.H = np.matmul(self.H_old, H_relative_smoothed)
+                const int c2 = e % 3;
+                const double H_e = (Ho0 * s_Hs[c2] + Ho1 * s_Hs[3 + c2]) + Ho2 * s_Hs[6 + c2];
+                if (lane < 9) {
+                    st->H_abs[e] = H_e;
+                    st->H_old[e] = H_e;
+                    s_Habs[j][e] = H_e;
+                }
+                if (lane == 0) {
                     st->hist_len = k;
-                    double Hs[9];
-                    if (k < 2) {
-                        for (int i = 0; i < 9; i++) Hs[i] = Hr[i];
-                    } else {
-                        for (int i = 0; i < 9; i++) {
-                            double acc = 0.;
-                            for (int a = 0; a < k; a++) acc += s_w[k * 5 + a] * st->hist[a][i];
-                            Hs[i] = acc;
-                        }
-                    }
-                    // self.H = np.matmul(self.H_old, H_relative_smoothed)
-                    double H[9];
-                    for (int r = 0; r < 3; r++)
-                        for (int c2 = 0; c2 < 3; c2++)
-                            H[r * 3 + c2] = (st->H_old[r * 3] * Hs[c2] + st->H_old[r * 3 + 1] * Hs[3 + c2]) +
-                                            st->H_old[r * 3 + 2] * Hs[6 + c2];
-                    for (int i = 0; i < 9; i++) {
-                        st->H_abs[i] = H[i];
-                        st->H_old[i] = H[i];
-                        s_Habs[j][i] = H[i];
-                    }
                     st->status = st->b_status[j] = status;
                     s_skip[j] = 0;
-                    last_good = j;
                 }
-                st->last_good = last_good;
+                last_good = j;
             }
+            if (lane == 0) st->last_good = last_good;
         }
         __syncthreads();
-        if (s_snap) {  // the state to return to when a later frame of the batch cannot be stitched
+        if (snapshot) {  // the state to return to when a later frame of the batch cannot be stitched
             const uint32_t* l = reinterpret_cast<const uint32_t*>(&S);
             uint32_t* g = reinterpret_cast<uint32_t*>(snap + j);
             for (int i = lane; i < WORDS; i += 64) g[i] = l[i];
