@@ -187,12 +187,12 @@ int rtvm_batch_status_at(rtvm_ctx* ctx, int back, int* n_done, int* status, int*
 /* Ticket of the batch queued last (rtvm_process_batch, rtvm_process_frame or rtvm_batch_retry);
  * tickets count up from 1 after rtvm_stream_begin. */
 long rtvm_batch_ticket(rtvm_ctx* ctx);
-/* rtvm_batch_status for one of the last 8 tickets, plus the reason (RTVM_PENDING_*) when
+/* rtvm_batch_status for one of the last 16 tickets, plus the reason (RTVM_PENDING_*) when
  * frames were left pending.  Waits for that batch only. */
 int rtvm_batch_status_of(rtvm_ctx* ctx, long ticket, int* n_done, int* reason, int* status,
                          int* n_matches, int* n_keypoints, int cap);
 /* Queues the canvas half again (validate / smooth / chain, warp, blend) for frames first ..
- * first+count-1 of the batch `ticket` (queued with rtvm_process_batch, one of the last four),
+ * first+count-1 of the batch `ticket` (queued with rtvm_process_batch or rtvm_batch_detect and still holding its slot set),
  * reusing its detection, matching and RANSAC results: for frames left pending with
  * RTVM_PENDING_MASK, or for a RTVM_PENDING_VOID batch queued behind such frames, in frame
  * order.  The retry is a batch of its own (rtvm_batch_ticket).  No counterpart in the

@@ -6,6 +6,8 @@ opened, the calls raise.
 import ctypes as C
 import os
 
+import time
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -344,7 +346,7 @@ class Context:
 
     def batch_status_of(self, ticket, n):
         """(frames consumed, reason, status[n], matches[n], keypoints[n]) of the batch `ticket`
-        (one of the last 8).  reason: PENDING_* when frames were left pending."""
+        (one of the last 16).  reason: PENDING_* when frames were left pending."""
         done, reason = C.c_int(0), C.c_int(0)
         st = np.zeros(n, np.int32)
         nm = np.zeros(n, np.int32)
@@ -369,7 +371,7 @@ class Context:
     def batch_release(self, ticket):
         self._check(lib().rtvm_batch_release(self._h, ticket))
 
-    def _stitch_rest(self, ticket, start, k, first, status, stats):
+    def _stitch_rest(self, ticket, start, k, first, status, stats, trace=None):
         """Frames first .. k-1 of the detected batch `ticket` (video frames start+first ..) came back
         pending although their detection, matching and RANSAC results stand: queues their canvas
         half again, one frame at first (such events come in runs), twice as many after every retry
@@ -383,6 +385,8 @@ class Context:
             stats["retries"] += 1
             stats["frames_retried"] += cnt
             d2, reason, st2, _, _ = self.batch_status_of(t2, cnt)
+            if trace is not None:
+                trace.append((time.perf_counter(), start + first, cnt, d2, reason))
             status[start + first:start + first + d2] = st2[:d2]
             first += d2
             if d2 == cnt:
@@ -395,7 +399,7 @@ class Context:
                 return start + first
         return None
 
-    def process_video(self, bgr_dev_ptrs, batch=16):
+    def process_video(self, bgr_dev_ptrs, batch=16, trace=None):
         """process_frame over a whole list of device-resident frames.  Detection, matching and
         RANSAC run up to three batches ahead (rtvm_batch_detect) of the canvas half, which is
         queued batch by batch, two in flight (rtvm_batch_retry).  Frames come back pending (a)
@@ -403,7 +407,9 @@ class Context:
         rest of its batch: their canvas half is queued again, in small steps, while detection
         keeps running ahead; (b) behind a frame the reference skips: the frames detected behind it
         were matched against the wrong frame, detection starts again from there.
-        Returns the per-frame status codes; self.video_stats counts what was queued."""
+        Returns the per-frame status codes; self.video_stats counts what was queued.  trace: a
+        list that receives (seconds, first frame, length, frames consumed, reason) for every
+        canvas half whose outcome was read."""
         self.reserve_batch(batch)
         n = len(bgr_dev_ptrs)
         status = np.zeros(n, np.int32)
@@ -439,6 +445,8 @@ class Context:
             dt, bt, start, k = inb.pop(0)
             done, reason, st, _, _ = self.batch_status_of(bt, k)
             status[start:start + done] = st[:done]
+            if trace is not None:
+                trace.append((time.perf_counter(), start, k, done, reason))
             if done == k:
                 self.batch_release(dt)
                 if st[k - 1] & (FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY) and start + k < n:
@@ -452,12 +460,12 @@ class Context:
                 start_over(start + done)
                 continue
             # canvas half again for the rest of this batch, then for the one queued behind it
-            redo = self._stitch_rest(dt, start, k, done, status, stats)
+            redo = self._stitch_rest(dt, start, k, done, status, stats, trace)
             self.batch_release(dt)
             while redo is None and inb:
                 dt, bt, start, k = inb.pop(0)
                 stats["frames_void"] += k   # queued behind the failed batch: its canvas half did nothing
-                redo = self._stitch_rest(dt, start, k, 0, status, stats)
+                redo = self._stitch_rest(dt, start, k, 0, status, stats, trace)
                 self.batch_release(dt)
             if redo is not None:
                 start_over(redo)

@@ -220,7 +220,7 @@ int alloc_all(rtvm_ctx* c) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_back[k], hipEventDisableTiming));
     }
     for (int k = 0; k < RTVM_REPORTS; k++) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
-    c->recs = (BatchRecord*)calloc(RTVM_RECORDS, sizeof(BatchRecord));
+    c->recs = (BatchRecord*)calloc(RTVM_NSETS, sizeof(BatchRecord));
     if (!c->recs) RTVM_FAIL(c, RTVM_E_NOMEM, "host allocation failed");
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     c->spec_tail = -1;

@@ -210,8 +210,7 @@ struct BatchRecord {
     int ahead;       // its first frame was matched against the frame queued before it (not feat_prev)
     const uint8_t* ptrs[RTVM_MAX_BATCH];
 };
-#define RTVM_RECORDS 64
-#define RTVM_REPORTS 8
+#define RTVM_REPORTS 16
 
 // frame pointers of a batch, passed to the binding kernel by value
 struct BatchPtrs {
@@ -238,7 +237,7 @@ struct rtvm_ctx {
     long seq;                  // batches queued since the stream began
     int n_set1;                // allocated slots of each of the sets 1 .. RTVM_NSETS-1
     BatchReport* h_rep;        // [RTVM_REPORTS] pinned, indexed by seq % RTVM_REPORTS
-    BatchRecord* recs;         // [RTVM_RECORDS], indexed by ticket % RTVM_RECORDS
+    BatchRecord* recs;         // [RTVM_NSETS]: the batch whose detection results each slot set holds
     long set_owner[RTVM_NSETS]; // ticket of the batch whose detection results the slot set holds
     int set_live[RTVM_NSETS];   // the set holds a batch queued with rtvm_batch_detect and not yet released
     BatchReport* d_rep;        // device view of h_rep

@@ -375,13 +375,15 @@ int queue_back_half(rtvm_ctx* c, int set, int sb, const uint8_t* const* ptrs, in
     int r;
     c->seq += 1;
     const int slot = (int)(c->seq % RTVM_REPORTS);
-    BatchRecord& rec = c->recs[c->seq % RTVM_RECORDS];
-    rec.ticket = c->seq;
-    rec.set = set;
-    rec.sb = sb;
-    rec.n = n;
-    rec.ahead = ahead;
-    for (int j = 0; j < n; j++) rec.ptrs[j] = ptrs[j];
+    if (c->set_owner[set] == c->seq) {  // the batch that owns the slot set (not a later piece of it)
+        BatchRecord& rec = c->recs[set];
+        rec.ticket = c->seq;
+        rec.set = set;
+        rec.sb = sb;
+        rec.n = n;
+        rec.ahead = ahead;
+        for (int j = 0; j < n; j++) rec.ptrs[j] = ptrs[j];
+    }
     RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
                 50.0, 0.3, ahead, c->d_snap);
     if ((r = rtvm_launch_warp_prep(c, c->d_H, c->d_skip, n))) return r;
@@ -601,11 +603,12 @@ extern "C" int rtvm_batch_status(rtvm_ctx* c, int* n_done, int* status, int* n_m
 extern "C" int rtvm_batch_retry(rtvm_ctx* c, long ticket, int first, int count) {
     if (!c) return RTVM_E_ARG;
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "batch_retry: no stream");
-    if (ticket < 1 || ticket > c->seq || c->seq - ticket >= RTVM_RECORDS)
-        RTVM_FAIL(c, RTVM_E_STATE, "batch_retry: unknown ticket %ld", ticket);
-    const BatchRecord rec = c->recs[ticket % RTVM_RECORDS];
-    if (rec.ticket != ticket || c->set_owner[rec.set] != ticket)
-        RTVM_FAIL(c, RTVM_E_STATE, "batch_retry: the detection results of batch %ld are no longer held", ticket);
+    int owner = -1;
+    for (int k = 0; k < RTVM_NSETS; k++)
+        if (ticket >= 1 && c->set_owner[k] == ticket && c->recs[k].ticket == ticket) owner = k;
+    if (owner < 0)
+        RTVM_FAIL(c, RTVM_E_STATE, "batch_retry: the detection results of batch %ld are not held (any more)", ticket);
+    const BatchRecord rec = c->recs[owner];
     if (first < 0 || count < 1 || first + count > rec.n)
         RTVM_FAIL(c, RTVM_E_ARG, "batch_retry: frames %d..%d of a batch of %d", first, first + count - 1, rec.n);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -630,7 +633,7 @@ extern "C" int rtvm_batch_detect(rtvm_ctx* c, const uint8_t* const* bgr_dev, int
     int set = 0, ahead = 0;
     if ((r = queue_detect(c, bgr_dev, n, &set, &ahead))) return r;
     c->seq += 1;
-    BatchRecord& rec = c->recs[c->seq % RTVM_RECORDS];
+    BatchRecord& rec = c->recs[set];
     rec.ticket = c->seq;
     rec.set = set;
     rec.sb = set * RTVM_MAX_BATCH;
