@@ -12,8 +12,9 @@
 //     count by ballot + popcount);
 //   * the keep/stop rule only needs the inlier counts in iteration order
 //     (k_rs_replay, one lane).
-// Iterations 0..63 are evaluated first; with a usable inlier ratio the budget has
-// dropped below 64 by then and the second batch (64..max_iters-1) exits at once.
+// Iterations are evaluated in three stages, 0..15, 16..63 and 64..max_iters-1; with a
+// usable inlier ratio the budget has dropped below 16 (or 64) by the time a stage has
+// been replayed and the later stages exit at once.
 // k_rs_refine then recomputes the winner's inlier mask, re-solves on all inliers
 // and runs the 10-iteration Levenberg-Marquardt polish, one wave per problem.
 //
@@ -28,7 +29,7 @@
 
 namespace {
 
-constexpr int RS_BATCH0 = 64;  // iterations evaluated in the first batch
+constexpr int RS_BATCH0 = 64;  // iterations evaluated in the first two stages (a quarter of them in the first)
 
 struct RsState {
     int niters, max_good, best, done, found, fail_at, next_pos, next_iter;
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(64) void k_rs_subsets(const FrameSlot* __restrict__
             if (lane == 0) st->fail_at = c0 + first_bad;
             return;
         }
-        base = __shfl(pos + cons, 63);
+        base = __shfl(pos + cons, min(63, h1 - 1 - c0));  // where the last iteration of this stage ends
     }
     if (lane == 0) {
         st->next_pos = base;
@@ -773,15 +774,18 @@ int rtvm_launch_ransac_search(rtvm_ctx* c, int sb, int nb, double thresh, int ma
     if (!(confidence > 0 && confidence < 1)) RTVM_FAIL(c, RTVM_E_ARG, "findHomography: confidence must be in (0,1)");
     const float thr = (float)(thresh * thresh);
     const FrameSlot* sl = c->d_slots;
-    const int b0 = max_iters < RS_BATCH0 ? max_iters : RS_BATCH0;
-    RTVM_LAUNCH(c, k_rs_subsets, dim3(nb), dim3(64), 0, sl, sb, c->d_rs_raw, c->rs_raw_n, 0, b0, confidence, max_iters, 1);
-    RTVM_LAUNCH(c, k_rs_hyp, dim3(b0, nb), dim3(64), 0, sl, sb, 0, b0, thr);
-    RTVM_LAUNCH(c, k_rs_replay, dim3(nb), dim3(64), 0, sl, sb, 0, b0, confidence, b0 >= max_iters ? 1 : 0);
-    if (b0 < max_iters) {
-        RTVM_LAUNCH(c, k_rs_subsets, dim3(nb), dim3(64), 0, sl, sb, c->d_rs_raw, c->rs_raw_n, b0, max_iters, confidence,
-                    max_iters, 0);
-        RTVM_LAUNCH(c, k_rs_hyp, dim3(max_iters - b0, nb), dim3(64), 0, sl, sb, b0, max_iters, thr);
-        RTVM_LAUNCH(c, k_rs_replay, dim3(nb), dim3(64), 0, sl, sb, b0, max_iters, confidence, 1);
+    // Iterations in stages: with a usable inlier ratio the budget (RsState::niters) has dropped below the
+    // end of the first or second stage by the time it has been replayed, and the later stages exit at once.
+    const int ends[3] = {RS_BATCH0 / 4, RS_BATCH0, max_iters};
+    int h0 = 0;
+    for (int s = 0; s < 3 && h0 < max_iters; s++) {
+        const int h1 = ends[s] < max_iters ? ends[s] : max_iters;
+        if (h1 <= h0) continue;
+        RTVM_LAUNCH(c, k_rs_subsets, dim3(nb), dim3(64), 0, sl, sb, c->d_rs_raw, c->rs_raw_n, h0, h1, confidence,
+                    max_iters, h0 == 0 ? 1 : 0);
+        RTVM_LAUNCH(c, k_rs_hyp, dim3(h1 - h0, nb), dim3(64), 0, sl, sb, h0, h1, thr);
+        RTVM_LAUNCH(c, k_rs_replay, dim3(nb), dim3(64), 0, sl, sb, h0, h1, confidence, h1 >= max_iters ? 1 : 0);
+        h0 = h1;
     }
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
