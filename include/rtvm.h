@@ -213,6 +213,24 @@ int rtvm_batch_release(rtvm_ctx* ctx, long ticket);
  * rtvm_process_frame (any may be NULL).  Syncs the stream. */
 int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_matches, double H_abs[9]);
 
+/* ---- mosaic finalisation: the step after the path, once per video ---------------- */
+
+/* crop_black_areas (main.py:980-1003): rect = {x, y, w, h} of cv2.boundingRect over the pixels
+ * whose gray value (cvtColor BGR2GRAY) exceeds `threshold` (cv2.threshold THRESH_BINARY,
+ * main.py:991-997) of a host image of h x w x 3 u8; *found = 0 when there is none (the
+ * reference then returns the image unchanged).  The margin arithmetic of main.py:999-1002 is
+ * the caller's.  Allocates scratch; syncs. */
+int rtvm_crop_rect(rtvm_ctx* ctx, const uint8_t* bgr, int h, int w, int threshold, int rect[4], int* found);
+/* Same on the context's canvas as it stands (what main.py:1647-1652 passes in), without
+ * copying it to the host first. */
+int rtvm_canvas_crop_rect(rtvm_ctx* ctx, int threshold, int rect[4], int* found);
+/* scale_to_screen's cv2.resize(image, (nw, nh), interpolation=INTER_LINEAR) (main.py:1037) of a
+ * host image of h x w x 3 u8 into out (nh x nw x 3).  Allocates scratch; syncs. */
+int rtvm_resize_linear(rtvm_ctx* ctx, const uint8_t* bgr, int h, int w, uint8_t* out, int nh, int nw);
+/* The same resize of the rectangle x, y, w, h of the context's canvas: crop and scale in one
+ * pass, only the scaled image crosses PCIe. */
+int rtvm_canvas_read_scaled(rtvm_ctx* ctx, int x, int y, int w, int h, uint8_t* out, int nh, int nw);
+
 /* ---- two-call form of process_frame for hosts that keep the validate / smooth /
  * chain arithmetic of main.py:733-746 on their side (the Python VideMosaic) ----- */
 

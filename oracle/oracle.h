@@ -63,6 +63,12 @@ void rtvm_oracle_gaussian_blur31(const float* src, int h, int w, float* dst);
 int rtvm_oracle_warp_blend(uint8_t* canvas, int ch, int cw, const uint8_t* bgr, int fh, int fw,
                            const double H[9], int fixed);
 
+/* main.py:991-997: bounding rectangle {x, y, w, h} of the pixels whose gray value exceeds
+ * `threshold` (crop_black_areas); returns 0 when there is none, else 1 */
+int rtvm_oracle_crop_rect(const uint8_t* bgr, int h, int w, int threshold, int rect[4]);
+/* main.py:1037: cv2.resize(image, (nw, nh), INTER_LINEAR) on 8UC3 (scale_to_screen) */
+int rtvm_oracle_resize_linear(const uint8_t* bgr, int h, int w, uint8_t* out, int nh, int nw);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,4 +7,4 @@ alias it as ``rtvm``).
 from . import _ffi, synth  # noqa: F401
 from ._ffi import Context, RtvmError  # noqa: F401
 from .types import KeyPoint, DMatch  # noqa: F401
-from .mosaic import VideMosaic  # noqa: F401
+from .mosaic import VideMosaic, crop_black_areas, scale_to_screen  # noqa: F401

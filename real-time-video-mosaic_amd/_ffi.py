@@ -46,6 +46,10 @@ SIGNATURES = {
     "rtvm_distance_transform": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "rtvm_warp_blend": (C.c_int, [_vp, _vp, _vp]),
     "rtvm_canvas_read": (C.c_int, [_vp, _vp]),
+    "rtvm_crop_rect": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _intp]),
+    "rtvm_canvas_crop_rect": (C.c_int, [_vp, C.c_int, _vp, _intp]),
+    "rtvm_resize_linear": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
+    "rtvm_canvas_read_scaled": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
     "rtvm_stream_begin": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_process_frame": (C.c_int, [_vp, _vp]),
     "rtvm_frame_status": (C.c_int, [_vp, _intp, _intp, _intp, _vp]),
@@ -127,6 +131,14 @@ def ptr(a):
         return None
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
+
+
+def _c_u8(image):
+    """The image as a C-contiguous H x W x 3 u8 array (the reference converts with astype(uint8) too)."""
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    if image.ndim != 3 or image.shape[2] != 3:
+        raise ValueError("expected an H x W x 3 image")
+    return image
 
 
 class Context:
@@ -253,6 +265,39 @@ class Context:
 
     def sync(self):
         self._check(lib().rtvm_sync(self._h))
+
+    # ---- mosaic finalisation (main.py:980-1038) -------------------------------
+    def crop_rect(self, image, threshold=15):
+        """cv2.boundingRect of the pixels of a BGR u8 image whose gray value exceeds threshold:
+        (x, y, w, h), or None when there is none."""
+        image = _c_u8(image)
+        rect = np.zeros(4, np.int32)
+        found = C.c_int(0)
+        self._check(lib().rtvm_crop_rect(self._h, ptr(image), image.shape[0], image.shape[1], int(threshold), ptr(rect),
+                                         C.byref(found)))
+        return tuple(int(v) for v in rect) if found.value else None
+
+    def canvas_crop_rect(self, threshold=15):
+        """crop_rect of the canvas as it stands on the device."""
+        rect = np.zeros(4, np.int32)
+        found = C.c_int(0)
+        self._check(lib().rtvm_canvas_crop_rect(self._h, int(threshold), ptr(rect), C.byref(found)))
+        return tuple(int(v) for v in rect) if found.value else None
+
+    def resize_linear(self, image, new_w, new_h):
+        """cv2.resize(image, (new_w, new_h), interpolation=cv2.INTER_LINEAR) of a BGR u8 image."""
+        image = _c_u8(image)
+        out = np.empty((int(new_h), int(new_w), 3), np.uint8)
+        self._check(lib().rtvm_resize_linear(self._h, ptr(image), image.shape[0], image.shape[1], ptr(out), int(new_h),
+                                             int(new_w)))
+        return out
+
+    def canvas_read_scaled(self, x, y, w, h, new_w, new_h):
+        """The rectangle x, y, w, h of the device canvas, resized like resize_linear."""
+        out = np.empty((int(new_h), int(new_w), 3), np.uint8)
+        self._check(lib().rtvm_canvas_read_scaled(self._h, int(x), int(y), int(w), int(h), ptr(out), int(new_h),
+                                                  int(new_w)))
+        return out
 
     # ---- two-call stream form (host frames, glue on the host) ---------------
     def first_frame(self, bgr, row_off, col_off):

@@ -254,6 +254,45 @@ class VideMosaic:
         self._ctx.close()
 
 
+def crop_black_areas(image, threshold=15, margin=5):
+    """main.py:980-1003: cut the black surroundings (and a margin) off a mosaic.  `image` is a
+    numpy image, or a VideMosaic: then the rectangle is found on the device canvas and only the
+    rectangle crosses PCIe before the canvas is read."""
+    if isinstance(image, VideMosaic):
+        canvas = image.output_img_u8()
+        rect = image._ctx.canvas_crop_rect(threshold)
+        image = canvas
+    else:
+        if image.dtype != np.uint8:
+            image = image.astype(np.uint8)
+        rect = _stage_ctx().crop_rect(image, threshold)
+    if rect is None:
+        return image
+    x, y, w, h = rect
+    x = max(0, x + margin)
+    y = max(0, y + margin)
+    w = min(image.shape[1] - x, w - 2 * margin)
+    h = min(image.shape[0] - y, h - 2 * margin)
+    return image[y:y + h, x:x + w]
+
+
+def scale_to_screen(image, target_w=None, target_h=None):
+    """main.py:1006-1038: resize to fit the screen (1920 x 1080 when no size is given: the
+    reference asks Windows and falls back to that), aspect ratio kept."""
+    ih, iw = image.shape[0], image.shape[1]
+    screen_w, screen_h = target_w, target_h
+    if screen_w is None or screen_h is None:
+        screen_w, screen_h = 1920, 1080
+    scale = min(screen_w / float(iw), screen_h / float(ih))
+    if scale <= 0:
+        scale = 1.0
+    new_w = max(1, int(iw * scale))
+    new_h = max(1, int(ih * scale))
+    if image.dtype != np.uint8:
+        image = image.astype(np.uint8)
+    return _stage_ctx().resize_linear(image, new_w, new_h)
+
+
 def _thick_line(image, p0, p1, color, thickness):
     x0, y0, x1, y1 = int(p0[0]), int(p0[1]), int(p1[0]), int(p1[1])
     n = max(abs(x1 - x0), abs(y1 - y0), 1)

@@ -154,3 +154,19 @@ def orb_pyramid(gray_img):
         blur.append(bl[off:off + n].reshape(lh[l], lw[l]).copy())
         off += n
     return pyr, blur
+
+
+def crop_rect(bgr, threshold=15):
+    """(x, y, w, h) of the pixels whose gray value exceeds threshold, or None."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    rect = np.zeros(4, np.int32)
+    found = lib().rtvm_oracle_crop_rect(_p(bgr), bgr.shape[0], bgr.shape[1], int(threshold), _p(rect))
+    return tuple(int(v) for v in rect) if found else None
+
+
+def resize_linear(bgr, new_w, new_h):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty((new_h, new_w, 3), np.uint8)
+    rc = lib().rtvm_oracle_resize_linear(_p(bgr), bgr.shape[0], bgr.shape[1], _p(out), int(new_h), int(new_w))
+    assert rc == 0
+    return out
