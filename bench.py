@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--path", default="bounded", choices=["bounded", "drift"],
                     help="camera path: 'bounded' keeps every frame inside the canvas for any number of frames; "
                          "'drift' moves 2 px/frame right and up for ever (leaves the 1.2x-wide canvas after ~64 frames)")
+    ap.add_argument("--host-frames", type=int, default=256,
+                    help="frames of the video also run from host memory through the ingest ring (0 = skip)")
     ap.add_argument("--dropin-frames", type=int, default=32,
                     help="frames of the PCIe-inclusive sample through the Python VideMosaic class (0 = skip)")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel timing table to this JSON file")
@@ -273,6 +275,22 @@ def main():
                       "note": "Python VideMosaic.process_frame with host frames: PCIe copies and one host round trip "
                               "per frame included"}
             vm.close()
+        host_ingest = None
+        if args.host_frames > 0:
+            # frames in host memory through the ingest ring (pinned slots, copies on a stream of their own)
+            # into the same batched pipeline: the PCIe-inclusive rate of the throughput path
+            nh = min(args.host_frames, T - 1)
+            host_frames = frames[:nh + 1].cpu().numpy()
+            ctx2 = rtvm.Context(fh, fw, ch, cw, nfeatures=nf,
+                                flags=(rtvm._ffi.FLAG_WARP_FIXED if args.warp_mode == "fixed" else 0), device=local_rank)
+            ctx2.process_host_video(host_frames[0], host_frames[1:1 + min(64, nh)], ch - fh, int(cw / 2 - fw / 2), batch=B)
+            th0 = time.perf_counter()
+            sth = ctx2.process_host_video(host_frames[0], host_frames[1:], ch - fh, int(cw / 2 - fw / 2), batch=B)
+            th = time.perf_counter() - th0
+            host_ingest = {"value": nh / th, "unit": "frames/s", "frames": nh, "frames_not_ok": int((sth != 0).sum()),
+                           "note": "Context.process_host_video: host frames -> pinned ring -> device, batches of %d; "
+                                   "one Python memcpy per frame included" % B}
+            ctx2.close()
         cpu = None
         if args.cpu_frames > 0:
             frames_np = frames[:args.cpu_frames + 1].cpu().numpy()
@@ -294,6 +312,7 @@ def main():
                        "canvas_half_retries": vstats["retries"], "frames_retried": vstats["frames_retried"],
                        "frames_void": vstats["frames_void"]},
             "roofline": roof, "warp_blend_stage": warp_blend, "cpu_baseline": cpu, "dropin_pcie_inclusive": dropin,
+            "host_frames_pcie_inclusive": host_ingest,
         }
         if args.kernel_table:
             rows = {k: {"launches": v[0], "total_ms": v[1], "avg_us": v[1] / v[0] * 1e3, "stream": v[2],

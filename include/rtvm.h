@@ -213,6 +213,20 @@ int rtvm_batch_release(rtvm_ctx* ctx, long ticket);
  * rtvm_process_frame (any may be NULL).  Syncs the stream. */
 int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_matches, double H_abs[9]);
 
+/* ---- frame ingest: the step before the path ------------------------------------ */
+
+/* The reference's loop (main.py:1596-1634) gets every frame from cap.read() as a host array.
+ * Here a ring of n_slots pinned host frames and as many device frames: the decoder writes
+ * frame i into the host slot (rtvm_ingest_host_slot), rtvm_ingest_submit queues its copy to
+ * the device on a stream of its own and returns the device address to hand to
+ * rtvm_process_batch / rtvm_batch_detect; the streams that read the frame wait for the copy,
+ * the host does not.  A slot may be filled again once the frame it held has been consumed
+ * (its batch status read with no frame of it pending).  No counterpart in the reference
+ * beyond the loop itself.  rtvm_ingest_reserve allocates (once per context). */
+int rtvm_ingest_reserve(rtvm_ctx* ctx, int n_slots);
+int rtvm_ingest_host_slot(rtvm_ctx* ctx, int slot, uint8_t** host);
+int rtvm_ingest_submit(rtvm_ctx* ctx, int slot, const uint8_t** dev);
+
 /* ---- mosaic finalisation: the step after the path, once per video ---------------- */
 
 /* crop_black_areas (main.py:980-1003): rect = {x, y, w, h} of cv2.boundingRect over the pixels

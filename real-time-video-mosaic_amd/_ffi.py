@@ -46,6 +46,9 @@ SIGNATURES = {
     "rtvm_distance_transform": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "rtvm_warp_blend": (C.c_int, [_vp, _vp, _vp]),
     "rtvm_canvas_read": (C.c_int, [_vp, _vp]),
+    "rtvm_ingest_reserve": (C.c_int, [_vp, C.c_int]),
+    "rtvm_ingest_host_slot": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
+    "rtvm_ingest_submit": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
     "rtvm_crop_rect": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _intp]),
     "rtvm_canvas_crop_rect": (C.c_int, [_vp, C.c_int, _vp, _intp]),
     "rtvm_resize_linear": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
@@ -131,6 +134,33 @@ def ptr(a):
         return None
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
+
+
+class HostFrameRing:
+    """Frame source for Context.process_video: frame i of `frames` (host arrays) is copied into
+    pinned slot i % n_slots and from there to the device when its batch is about to be detected.
+    n_slots must cover the frames process_video keeps alive (four batches); one more slot holds
+    the first frame of the stream."""
+
+    def __init__(self, ctx, n_slots):
+        ctx.ingest_reserve(n_slots + 1)
+        self.ctx, self.n_slots, self.frames = ctx, n_slots, []
+        self.views = [ctx.ingest_host_slot(i) for i in range(n_slots + 1)]
+
+    def __len__(self):
+        return len(self.frames)
+
+    def upload_first(self, frame):
+        np.copyto(self.views[self.n_slots], frame)
+        return self.ctx.ingest_submit(self.n_slots)
+
+    def acquire(self, first, k):
+        ptrs = []
+        for i in range(first, first + k):
+            slot = i % self.n_slots
+            np.copyto(self.views[slot], self.frames[i])
+            ptrs.append(self.ctx.ingest_submit(slot))
+        return ptrs
 
 
 def _c_u8(image):
@@ -457,6 +487,8 @@ class Context:
         canvas half whose outcome was read."""
         self.reserve_batch(batch)
         n = len(bgr_dev_ptrs)
+        # a frame source (HostFrameRing) hands out device addresses batch by batch; a list has them all
+        acquire = getattr(bgr_dev_ptrs, "acquire", None) or (lambda first, k: bgr_dev_ptrs[first:first + k])
         status = np.zeros(n, np.int32)
         det = []     # detected, canvas half not queued yet: (detect ticket, first frame, length)
         inb = []     # canvas half queued: (detect ticket, canvas-half ticket, first frame, length)
@@ -479,7 +511,7 @@ class Context:
         while nxt < n or det or inb:
             while len(det) + len(inb) < 4 and nxt < n:
                 k = min(batch, n - nxt)
-                t = self.batch_detect(bgr_dev_ptrs[nxt:nxt + k])
+                t = self.batch_detect(acquire(nxt, k))
                 stats["batches_queued"] += 1
                 stats["frames_queued"] += k
                 det.append((t, nxt, k))
@@ -516,6 +548,35 @@ class Context:
                 start_over(redo)
         self.video_stats = stats
         return status
+
+    # ---- frame ingest (host frames -> device ring) ------------------------------
+    def ingest_reserve(self, n_slots):
+        self._check(lib().rtvm_ingest_reserve(self._h, int(n_slots)))
+
+    def ingest_host_slot(self, slot):
+        """The pinned host frame of a slot as a numpy array (frame_h, frame_w, 3) u8 to write into."""
+        p = C.c_void_p()
+        self._check(lib().rtvm_ingest_host_slot(self._h, int(slot), C.byref(p)))
+        n = self.frame_h * self.frame_w * 3
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(p.value)).reshape(self.frame_h, self.frame_w, 3)
+
+    def ingest_submit(self, slot):
+        """Queues the copy of a slot to the device; returns the device address of the frame."""
+        p = C.c_void_p()
+        self._check(lib().rtvm_ingest_submit(self._h, int(slot), C.byref(p)))
+        return p.value
+
+    def process_host_video(self, first_frame, frames, row_off, col_off, batch=16, trace=None):
+        """The reference's loop (main.py:1596-1634) for frames in host memory: stream_begin with
+        first_frame, then process_video over `frames` (a sequence of H x W x 3 u8 arrays), which
+        travel through the ingest ring batch by batch while earlier batches are being stitched.
+        Returns the per-frame status codes."""
+        ring = getattr(self, "_ring", None)
+        if ring is None:
+            ring = self._ring = HostFrameRing(self, 4 * 32)
+        self.stream_begin(ring.upload_first(first_frame), row_off, col_off)
+        ring.frames = frames
+        return self.process_video(ring, batch, trace)
 
     def frame_status(self):
         st, nk, nm = C.c_int(0), C.c_int(0), C.c_int(0)

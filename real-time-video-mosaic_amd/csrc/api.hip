@@ -293,6 +293,17 @@ int alloc_all(rtvm_ctx* c) {
 }
 
 void free_all(rtvm_ctx* c) {
+    if (c->stream_copy) {
+        (void)hipStreamSynchronize(c->stream_copy);
+        (void)hipStreamDestroy(c->stream_copy);
+        c->stream_copy = nullptr;
+    }
+    if (c->ev_ingest) (void)hipEventDestroy(c->ev_ingest);
+    c->ev_ingest = nullptr;
+    if (c->ingest_host) (void)hipHostFree(c->ingest_host);
+    if (c->ingest_dev) (void)hipFree(c->ingest_dev);
+    c->ingest_host = c->ingest_dev = nullptr;
+    c->ingest_slots = 0;
     void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas,
                     c->d_mask_old, c->d_bold, c->d_snap_canvas, c->d_snap_mask, c->d_side, c->d_snap, c->d_gk, c->d_H,
                     c->d_wp, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,

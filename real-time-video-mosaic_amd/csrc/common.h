@@ -228,6 +228,14 @@ struct rtvm_ctx {
     hipEvent_t ev_feat[RTVM_NSETS];   // detection + matching of the batch in slot set k is complete
     hipEvent_t ev_front[RTVM_NSETS];  // RANSAC polish of the batch in slot set k is complete
     hipEvent_t ev_back[RTVM_NSETS];   // canvas half of the batch that used slot set k is complete
+    // frame ingest ring (rtvm_ingest_*): pinned host slots the caller decodes into, device slots
+    // they are copied to on a stream of their own
+    uint8_t* ingest_host;
+    uint8_t* ingest_dev;
+    int ingest_slots;
+    hipStream_t stream_copy;
+    hipEvent_t ev_ingest;      // the last copy queued
+    int ingest_used;           // a copy was queued: streams that read frames wait for ev_ingest
     hipEvent_t ev_done[RTVM_REPORTS];  // batch number (seq % RTVM_REPORTS) is complete
     hipEvent_t ev_main;
     int back_rec[RTVM_NSETS];  // ev_back[k] has been recorded

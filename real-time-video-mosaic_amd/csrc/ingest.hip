@@ -1,0 +1,48 @@
+// Frame ingest, the step before the stitching path (reference main.py:1596-1634: cap.read()
+// hands every frame to process_frame as a host array).  A ring of pinned host slots and
+// device slots: the caller's decoder writes a frame into a host slot, rtvm_ingest_submit
+// copies it to the device on a stream of its own, and whatever stream later reads the frame
+// (detection, warp) waits for the copy, not the host.
+#include "common.h"
+
+extern "C" int rtvm_ingest_reserve(rtvm_ctx* c, int n_slots) {
+    if (!c) return RTVM_E_ARG;
+    if (c->fh <= 0 || c->fw <= 0) RTVM_FAIL(c, RTVM_E_STATE, "ingest_reserve: context was created without a frame size");
+    if (n_slots < 1 || n_slots > 4096) RTVM_FAIL(c, RTVM_E_ARG, "ingest_reserve: 1..4096 slots");
+    if (c->ingest_slots) RTVM_FAIL(c, RTVM_E_STATE, "ingest_reserve: the ring exists already (%d slots)", c->ingest_slots);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->fh * c->fw * 3 * n_slots;
+    hipError_t e = hipHostMalloc((void**)&c->ingest_host, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) RTVM_FAIL(c, RTVM_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    e = hipMalloc((void**)&c->ingest_dev, bytes);
+    if (e != hipSuccess) {
+        (void)hipHostFree(c->ingest_host);
+        c->ingest_host = nullptr;
+        RTVM_FAIL(c, RTVM_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_ingest, hipEventDisableTiming));
+    c->ingest_slots = n_slots;
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_ingest_host_slot(rtvm_ctx* c, int slot, uint8_t** host) {
+    if (!c) return RTVM_E_ARG;
+    if (!host) RTVM_FAIL(c, RTVM_E_ARG, "ingest_host_slot: null argument");
+    if (slot < 0 || slot >= c->ingest_slots) RTVM_FAIL(c, RTVM_E_ARG, "ingest_host_slot: slot %d of %d", slot, c->ingest_slots);
+    *host = c->ingest_host + (size_t)slot * c->fh * c->fw * 3;
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_ingest_submit(rtvm_ctx* c, int slot, const uint8_t** dev) {
+    if (!c) return RTVM_E_ARG;
+    if (!dev) RTVM_FAIL(c, RTVM_E_ARG, "ingest_submit: null argument");
+    if (slot < 0 || slot >= c->ingest_slots) RTVM_FAIL(c, RTVM_E_ARG, "ingest_submit: slot %d of %d", slot, c->ingest_slots);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t fb = (size_t)c->fh * c->fw * 3;
+    HIP_TRY(c, hipMemcpyAsync(c->ingest_dev + slot * fb, c->ingest_host + slot * fb, fb, hipMemcpyHostToDevice, c->stream_copy));
+    HIP_TRY(c, hipEventRecord(c->ev_ingest, c->stream_copy));
+    c->ingest_used = 1;
+    *dev = c->ingest_dev + slot * fb;
+    return RTVM_OK;
+}

@@ -333,6 +333,8 @@ int bind_batch(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, const Fea
         bp.p[j] = ptrs[j];
         c->h_slots[sb + j].bgr = ptrs[j];
     }
+    // frames that came through the ingest ring: the stream that reads them waits for the copies
+    if (c->ingest_used) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_ingest, 0));
     RTVM_LAUNCH(c, k_batch_bind, dim3(1), dim3(64), 0, c->d_slots, sb, n, bp, prev);
     return RTVM_OK;
 }
@@ -503,6 +505,7 @@ extern "C" int rtvm_stream_begin(rtvm_ctx* c, const uint8_t* bgr_dev, int row_of
     int r = need_stream_ctx(c, "stream_begin");
     if (r) return r;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->ingest_used) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_ingest, 0));
     return queue_first_frame(c, bgr_dev, row_off, col_off);
 }
 

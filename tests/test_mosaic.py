@@ -337,3 +337,30 @@ def test_detection_queued_ahead_of_the_canvas_half():
     t = ctx.batch_detect([dev[1].data_ptr()])
     ctx.batch_release(t)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_host_frames_through_the_ingest_ring_give_the_same_mosaic():
+    """rtvm_ingest_*: frames in host memory, copied through pinned slots on a stream of their own while
+    earlier batches are stitched, against the oracle frame by frame (more frames than ring slots per
+    batch set, so slots are reused)."""
+    frames, _ = video(23, seed=14)
+    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=500)
+    om = OracleMosaic(frames[0], nfeatures=500, glue="explicit")
+    ctx._ring = rtvm._ffi.HostFrameRing(ctx, 12)      # four batches of 3
+    st = ctx.process_host_video(frames[0], frames[1:], om.w_offset, om.h_offset, batch=3)
+    want = []
+    for f in frames[1:]:
+        om.process_frame(f)
+        want.append(om.status)
+    assert st.tolist() == want
+    _, _, _, H = ctx.frame_status()
+    assert np.array_equal(H, om.H)
+    assert np.array_equal(ctx.canvas_read(), om.canvas)
+    # slots hand out pinned host memory of the frame's size; a second ring is refused
+    assert ctx.ingest_host_slot(0).shape == (FH, FW, 3)
+    with pytest.raises(RuntimeError):
+        ctx.ingest_reserve(4)
+    with pytest.raises(RuntimeError):
+        ctx.ingest_submit(99)
+    ctx.close()
