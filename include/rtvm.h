@@ -105,6 +105,16 @@ int rtvm_gray(rtvm_ctx* ctx, const uint8_t* bgr, uint8_t* gray);
 int rtvm_orb(rtvm_ctx* ctx, const uint8_t* bgr, int* n_out, float* xy, float* size,
              float* angle_deg, float* response, int32_t* octave, uint8_t* desc);
 
+/* cv2.cvtColor + cv2.SIFT_create(nfeatures).detectAndCompute(gray, None)  main.py:33,111-112,717-718
+ * (the reference's default detector) on a host frame of h x w x 3 u8, OpenCV's defaults for the
+ * other SIFT parameters.  Outputs (capacity rtvm_sift_max_keypoints(nfeatures)): xy n*2 f32,
+ * size, angle_deg, response n f32, octave n i32 (OpenCV's packed octave | layer << 8 | ...),
+ * desc n*128 f32 (integer-valued 0..255).  Keypoints come sorted by (x, y), duplicates removed,
+ * the nfeatures strongest kept (ties included).  Allocates its pyramids per call; syncs. */
+int rtvm_sift_max_keypoints(int nfeatures);
+int rtvm_sift(rtvm_ctx* ctx, const uint8_t* bgr, int h, int w, int nfeatures, int* n_out, float* xy,
+              float* size, float* angle_deg, float* response, int32_t* octave, float* desc);
+
 /* cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(q, t)  main.py:37,695.
  * q: nq*32 u8, t: nt*32 u8; outputs have capacity nq; matches are emitted in
  * ascending query index.  nq, nt <= 65535. */

@@ -39,6 +39,11 @@ int rtvm_oracle_orb(const uint8_t* bgr, int h, int w, int nfeatures, int* n_out,
 int rtvm_oracle_orb_pyramid(const uint8_t* gray, int h, int w, int* level_h, int* level_w,
                             uint8_t* pyr, uint8_t* pyr_blur);
 
+/* main.py:33,112,718  cv2.SIFT_create(n).detectAndCompute on a BGR frame; desc: n x 128 f32 */
+int rtvm_oracle_sift_max_keypoints(int nfeatures);
+int rtvm_oracle_sift(const uint8_t* bgr, int h, int w, int nfeatures, int* n_out, float* xy,
+                     float* size, float* angle_deg, float* response, int32_t* octave, float* desc);
+
 /* main.py:37,695 (+698 when sorted != 0) */
 int rtvm_oracle_match_hamming_xcheck(const uint8_t* q, int nq, const uint8_t* t, int nt,
                                      int32_t* qidx, int32_t* tidx, int32_t* dist, int* m_out,

@@ -46,6 +46,8 @@ SIGNATURES = {
     "rtvm_distance_transform": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "rtvm_warp_blend": (C.c_int, [_vp, _vp, _vp]),
     "rtvm_canvas_read": (C.c_int, [_vp, _vp]),
+    "rtvm_sift_max_keypoints": (C.c_int, [C.c_int]),
+    "rtvm_sift": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _intp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtvm_ingest_reserve": (C.c_int, [_vp, C.c_int]),
     "rtvm_ingest_host_slot": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
     "rtvm_ingest_submit": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
@@ -295,6 +297,23 @@ class Context:
 
     def sync(self):
         self._check(lib().rtvm_sync(self._h))
+
+    def sift(self, bgr, nfeatures=700):
+        """cv2.SIFT_create(nfeatures).detectAndCompute on a BGR u8 frame: dict of arrays."""
+        bgr = _c_u8(bgr)
+        cap = lib().rtvm_sift_max_keypoints(int(nfeatures))
+        n = C.c_int(0)
+        xy = np.empty((cap, 2), np.float32)
+        size = np.empty(cap, np.float32)
+        angle = np.empty(cap, np.float32)
+        resp = np.empty(cap, np.float32)
+        octave = np.empty(cap, np.int32)
+        desc = np.empty((cap, 128), np.float32)
+        self._check(lib().rtvm_sift(self._h, ptr(bgr), bgr.shape[0], bgr.shape[1], int(nfeatures), C.byref(n), ptr(xy),
+                                    ptr(size), ptr(angle), ptr(resp), ptr(octave), ptr(desc)))
+        k = n.value
+        return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=angle[:k].copy(), response=resp[:k].copy(),
+                    octave=octave[:k].copy(), desc=desc[:k].copy())
 
     # ---- mosaic finalisation (main.py:980-1038) -------------------------------
     def crop_rect(self, image, threshold=15):

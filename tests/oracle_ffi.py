@@ -170,3 +170,22 @@ def resize_linear(bgr, new_w, new_h):
     rc = lib().rtvm_oracle_resize_linear(_p(bgr), bgr.shape[0], bgr.shape[1], _p(out), int(new_h), int(new_w))
     assert rc == 0
     return out
+
+
+def sift(bgr, nfeatures):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w = bgr.shape[:2]
+    cap = lib().rtvm_oracle_sift_max_keypoints(nfeatures)
+    n = C.c_int(0)
+    xy = np.empty((cap, 2), np.float32)
+    size = np.empty(cap, np.float32)
+    angle = np.empty(cap, np.float32)
+    resp = np.empty(cap, np.float32)
+    octave = np.empty(cap, np.int32)
+    desc = np.empty((cap, 128), np.float32)
+    rc = lib().rtvm_oracle_sift(_p(bgr), h, w, nfeatures, C.byref(n), _p(xy), _p(size), _p(angle), _p(resp),
+                                _p(octave), _p(desc))
+    assert rc == 0, rc
+    k = n.value
+    return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=angle[:k].copy(), response=resp[:k].copy(),
+                octave=octave[:k].copy(), desc=desc[:k].copy())
