@@ -50,6 +50,7 @@ class VideMosaic:
         flags = _ffi.FLAG_WARP_FIXED if warp_mode == "fixed" else 0
         det = _ffi.DET_ORB if detector_type == "orb" else _ffi.DET_SIFT_MATCH_ONLY
         self._ctx = _ffi.Context(fh, fw, self._ch, self._cw, det, nfeatures, flags, device)
+        self._nfeatures = nfeatures
         self._cache = {}
         self._canvas_cache = None
 
@@ -73,20 +74,35 @@ class VideMosaic:
     # ------------------------------------------------------------------ frames
     def process_first_frame(self, first_image):
         """main.py:104-112 plus the canvas set-up of main.py:80-90."""
-        if self.detector_type != "orb":
-            raise NotImplementedError(
-                "SIFT detect+describe is not built yet; construct with detector_type='orb' "
-                "(the SIFT matcher, VideMosaic.match, is available)")
         self.frame_prev = first_image
         self.frame_cur = first_image
-        self._ctx.first_frame(first_image, self.w_offset, self.h_offset)
+        if self.detector_type == "sift":
+            # stage by stage, the way the reference itself runs: features, canvas
+            self._sift_prev = self._ctx.sift(first_image, self._nfeatures)
+            self._sift_cur = self._sift_prev
+            self._sift_matches = []
+            self._ctx.canvas_init(first_image, self.w_offset, self.h_offset)
+        else:
+            self._ctx.first_frame(first_image, self.w_offset, self.h_offset)
         self._cache.clear()
         self._canvas_cache = None
 
     def process_frame(self, frame_cur, frame_count):
         """main.py:710-759."""
         self.frame_cur = frame_cur
-        n_matches, found, H_relative = self._ctx.frame_register(frame_cur)
+        if self.detector_type == "sift":
+            # main.py:716-731 with the SIFT branch of match(): detect, knn-2 + ratio, RANSAC
+            cur = self._sift_cur = self._ctx.sift(frame_cur, self._nfeatures)
+            prev = self._sift_prev
+            ms = self._sift_matches = self.match(cur["desc"], prev["desc"]) if len(cur["xy"]) and len(prev["xy"]) >= 2 else []
+            n_matches, found, H_relative = len(ms), False, None
+            if n_matches >= 4:
+                qi = np.array([m.queryIdx for m in ms])
+                ti = np.array([m.trainIdx for m in ms])
+                H_relative, _ = _stage_ctx().find_homography(cur["xy"][qi], prev["xy"][ti], 2.0)
+                found = H_relative is not None
+        else:
+            n_matches, found, H_relative = self._ctx.frame_register(frame_cur)
         self._cache.clear()
         if n_matches < 4:
             print(f"Предупреждение: Недостаточно совпадений ({n_matches}), пропуск кадра")
@@ -101,7 +117,11 @@ class VideMosaic:
             self.last_valid_H = H_relative.copy()
         H_relative_smoothed = self.smooth_homography(H_relative)
         self.H = np.matmul(self.H_old, H_relative_smoothed)
-        self._ctx.frame_commit(self.H)
+        if self.detector_type == "sift":
+            self._ctx.warp_blend(frame_cur, self.H)   # main.py:748
+            self._sift_prev = self._sift_cur          # main.py:757-758
+        else:
+            self._ctx.frame_commit(self.H)
         self._canvas_cache = None
         self.H_old = self.H
         self.frame_prev = self.frame_cur
@@ -109,6 +129,8 @@ class VideMosaic:
 
     # ------------------------------------------------------------------ lazily fetched state
     def _features(self, slot):
+        if self.detector_type == "sift":
+            return self._sift_cur if slot == 0 else self._sift_prev
         key = "feat%d" % slot
         if key not in self._cache:
             self._cache[key] = self._ctx.get_features(slot)
@@ -136,6 +158,8 @@ class VideMosaic:
 
     @property
     def matches(self):
+        if self.detector_type == "sift":
+            return self._sift_matches
         if "matches" not in self._cache:
             self._cache["matches"] = matches_from_arrays(*self._ctx.get_matches())
         return self._cache["matches"]

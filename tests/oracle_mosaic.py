@@ -15,7 +15,7 @@ FEW, NO_H, INVALID = 1, 2, 4
 
 class OracleMosaic:
     def __init__(self, first_image, output_height_times=2, output_width_times=1.2, nfeatures=700,
-                 canvas_size=None, fixed=False, glue="numpy"):
+                 canvas_size=None, fixed=False, glue="numpy", detector="orb"):
         fh, fw = first_image.shape[:2]
         if canvas_size is None:
             canvas_size = (int(output_height_times * fh), int(output_width_times * fw))
@@ -23,7 +23,8 @@ class OracleMosaic:
         self.nfeatures, self.fixed, self.glue = nfeatures, int(fixed), glue
         self.w_offset = int(self.ch / 1 - fh / 1)
         self.h_offset = int(self.cw / 2 - fw / 2)
-        self.feat_prev = orc.orb(first_image, nfeatures)
+        self.detector = detector
+        self.feat_prev = self.detect(first_image)
         self.canvas = np.zeros((self.ch, self.cw, 3), np.uint8)
         self.canvas[self.w_offset:self.w_offset + fh, self.h_offset:self.h_offset + fw] = first_image
         self.H_old = np.eye(3)
@@ -84,9 +85,22 @@ class OracleMosaic:
                 C[r, c] = (A[r, 0] * B[0, c] + A[r, 1] * B[1, c]) + A[r, 2] * B[2, c]
         return C
 
+    def detect(self, frame):
+        return orc.sift(frame, self.nfeatures) if self.detector == "sift" else orc.orb(frame, self.nfeatures)
+
+    def match(self, cur, prev):
+        if self.detector != "sift":
+            return orc.match_hamming(cur["desc"], prev["desc"], True)
+        # main.py:688-692, 698: knn-2, Lowe's ratio 0.7 (a float64 product in Python), stable sort by distance
+        idx, dist = orc.match_l2_knn2(cur["desc"], prev["desc"])
+        keep = dist[:, 0].astype(np.float64) < 0.7 * dist[:, 1].astype(np.float64)
+        qi = np.nonzero(keep)[0]
+        qi = qi[np.argsort(dist[qi, 0], kind="stable")]
+        return qi, idx[qi, 0], dist[qi, 0]
+
     def process_frame(self, frame):
-        cur = orc.orb(frame, self.nfeatures)
-        qi, ti, di = orc.match_hamming(cur["desc"], self.feat_prev["desc"], True)
+        cur = self.detect(frame)
+        qi, ti, di = self.match(cur, self.feat_prev)
         self.feat_cur, self.matches = cur, (qi, ti, di)
         self.n_matches = len(qi)
         if len(qi) < 4:

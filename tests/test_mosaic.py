@@ -118,8 +118,6 @@ def test_stage_methods(capsys):
     assert c[0].tolist() == [[2, -3], [FW + 2, -3], [FW + 2, FH - 4], [2, FH - 4]]
     out = vm.warp(frames[2], vm.H_old)
     assert out.dtype == np.float64 and out.shape == vm.output_img.shape
-    with pytest.raises(NotImplementedError):
-        rtvm.VideMosaic(frames[0], detector_type="sift")
     vm.close()
 
 
@@ -364,3 +362,24 @@ def test_host_frames_through_the_ingest_ring_give_the_same_mosaic():
     with pytest.raises(RuntimeError):
         ctx.ingest_submit(99)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_dropin_with_the_default_sift_detector_matches_oracle(capsys):
+    """VideMosaic(first_image) with the reference's default detector_type="sift": SIFT features, knn-2 + ratio
+    matches (main.py:688-692), RANSAC, warp + blend, frame by frame against the oracle."""
+    frames, _ = video(6, seed=15)
+    vm = rtvm.VideMosaic(frames[0], visualize=False, show_intermediate=False, nfeatures=400)
+    assert vm.detector_type == "sift"
+    om = OracleMosaic(frames[0], nfeatures=400, detector="sift")
+    for t, f in enumerate(frames[1:], 1):
+        vm.process_frame(f, t)
+        om.process_frame(f)
+        assert om.status == 0 and om.n_matches > 30
+        assert len(vm.matches) == om.n_matches
+        assert [(m.queryIdx, m.trainIdx) for m in vm.matches] == list(zip(om.matches[0].tolist(), om.matches[1].tolist()))
+        assert np.array_equal(vm.H, om.H)
+    assert np.array_equal(vm.des_prev, om.feat_prev["desc"]) and vm.des_prev.shape[1] == 128
+    assert len(vm.kp_prev) == len(om.feat_prev["xy"])
+    assert np.array_equal(vm.output_img, om.canvas.astype(np.float64))
+    vm.close()

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Times SIFT detect + describe (rtvm_sift) and the drop-in class with detector_type="sift" on synthetic frames,
+next to the CPU oracle."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+rtvm = importlib.import_module("real-time-video-mosaic_amd")
+import oracle_ffi as orc
+for (fh, fw, nf) in [(720, 1280, 700), (1080, 1920, 2000)]:
+    n = 6
+    Gs, wh, ww = rtvm.synth.bounded_path(n + 1, fh, fw, seed=2)
+    world = rtvm.synth.make_world(wh, ww, seed=0)
+    frames = [rtvm.synth.render_frame(world, G, fh, fw) for G in Gs[:n + 1]] if hasattr(rtvm.synth, "render_frame") else None
+    if frames is None:
+        import torch
+        fr = rtvm.synth.render_video_torch(world, Gs, fh, fw, torch.device("cuda", 0))
+        frames = list(fr.cpu().numpy())
+    ctx = rtvm.Context()
+    ctx.sift(frames[0], nf)
+    t0 = time.perf_counter()
+    for f in frames[1:4]:
+        got = ctx.sift(f, nf)
+    t_gpu = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    want = orc.sift(frames[3], nf)
+    t_cpu = time.perf_counter() - t0
+    same = all(np.array_equal(got[k], want[k]) for k in got)
+    ctx.close()
+    vm = rtvm.VideMosaic(frames[0], visualize=False, show_intermediate=False, nfeatures=nf)
+    t0 = time.perf_counter()
+    for t, f in enumerate(frames[1:], 1):
+        vm.process_frame(f, t)
+    t_vm = (time.perf_counter() - t0) / n
+    print("%dx%d n=%d: rtvm_sift %.1f ms (%d keypoints), oracle %.0f ms, equal %s; drop-in frame %.1f ms = %.1f frames/s, %d matches"
+          % (fh, fw, nf, t_gpu * 1e3, len(got["xy"]), t_cpu * 1e3, same, t_vm * 1e3, 1 / t_vm, len(vm.matches)))
+    vm.close()
