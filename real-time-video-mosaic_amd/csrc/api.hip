@@ -293,6 +293,11 @@ int alloc_all(rtvm_ctx* c) {
 }
 
 void free_all(rtvm_ctx* c) {
+    for (int i = 0; i < 8; i++) {
+        if (c->sift_buf[i]) (void)hipFree(c->sift_buf[i]);
+        c->sift_buf[i] = nullptr;
+        c->sift_bytes[i] = 0;
+    }
     if (c->stream_copy) {
         (void)hipStreamSynchronize(c->stream_copy);
         (void)hipStreamDestroy(c->stream_copy);

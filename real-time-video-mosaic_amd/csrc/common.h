@@ -228,6 +228,10 @@ struct rtvm_ctx {
     hipEvent_t ev_feat[RTVM_NSETS];   // detection + matching of the batch in slot set k is complete
     hipEvent_t ev_front[RTVM_NSETS];  // RANSAC polish of the batch in slot set k is complete
     hipEvent_t ev_back[RTVM_NSETS];   // canvas half of the batch that used slot set k is complete
+    // rtvm_sift's device buffers (pyramids, frame, candidate keys, ...), kept between calls and
+    // grown on demand
+    void* sift_buf[8];
+    size_t sift_bytes[8];
     // frame ingest ring (rtvm_ingest_*): pinned host slots the caller decodes into, device slots
     // they are copied to on a stream of their own
     uint8_t* ingest_host;

@@ -11,9 +11,9 @@
 //   k_sift_decimate  next octave = every second pixel of layer 3
 //   k_sift_sub       difference of Gaussians
 //   k_sift_extrema   26-neighbour extrema above the contrast floor -> candidate keys
-//   k_sift_refine    one thread per candidate (keys sorted on the host: octave, layer, row,
+//   k_sift_refine    one wave per candidate (keys sorted on the host: octave, layer, row,
 //                    column): adjustLocalExtrema, orientation histogram, peaks
-//   k_sift_describe  one thread per keypoint: calcSIFTDescriptor
+//   k_sift_describe  one wave per keypoint: calcSIFTDescriptor (samples in parallel, sums in order)
 // Sums that OpenCV accumulates sequentially (orientation and descriptor histograms) are
 // accumulated sequentially by one thread here as well; exp, atan2, cos, sin and pow are
 // evaluated in double precision and rounded to float.  Duplicate removal and
@@ -219,52 +219,72 @@ __device__ __forceinline__ float angle_deg(float y, float x) {
     return a;
 }
 
-__device__ float orientation_hist(const SImg img, int px, int py, int radius, float sigma, float* hist) {
-    const int n = ORI_BINS;
+// calcOrientationHist by one wave: 64 window positions at a time (gradient, exp, atan2, bin),
+// lane 0 adds the weighted magnitudes to the 36 bins in scan order.  Returns the largest
+// smoothed bin; hist (LDS) holds the smoothed histogram.
+__device__ float orientation_hist(const SImg img, int px, int py, int radius, float sigma, float* temphist, float* hist,
+                                  float* s_val, int* s_bin) {
+    const int n = ORI_BINS, lane = threadIdx.x;
     const float expf_scale = -1.f / (2.f * sigma * sigma);
-    float temphist[ORI_BINS];
-    for (int i = 0; i < n; i++) temphist[i] = 0.f;
-    for (int i = -radius; i <= radius; i++) {
-        const int y = py + i;
-        if (y <= 0 || y >= img.h - 1) continue;
-        for (int j = -radius; j <= radius; j++) {
-            const int x = px + j;
-            if (x <= 0 || x >= img.w - 1) continue;
-            const float dx = AT(img, y, x + 1) - AT(img, y, x - 1);
-            const float dy = AT(img, y - 1, x) - AT(img, y + 1, x);
-            const float W = (float)exp((double)((float)(i * i + j * j) * expf_scale));
-            const float ori = angle_deg(dy, dx);
-            const float mag = sqrtf(dx * dx + dy * dy);
-            int bin = __float2int_rn((n / 360.f) * ori);
-            if (bin >= n) bin -= n;
-            if (bin < 0) bin += n;
-            temphist[bin] += W * mag;
+    if (lane < n) temphist[lane] = 0.f;
+    const int side = 2 * radius + 1;
+    const long long total = (long long)side * side;
+    __syncthreads();
+    for (long long base = 0; base < total; base += 64) {
+        const long long t = base + lane;
+        int bin = -1;
+        if (t < total) {
+            const int i = (int)(t / side) - radius, j = (int)(t % side) - radius;
+            const int y = py + i, x = px + j;
+            if (!(y <= 0 || y >= img.h - 1 || x <= 0 || x >= img.w - 1)) {
+                const float dx = AT(img, y, x + 1) - AT(img, y, x - 1);
+                const float dy = AT(img, y - 1, x) - AT(img, y + 1, x);
+                const float W = (float)exp((double)((float)(i * i + j * j) * expf_scale));
+                const float ori = angle_deg(dy, dx);
+                const float mag = sqrtf(dx * dx + dy * dy);
+                bin = __float2int_rn((n / 360.f) * ori);
+                if (bin >= n) bin -= n;
+                if (bin < 0) bin += n;
+                s_val[lane] = W * mag;
+            }
         }
+        s_bin[lane] = bin;
+        __syncthreads();
+        if (lane == 0)
+            for (int l = 0; l < 64; l++)
+                if (s_bin[l] >= 0) temphist[s_bin[l]] += s_val[l];
+        __syncthreads();
     }
-    float maxval = 0;
-    for (int i = 0; i < n; i++) {
+    if (lane < n) {
+        const int i = lane;
         const float m2 = temphist[(i + n - 2) % n], m1 = temphist[(i + n - 1) % n];
         const float p1 = temphist[(i + 1) % n], p2 = temphist[(i + 2) % n];
         hist[i] = (m2 + p2) * (1.f / 16.f) + (m1 + p1) * (4.f / 16.f) + temphist[i] * (6.f / 16.f);
-        maxval = i == 0 ? hist[0] : fmaxf(maxval, hist[i]);
     }
+    __syncthreads();
+    float maxval = hist[0];
+    for (int i = 1; i < n; i++) maxval = fmaxf(maxval, hist[i]);
     return maxval;
 }
 
-// out: per candidate MAX_PEAKS keypoints, npeaks[candidate] of them valid
+// One wave per candidate; out: per candidate MAX_PEAKS keypoints, npeaks[candidate] of them valid.
 __global__ __launch_bounds__(64) void k_sift_refine(const SPyr* __restrict__ P, const unsigned long long* __restrict__ keys,
                                                     int n, SKp* __restrict__ out, int* __restrict__ npeaks) {
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    if (q >= n) return;
+    const int q = blockIdx.x, lane = threadIdx.x;
     const unsigned long long key = keys[q];
     const int o = (int)(key >> 56), c0 = (int)(key & 0xFFFFFF), r0 = (int)((key >> 24) & 0xFFFFFF);
     int layer = (int)((key >> 48) & 0xFF), r = r0, c = c0;
-    npeaks[q] = 0;
     SKp kp;
-    if (!adjust_extremum(P, o, layer, r, c, kp)) return;
+    if (!adjust_extremum(P, o, layer, r, c, kp)) {  // the same in every lane
+        if (lane == 0) npeaks[q] = 0;
+        return;
+    }
+    __shared__ float temphist[ORI_BINS], hist[ORI_BINS], s_val[64];
+    __shared__ int s_bin[64];
     const float scl_octv = kp.size * 0.5f / (float)(1 << o);
-    float hist[ORI_BINS];
-    const float omax = orientation_hist(P->gp[o * (SL + 3) + layer], c, r, __float2int_rn(4.5f * scl_octv), 1.5f * scl_octv, hist);
+    const float omax = orientation_hist(P->gp[o * (SL + 3) + layer], c, r, __float2int_rn(4.5f * scl_octv), 1.5f * scl_octv,
+                                        temphist, hist, s_val, s_bin);
+    if (lane != 0) return;
     const float mag_thr = omax * 0.8f;
     int peaks = 0;
     for (int j = 0; j < ORI_BINS && peaks < MAX_PEAKS; j++) {
@@ -281,10 +301,13 @@ __global__ __launch_bounds__(64) void k_sift_refine(const SPyr* __restrict__ P, 
     npeaks[q] = peaks;
 }
 
+// One wave per keypoint.  The lanes evaluate 64 consecutive sample positions of the window at a
+// time (gradient, exp, atan2, the eight trilinear shares and the bin index); lane 0 then adds
+// the shares to the histogram in LDS in scan order, which is the order of OpenCV's sequential
+// loop, so the float sums come out the same.
 __global__ __launch_bounds__(64) void k_sift_describe(const SPyr* __restrict__ P, const SKp* __restrict__ kps, int n,
                                                       float* __restrict__ desc) {
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    if (q >= n) return;
+    const int q = blockIdx.x, lane = threadIdx.x;
     const SKp kp = kps[q];
     const int oct = kp.octave & 255, layer = (kp.octave >> 8) & 255;
     const float scale_oct = 1.f / (float)(1 << oct);
@@ -303,47 +326,69 @@ __global__ __launch_bounds__(64) void k_sift_describe(const SPyr* __restrict__ P
     radius = min(radius, (int)sqrt((double)img.w * img.w + (double)img.h * img.h));
     cos_t /= hist_width;
     sin_t /= hist_width;
-    float hist[(SD + 2) * (SD + 2) * (SNB + 2)];
-    for (int i = 0; i < (SD + 2) * (SD + 2) * (SNB + 2); i++) hist[i] = 0.f;
-    for (int i = -radius; i <= radius; i++)
-        for (int j = -radius; j <= radius; j++) {
+    constexpr int HLEN = (SD + 2) * (SD + 2) * (SNB + 2);
+    __shared__ float hist[HLEN];
+    __shared__ float s_v[64][8];
+    __shared__ int s_idx[64];
+    for (int i = lane; i < HLEN; i += 64) hist[i] = 0.f;
+    const int side = 2 * radius + 1;
+    const long long total = (long long)side * side;
+    for (long long base = 0; base < total; base += 64) {
+        const long long t = base + lane;
+        int idx = -1;
+        if (t < total) {
+            const int i = (int)(t / side) - radius, j = (int)(t % side) - radius;
             const float c_rot = j * cos_t - i * sin_t;
             const float r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f;
             float cbin = c_rot + d / 2 - 0.5f;
             const int r = py + i, c = px + j;
-            if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < img.h - 1 && c > 0 && c < img.w - 1)) continue;
-            const float dx = AT(img, r, c + 1) - AT(img, r, c - 1);
-            const float dy = AT(img, r - 1, c) - AT(img, r + 1, c);
-            const float W = (float)exp((double)((c_rot * c_rot + r_rot * r_rot) * exp_scale));
-            const float Ori = angle_deg(dy, dx);
-            const float Mag = sqrtf(dx * dx + dy * dy);
-            float obin = (Ori - ori) * bins_per_rad;
-            const float mag = Mag * W;
-            const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
-            int o0 = (int)floorf(obin);
-            rbin -= r0;
-            cbin -= c0;
-            obin -= o0;
-            if (o0 < 0) o0 += nb;
-            if (o0 >= nb) o0 -= nb;
-            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
-            const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
-            const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
-            const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-            const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (nb + 2) + o0;
-            hist[idx] += v_rco000;
-            hist[idx + 1] += v_rco001;
-            hist[idx + (nb + 2)] += v_rco010;
-            hist[idx + (nb + 3)] += v_rco011;
-            hist[idx + (d + 2) * (nb + 2)] += v_rco100;
-            hist[idx + (d + 2) * (nb + 2) + 1] += v_rco101;
-            hist[idx + (d + 3) * (nb + 2)] += v_rco110;
-            hist[idx + (d + 3) * (nb + 2) + 1] += v_rco111;
+            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < img.h - 1 && c > 0 && c < img.w - 1) {
+                const float dx = AT(img, r, c + 1) - AT(img, r, c - 1);
+                const float dy = AT(img, r - 1, c) - AT(img, r + 1, c);
+                const float W = (float)exp((double)((c_rot * c_rot + r_rot * r_rot) * exp_scale));
+                const float Ori = angle_deg(dy, dx);
+                const float Mag = sqrtf(dx * dx + dy * dy);
+                float obin = (Ori - ori) * bins_per_rad;
+                const float mag = Mag * W;
+                const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+                int o0 = (int)floorf(obin);
+                rbin -= r0;
+                cbin -= c0;
+                obin -= o0;
+                if (o0 < 0) o0 += nb;
+                if (o0 >= nb) o0 -= nb;
+                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+                const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+                const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+                const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+                const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+                idx = ((r0 + 1) * (d + 2) + c0 + 1) * (nb + 2) + o0;
+                s_v[lane][0] = v_rco000, s_v[lane][1] = v_rco001, s_v[lane][2] = v_rco010, s_v[lane][3] = v_rco011;
+                s_v[lane][4] = v_rco100, s_v[lane][5] = v_rco101, s_v[lane][6] = v_rco110, s_v[lane][7] = v_rco111;
+            }
         }
+        s_idx[lane] = idx;
+        __syncthreads();
+        if (lane == 0) {
+            for (int l = 0; l < 64; l++) {
+                const int k = s_idx[l];
+                if (k < 0) continue;
+                hist[k] += s_v[l][0];
+                hist[k + 1] += s_v[l][1];
+                hist[k + (nb + 2)] += s_v[l][2];
+                hist[k + (nb + 3)] += s_v[l][3];
+                hist[k + (d + 2) * (nb + 2)] += s_v[l][4];
+                hist[k + (d + 2) * (nb + 2) + 1] += s_v[l][5];
+                hist[k + (d + 3) * (nb + 2)] += s_v[l][6];
+                hist[k + (d + 3) * (nb + 2) + 1] += s_v[l][7];
+            }
+        }
+        __syncthreads();
+    }
+    if (lane != 0) return;
     float* __restrict__ dst = desc + (size_t)q * 128;
     for (int i = 0; i < d; i++)
         for (int j = 0; j < d; j++) {
@@ -397,12 +442,29 @@ bool kp_less(const SKp& a, const SKp& b) {
     return a.octave > b.octave;
 }
 
+// Buffer `slot` of the context with room for `bytes`: kept between calls, replaced by a larger
+// one when needed (the stream is idle then: every call ends with a sync).
+int sift_buffer(rtvm_ctx* c, int slot, size_t bytes, void** out) {
+    if (c->sift_bytes[slot] < bytes) {
+        if (c->sift_buf[slot]) (void)hipFree(c->sift_buf[slot]);
+        c->sift_buf[slot] = nullptr;
+        c->sift_bytes[slot] = 0;
+        const size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&c->sift_buf[slot], want);
+        if (e != hipSuccess) RTVM_FAIL(c, RTVM_E_NOMEM, "sift: hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        c->sift_bytes[slot] = want;
+    }
+    *out = c->sift_buf[slot];
+    return RTVM_OK;
+}
 struct Dev {
     void* p = nullptr;
-    ~Dev() {
-        if (p) (void)hipFree(p);
-    }
 };
+#define SIFT_BUF(c, slot, dev, bytes)                                   \
+    do {                                                                \
+        int r_ = sift_buffer((c), (slot), (size_t)(bytes), &(dev).p);   \
+        if (r_ != RTVM_OK) return r_;                                   \
+    } while (0)
 
 dim3 grid2(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 
@@ -453,11 +515,11 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
     total += (size_t)bh * bw;
     const int cand_cap = 1 << 18;
     Dev arena, frame, keys, count, pyr, cand_out, cand_np, kp_dev, desc_dev;
-    HIP_TRY(c, hipMalloc(&arena.p, total * sizeof(float)));
-    HIP_TRY(c, hipMalloc(&frame.p, (size_t)h * w * 3));
-    HIP_TRY(c, hipMalloc(&keys.p, (size_t)cand_cap * 8));
-    HIP_TRY(c, hipMalloc(&count.p, sizeof(int)));
-    HIP_TRY(c, hipMalloc(&pyr.p, sizeof(SPyr)));
+    SIFT_BUF(c, 0, arena, total * sizeof(float));
+    SIFT_BUF(c, 1, frame, (size_t)h * w * 3);
+    SIFT_BUF(c, 2, keys, (size_t)cand_cap * 8);
+    SIFT_BUF(c, 3, count, sizeof(int));
+    SIFT_BUF(c, 4, pyr, sizeof(SPyr));
     float* A = (float*)arena.p;
     for (size_t i = 0; i < off_gp.size(); i++) P.gp[i].px = A + off_gp[i];
     for (size_t i = 0; i < off_dog.size(); i++) P.dog[i].px = A + off_dog[i];
@@ -513,9 +575,9 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
         HIP_TRY(c, hipMemcpy(hk.data(), keys.p, (size_t)n_cand * 8, hipMemcpyDeviceToHost));
         std::sort(hk.begin(), hk.end());  // octave, layer, row, column
         HIP_TRY(c, hipMemcpyAsync(keys.p, hk.data(), (size_t)n_cand * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMalloc(&cand_out.p, (size_t)n_cand * MAX_PEAKS * sizeof(SKp)));
-        HIP_TRY(c, hipMalloc(&cand_np.p, (size_t)n_cand * sizeof(int)));
-        RTVM_LAUNCH(c, k_sift_refine, dim3((n_cand + 63) / 64), dim3(64), 0, (const SPyr*)pyr.p,
+        SIFT_BUF(c, 5, cand_out, (size_t)n_cand * MAX_PEAKS * sizeof(SKp));
+        SIFT_BUF(c, 6, cand_np, (size_t)n_cand * sizeof(int));
+        RTVM_LAUNCH(c, k_sift_refine, dim3(n_cand), dim3(64), 0, (const SPyr*)pyr.p,
                     (const unsigned long long*)keys.p, n_cand, (SKp*)cand_out.p, (int*)cand_np.p);
         HIP_TRY(c, hipGetLastError());
         std::vector<SKp> ho((size_t)n_cand * MAX_PEAKS);
@@ -546,10 +608,10 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
     const int n = std::min((int)uniq.size(), rtvm_sift_max_keypoints(nfeatures));
     *n_out = n;
     if (n == 0) return RTVM_OK;
-    HIP_TRY(c, hipMalloc(&kp_dev.p, (size_t)n * sizeof(SKp)));
-    HIP_TRY(c, hipMalloc(&desc_dev.p, (size_t)n * 128 * sizeof(float)));
+    SIFT_BUF(c, 7, kp_dev, (size_t)n * (sizeof(SKp) + 128 * sizeof(float)) + 256);
+    desc_dev.p = (char*)kp_dev.p + (((size_t)n * sizeof(SKp) + 255) & ~(size_t)255);
     HIP_TRY(c, hipMemcpyAsync(kp_dev.p, uniq.data(), (size_t)n * sizeof(SKp), hipMemcpyHostToDevice, c->stream));
-    RTVM_LAUNCH(c, k_sift_describe, dim3((n + 63) / 64), dim3(64), 0, (const SPyr*)pyr.p, (const SKp*)kp_dev.p, n,
+    RTVM_LAUNCH(c, k_sift_describe, dim3(n), dim3(64), 0, (const SPyr*)pyr.p, (const SKp*)kp_dev.p, n,
                 (float*)desc_dev.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(desc, desc_dev.p, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
