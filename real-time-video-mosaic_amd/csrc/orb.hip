@@ -45,10 +45,25 @@ __global__ __launch_bounds__(256) void k_gray(const FrameSlot* __restrict__ slot
     uint8_t* __restrict__ out = S.pyr + off0;
     if (blockIdx.x == 0 && blockIdx.y == 0)
         for (int i = threadIdx.x; i < RTVM_NLEVELS + RTVM_NLEVELS * 256; i += 256) S.cand_count[i] = 0;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    // four pixels per lane: twelve bytes in (three unaligned-safe word loads), one word out
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
     if (x >= w) return;
     const uint8_t* p = bgr + ((size_t)y * w + x) * 3;
-    out[(size_t)y * pitch + x] = (uint8_t)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15);
+    if (x + 4 <= w) {
+        uint32_t v[3];
+        __builtin_memcpy(v, p, 12);
+        const uint32_t b0 = v[0] & 255, g0 = (v[0] >> 8) & 255, r0 = (v[0] >> 16) & 255, b1 = v[0] >> 24;
+        const uint32_t g1 = v[1] & 255, r1 = (v[1] >> 8) & 255, b2 = (v[1] >> 16) & 255, g2 = v[1] >> 24;
+        const uint32_t r2 = v[2] & 255, b3 = (v[2] >> 8) & 255, g3 = (v[2] >> 16) & 255, r3 = v[2] >> 24;
+        const uint32_t y0 = (b0 * 3735 + g0 * 19235 + r0 * 9798 + (1 << 14)) >> 15;
+        const uint32_t y1 = (b1 * 3735 + g1 * 19235 + r1 * 9798 + (1 << 14)) >> 15;
+        const uint32_t y2 = (b2 * 3735 + g2 * 19235 + r2 * 9798 + (1 << 14)) >> 15;
+        const uint32_t y3 = (b3 * 3735 + g3 * 19235 + r3 * 9798 + (1 << 14)) >> 15;
+        *reinterpret_cast<uint32_t*>(out + (size_t)y * pitch + x) = y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
+    } else {
+        for (int i = 0; x + i < w; i++)
+            out[(size_t)y * pitch + x + i] = (uint8_t)((p[3 * i] * 3735 + p[3 * i + 1] * 19235 + p[3 * i + 2] * 9798 + (1 << 14)) >> 15);
+    }
 }
 
 // INTER_LINEAR_EXACT: 8.8 coefficients (xw/yw = weight of the second tap, 0xFFFF = clamped
@@ -742,7 +757,7 @@ int rtvm_orb_setup(rtvm_ctx* c) {
 int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
     const OrbDev& P = c->orb;
     const FrameSlot* sl = c->d_slots;
-    RTVM_LAUNCH(c, k_gray, dim3((P.w[0] + 255) / 256, P.h[0], nb), dim3(256), 0, sl, sb, P.off[0], P.w[0], P.h[0],
+    RTVM_LAUNCH(c, k_gray, dim3((P.w[0] + 1023) / 1024, P.h[0], nb), dim3(256), 0, sl, sb, P.off[0], P.w[0], P.h[0],
                 P.pitch[0]);
     for (int l = 1; l < RTVM_NLEVELS; l++)
         RTVM_LAUNCH(c, k_resize, dim3((P.w[l] + 63) / 64, (P.h[l] + 15) / 16, nb), dim3(256), 0, sl, sb, P.off[l - 1],
