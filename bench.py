@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--path", default="bounded", choices=["bounded", "drift"],
                     help="camera path: 'bounded' keeps every frame inside the canvas for any number of frames; "
                          "'drift' moves 2 px/frame right and up for ever (leaves the 1.2x-wide canvas after ~64 frames)")
+    ap.add_argument("--canvas-batch", type=int, default=0,
+                    help="frames per canvas-half piece (0 = half a batch)")
     ap.add_argument("--host-frames", type=int, default=256,
                     help="frames of the video also run from host memory through the ingest ring (0 = skip)")
     ap.add_argument("--dropin-frames", type=int, default=32,
@@ -176,7 +178,8 @@ def main():
     def run(first, count):
         # frames first .. first+count-1 in batches of up to B, three batches in flight; frames that
         # come back pending (see Context.process_video) are queued again, so every frame is stitched
-        st = ctx.process_video([base + (first + j) * stride for j in range(count)], batch=B)
+        st = ctx.process_video([base + (first + j) * stride for j in range(count)], batch=B,
+                               canvas_batch=args.canvas_batch)
         return st, dict(ctx.video_stats)
 
     ctx.stream_begin(base, row_off, col_off)
@@ -225,9 +228,9 @@ def main():
         launches, total_ms = dom[0], dom[1]
         avg_s = total_ms / launches * 1e-3
         ab_frame = algorithmic_bytes(dominant, fh, fw, ch, cw, nf, roi_px, B)
-        # frames that went through the canvas-half kernels: those of the batches that were not void,
+        # frames that went through the canvas-half kernels: those of the pieces that were not void,
         # plus the ones whose canvas half was queued again
-        K_back = vstats["frames_queued"] - vstats["frames_void"] + vstats["frames_retried"]
+        K_back = vstats["canvas_frames"] - vstats["frames_void"] + vstats["frames_retried"]
         ab = ab_frame * K_back / launches if ab_frame else None   # mean per launch
         # HBM traffic of the same kernel from the PMC counters of a separate rocprofv3 run (committed
         # summary; the counters cannot be read from inside this process)
@@ -310,7 +313,8 @@ def main():
                        "frames_queued": vstats["frames_queued"], "batches_queued": vstats["batches_queued"],
                        "batches_with_pending_frames": vstats["batches_with_pending_frames"],
                        "canvas_half_retries": vstats["retries"], "frames_retried": vstats["frames_retried"],
-                       "frames_void": vstats["frames_void"]},
+                       "frames_void": vstats["frames_void"], "canvas_pieces": vstats["canvas_pieces"],
+                       "canvas_batch": args.canvas_batch or (B + 1) // 2},
             "roofline": roof, "warp_blend_stage": warp_blend, "cpu_baseline": cpu, "dropin_pcie_inclusive": dropin,
             "host_frames_pcie_inclusive": host_ingest,
         }

@@ -469,100 +469,139 @@ class Context:
         """Frames first .. k-1 of the detected batch `ticket` (video frames start+first ..) came back
         pending although their detection, matching and RANSAC results stand: queues their canvas
         half again, one frame at first (such events come in runs), twice as many after every retry
-        that goes through whole.  Returns None when all k frames are consumed, else the video frame
-        from which detection has to start again (a skipped frame invalidated the matching behind
-        it)."""
-        m = 1
-        while first < k:
-            cnt = min(m, k - first)
-            t2 = self.batch_retry(ticket, first, cnt)
+        that goes through whole.  The next piece is queued before the outcome of the current one
+        is read, so the device does not wait for the host between pieces; when the current one
+        leaves frames pending, that next piece did nothing and is queued again.  Returns None when
+        all k frames are consumed, else the video frame from which detection has to start again (a
+        skipped frame invalidated the matching behind it)."""
+        skip_bits = FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY
+        m, pos, q = 1, first, []   # q: pieces in flight, oldest first: (ticket, first frame of the piece, length)
+
+        def queue():
+            nonlocal pos, m
+            cnt = min(m, k - pos)
+            q.append((self.batch_retry(ticket, pos, cnt), pos, cnt))
             stats["retries"] += 1
             stats["frames_retried"] += cnt
+            pos += cnt
+            m = min(2 * m, k)
+
+        while first < k:
+            while len(q) < 2 and pos < k:
+                queue()
+            t2, p0, cnt = q.pop(0)
             d2, reason, st2, _, _ = self.batch_status_of(t2, cnt)
             if trace is not None:
-                trace.append((time.perf_counter(), start + first, cnt, d2, reason))
-            status[start + first:start + first + d2] = st2[:d2]
-            first += d2
-            if d2 == cnt:
-                if st2[cnt - 1] & (FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY):
-                    return start + first if start + first < len(status) else None
-                m = min(2 * m, k)
-            elif reason == PENDING_MASK:
-                m = 1
-            else:
+                trace.append((time.perf_counter(), start + p0, cnt, d2, reason))
+            status[start + p0:start + p0 + d2] = st2[:d2]
+            first = p0 + d2
+            skipped = d2 > 0 and bool(st2[d2 - 1] & skip_bits)
+            if d2 == cnt and not skipped:
+                continue
+            for t3, _, c3 in q:   # queued behind a piece that left frames pending: void
+                self.batch_status_of(t3, c3)
+                stats["frames_void"] += c3
+            q.clear()
+            if skipped and d2 == cnt:
+                return start + first if start + first < len(status) else None
+            if reason != PENDING_MASK:
                 return start + first
+            m, pos = 1, first
         return None
 
-    def process_video(self, bgr_dev_ptrs, batch=16, trace=None):
+    def process_video(self, bgr_dev_ptrs, batch=16, trace=None, canvas_batch=None):
         """process_frame over a whole list of device-resident frames.  Detection, matching and
-        RANSAC run up to three batches ahead (rtvm_batch_detect) of the canvas half, which is
-        queued batch by batch, two in flight (rtvm_batch_retry).  Frames come back pending (a)
-        behind a blend that cleared a canvas pixel and so broke the canvas masks predicted for the
-        rest of its batch: their canvas half is queued again, in small steps, while detection
-        keeps running ahead; (b) behind a frame the reference skips: the frames detected behind it
-        were matched against the wrong frame, detection starts again from there.
+        RANSAC run up to four batches ahead (rtvm_batch_detect) of the canvas half, which follows in
+        pieces of canvas_batch frames (default: half a batch; rtvm_batch_retry), three in flight.
+        Frames come back pending (a) behind a blend that cleared a canvas pixel and so broke the
+        canvas masks predicted for the rest of its piece: what was computed for them is lost
+        (hence pieces shorter than the detection batches: a piece of 16 frames costs no more per
+        frame than one of 32), the pieces queued behind did nothing, and the rest of that batch is
+        stitched one frame at first and twice as many after every piece that goes through whole,
+        while detection keeps running ahead; (b) behind a frame the reference skips: the frames
+        detected behind it were matched against the wrong frame, detection starts again from there.
         Returns the per-frame status codes; self.video_stats counts what was queued.  trace: a
         list that receives (seconds, first frame, length, frames consumed, reason) for every
         canvas half whose outcome was read."""
         self.reserve_batch(batch)
         n = len(bgr_dev_ptrs)
+        cb = max(1, min(batch, canvas_batch if canvas_batch else (batch + 1) // 2))
         # a frame source (HostFrameRing) hands out device addresses batch by batch; a list has them all
         acquire = getattr(bgr_dev_ptrs, "acquire", None) or (lambda first, k: bgr_dev_ptrs[first:first + k])
         status = np.zeros(n, np.int32)
-        det = []     # detected, canvas half not queued yet: (detect ticket, first frame, length)
-        inb = []     # canvas half queued: (detect ticket, canvas-half ticket, first frame, length)
+        det = []     # detected batches, oldest first: [detect ticket, first frame, length, frames queued, frames consumed]
+        inb = []     # canvas-half pieces in flight, oldest first: (batch entry, piece ticket, first frame of the batch, length)
         nxt = 0      # next frame to detect
         stats = {"frames": n, "batches_queued": 0, "frames_queued": 0, "batches_with_pending_frames": 0,
-                 "retries": 0, "frames_retried": 0, "frames_void": 0, "frames_detected_again": 0}
+                 "retries": 0, "frames_retried": 0, "frames_void": 0, "frames_detected_again": 0,
+                 "canvas_pieces": 0, "canvas_frames": 0}
+        skip_bits = FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY
 
         def start_over(frame):
             # a skipped frame: everything detected behind it is void
             nonlocal nxt
             for rec in det:
                 self.batch_release(rec[0])
-            for rec in inb:
-                self.batch_release(rec[0])
             stats["frames_detected_again"] += nxt - frame
             det.clear()
             inb.clear()
             nxt = frame
 
-        while nxt < n or det or inb:
-            while len(det) + len(inb) < 4 and nxt < n:
+        def drain():
+            # the pieces queued behind a piece that left frames pending did nothing
+            for e2, t2, _, c2 in inb:
+                self.batch_status_of(t2, c2)
+                stats["frames_void"] += c2
+            inb.clear()
+            for e2 in det:
+                e2[3] = e2[4]
+
+        while nxt < n or det:
+            while len(det) < 4 and nxt < n:
                 k = min(batch, n - nxt)
-                t = self.batch_detect(acquire(nxt, k))
+                det.append([self.batch_detect(acquire(nxt, k)), nxt, k, 0, 0])
                 stats["batches_queued"] += 1
                 stats["frames_queued"] += k
-                det.append((t, nxt, k))
                 nxt += k
-            while len(inb) < 2 and det:
-                t, start, k = det.pop(0)
-                inb.append((t, self.batch_retry(t, 0, k), start, k))
-            dt, bt, start, k = inb.pop(0)
-            done, reason, st, _, _ = self.batch_status_of(bt, k)
-            status[start:start + done] = st[:done]
+            while len(inb) < 3:
+                e = next((r for r in det if r[3] < r[2]), None)
+                if e is None:
+                    break
+                cnt = min(cb, e[2] - e[3])
+                inb.append((e, self.batch_retry(e[0], e[3], cnt), e[3], cnt))
+                e[3] += cnt
+                stats["canvas_pieces"] += 1
+                stats["canvas_frames"] += cnt
+            e, bt, off, cnt = inb.pop(0)
+            start = e[1]
+            done, reason, st, _, _ = self.batch_status_of(bt, cnt)
+            status[start + off:start + off + done] = st[:done]
             if trace is not None:
-                trace.append((time.perf_counter(), start, k, done, reason))
-            if done == k:
-                self.batch_release(dt)
-                if st[k - 1] & (FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY) and start + k < n:
-                    if inb:
-                        self.batch_status_of(inb[0][1], inb[0][3])   # void: drain it
-                    start_over(start + k)
+                trace.append((time.perf_counter(), start + off, cnt, done, reason))
+            e[4] = off + done
+            skipped = done > 0 and bool(st[done - 1] & skip_bits)
+            if done == cnt and not skipped:
+                if e[4] == e[2]:
+                    self.batch_release(e[0])
+                    det.remove(e)
+                continue
+            if done == cnt:   # a skipped last frame: what follows was matched against it
+                drain()
+                if start + e[4] < n:
+                    start_over(start + e[4])
+                else:
+                    self.batch_release(e[0])
+                    det.remove(e)
                 continue
             stats["batches_with_pending_frames"] += 1
+            drain()
             if reason != PENDING_MASK:
-                self.batch_release(dt)
-                start_over(start + done)
+                start_over(start + e[4])
                 continue
-            # canvas half again for the rest of this batch, then for the one queued behind it
-            redo = self._stitch_rest(dt, start, k, done, status, stats, trace)
-            self.batch_release(dt)
-            while redo is None and inb:
-                dt, bt, start, k = inb.pop(0)
-                stats["frames_void"] += k   # queued behind the failed batch: its canvas half did nothing
-                redo = self._stitch_rest(dt, start, k, 0, status, stats, trace)
-                self.batch_release(dt)
+            # canvas half again for the rest of this batch; the batches behind it follow in pieces as before
+            redo = self._stitch_rest(e[0], start, e[2], e[4], status, stats, trace)
+            self.batch_release(e[0])
+            det.remove(e)
             if redo is not None:
                 start_over(redo)
         self.video_stats = stats
