@@ -263,7 +263,7 @@ def main():
                       "achieved": wb_bytes / wb_us / 1e3, "unit": "GB/s", "frac": wb_bytes / wb_us / 1e3 / 8000.0,
                       "note": "sum of the main-stream kernels of one full batch (HIP events, un-timed probe)"}
         dropin = None
-        if args.dropin_frames > 0:
+        if args.dropin_frames > 0 and world == 1:
             # the drop-in class as the reference's main loop drives it: one host frame per call
             # (H2D copy + RANSAC read-back + host-side validate/smooth/chain + commit)
             nd = min(args.dropin_frames, T - 1)
@@ -279,7 +279,7 @@ def main():
                               "per frame included"}
             vm.close()
         host_ingest = None
-        if args.host_frames > 0:
+        if args.host_frames > 0 and world == 1:
             # frames in host memory through the ingest ring (pinned slots, copies on a stream of their own)
             # into the same batched pipeline: the PCIe-inclusive rate of the throughput path
             nh = min(args.host_frames, T - 1)
@@ -295,7 +295,7 @@ def main():
                                    "one Python memcpy per frame included" % B}
             ctx2.close()
         cpu = None
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:   # reported at N = 1 only
             frames_np = frames[:args.cpu_frames + 1].cpu().numpy()
             fps_cpu, _ = cpu_baseline(frames_np, cfg, args.cpu_frames)
             cpu = {"value": fps_cpu, "unit": "frames/s", "cores": 1, "kind": "port",
