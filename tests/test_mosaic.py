@@ -383,3 +383,40 @@ def test_dropin_with_the_default_sift_detector_matches_oracle(capsys):
     assert len(vm.kp_prev) == len(om.feat_prev["xy"])
     assert np.array_equal(vm.output_img, om.canvas.astype(np.float64))
     vm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fh,fw,ch,cw,nf,batch", [(1080, 1920, 2160, 2304, 1000, 4), (2160, 3840, 4096, 16384, 4000, 3)])
+def test_full_size_configs_batched_equals_frame_by_frame(fh, fw, ch, cw, nf, batch):
+    """At the 1080p and the 4K / 16384-wide-canvas sizes the oracle is too slow to run per test; what is checked
+    there is the size-independent property of the batched path: any batching of the frames (detection ahead,
+    predicted masks, retries) gives the canvas, homography and status of frame-by-frame processing."""
+    import torch
+    n = 7
+    Gs, wh, ww = rtvm.synth.bounded_path(n + 1, fh, fw, seed=21)
+    world = rtvm.synth.make_world(wh, ww, seed=3, n_shapes=4000)
+    dev = torch.device("cuda", 0)
+    frames = rtvm.synth.render_video_torch(world, Gs, fh, fw, dev)
+    torch.cuda.synchronize()
+    stride = fh * fw * 3
+    base = frames.data_ptr()
+    row_off, col_off = ch - fh, int(cw / 2 - fw / 2)
+    a = rtvm.Context(fh, fw, ch, cw, nfeatures=nf)
+    a.stream_begin(base, row_off, col_off)
+    st_a = []
+    for j in range(1, n + 1):
+        a.process_frame(base + j * stride)
+        st_a.append(a.frame_status()[0])
+    _, _, nm_a, H_a = a.frame_status()
+    canvas_a = a.canvas_read()
+    a.close()
+    b = rtvm.Context(fh, fw, ch, cw, nfeatures=nf)
+    b.stream_begin(base, row_off, col_off)
+    st_b = b.process_video([base + j * stride for j in range(1, n + 1)], batch=batch)
+    _, _, nm_b, H_b = b.frame_status()
+    canvas_b = b.canvas_read()
+    b.close()
+    assert st_a == st_b.tolist() and st_a == [0] * n and nm_a == nm_b and nm_a > 100
+    assert np.array_equal(H_a, H_b)
+    assert np.array_equal(canvas_a, canvas_b)
+    assert canvas_a[row_off:row_off + 8, col_off:col_off + 8].any()
