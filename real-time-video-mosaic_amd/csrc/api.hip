@@ -252,6 +252,7 @@ int alloc_all(rtvm_ctx* c) {
     ALLOC(c, d_gk, 32);
     ALLOC(c, d_H, RTVM_MAX_BATCH * 9 + 16);
     ALLOC(c, d_wp, RTVM_MAX_BATCH);
+    ALLOC(c, d_cbox, 4);
     ALLOC(c, d_jobs, 2 * RTVM_MAX_BATCH + 2);
     ALLOC(c, d_side, RTVM_MAX_BATCH);
     c->h_side = (SideDev*)calloc(RTVM_MAX_BATCH, sizeof(SideDev));
@@ -311,7 +312,7 @@ void free_all(rtvm_ctx* c) {
     c->ingest_slots = 0;
     void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas,
                     c->d_mask_old, c->d_bold, c->d_snap_canvas, c->d_snap_mask, c->d_side, c->d_snap, c->d_gk, c->d_H,
-                    c->d_wp, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
+                    c->d_wp, c->d_cbox, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
                     c->d_skip};
     free_feat(&c->feat_prev);
     for (void* p : ptrs)

@@ -116,7 +116,8 @@ __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restric
         jobs[0]->y1 = jobs[0]->oy1 = y1;
     }
     if (jobs[1]) {
-        // old mask: transform on the whole canvas, distances needed where the weights are
+        // old mask: distances needed where the weights are; the rectangle of the transform (here the
+        // whole canvas) is narrowed by k_old_rects
         jobs[1]->x0 = 0;
         jobs[1]->y0 = 0;
         jobs[1]->x1 = empty ? 0 : cw;
@@ -125,6 +126,44 @@ __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restric
         jobs[1]->oy0 = wp->wy0;
         jobs[1]->ox1 = wp->wx1;
         jobs[1]->oy1 = wp->wy1;
+    }
+}
+
+// The rectangle the distance transform of the canvas mask is computed on, per frame of the batch.
+// The reference transforms the whole canvas, but everything outside the bounding box of what
+// was ever pasted or warped onto it is zero, and a zero pixel beyond the one-pixel ring around
+// that box is never nearer (in 3x3 chamfer steps) than the ring pixel a path to it crosses: the
+// transform on box + ring, joined with the window the weights are read in, gives the same
+// distances.  cbox = bounding box so far (x0, y0, x1, y1; regions of interest, so a superset of
+// the non-zero pixels, which is the safe side); frame j also counts the frames before it in the
+// batch.  One block; thread j = frame j.
+__global__ __launch_bounds__(64) void k_old_rects(const WarpParams* __restrict__ wp, DtJob* __restrict__ jobs_old, int n,
+                                                  int* __restrict__ cbox, int ch, int cw) {
+    const int j = threadIdx.x;
+    int x0 = cbox[0], y0 = cbox[1], x1 = cbox[2], y1 = cbox[3];
+    __syncthreads();
+    if (j < n && wp[j].rx1 > wp[j].rx0) {
+        for (int i = 0; i < j; i++)
+            if (wp[i].rx1 > wp[i].rx0) {
+                x0 = min(x0, wp[i].rx0), y0 = min(y0, wp[i].ry0);
+                x1 = max(x1, wp[i].rx1), y1 = max(y1, wp[i].ry1);
+            }
+        // the ring of zeros around the box, then the window of this frame
+        x0 = min(max(x0 - 1, 0), wp[j].wx0), y0 = min(max(y0 - 1, 0), wp[j].wy0);
+        x1 = max(min(x1 + 1, cw), wp[j].wx1), y1 = max(min(y1 + 1, ch), wp[j].wy1);
+        jobs_old[j].x0 = x0;
+        jobs_old[j].y0 = y0;
+        jobs_old[j].x1 = x1;
+        jobs_old[j].y1 = y1;
+    }
+    if (j == 0) {
+        int b[4] = {cbox[0], cbox[1], cbox[2], cbox[3]};
+        for (int i = 0; i < n; i++)
+            if (wp[i].rx1 > wp[i].rx0) {
+                b[0] = min(b[0], wp[i].rx0), b[1] = min(b[1], wp[i].ry0);
+                b[2] = max(b[2], wp[i].rx1), b[3] = max(b[3], wp[i].ry1);
+            }
+        for (int k = 0; k < 4; k++) cbox[k] = b[k];
     }
 }
 
@@ -578,7 +617,11 @@ __global__ __launch_bounds__(256) void k_commit(const WarpParams* __restrict__ w
 
 __global__ __launch_bounds__(256) void k_canvas_paste(const uint8_t* __restrict__ src, uint8_t* __restrict__ canvas,
                                                       uint8_t* __restrict__ mask_old, int fh, int fw, int ch, int cw,
-                                                      int row_off, int col_off) {
+                                                      int row_off, int col_off, int* __restrict__ cbox) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {  // bounding box of the canvas content
+        cbox[0] = min(max(col_off, 0), cw), cbox[1] = min(max(row_off, 0), ch);
+        cbox[2] = max(min(col_off + fw, cw), 0), cbox[3] = max(min(row_off + fh, ch), 0);
+    }
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= fw || y >= fh) return;
     const int cy = y + row_off, cx = x + col_off;
@@ -635,7 +678,7 @@ int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int 
     HIP_TRY(c, hipMemsetAsync(c->d_canvas, 0, n_px * 3, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_mask_old, 0, n_px, c->stream));
     RTVM_LAUNCH(c, k_canvas_paste, dim3((c->fw + 63) / 64, (c->fh + 3) / 4), dim3(256), 0, d_bgr,
-                       c->d_canvas, c->d_mask_old, c->fh, c->fw, c->ch, c->cw, row_off, col_off);
+                       c->d_canvas, c->d_mask_old, c->fh, c->fw, c->ch, c->cw, row_off, col_off, c->d_cbox);
     HIP_TRY(c, hipGetLastError());
     int r = rtvm_launch_dt_bits(c, c->d_jobs + RTVM_JOB_CANVAS, 1, c->cw, c->ch);
     if (r != RTVM_OK) return r;
@@ -665,6 +708,8 @@ int rtvm_launch_warp_prep(rtvm_ctx* c, const double* d_H, const int* d_skip, int
     if (n < 1 || n > c->n_side) RTVM_FAIL(c, RTVM_E_STATE, "warp: %d frames, planes for %d", n, c->n_side);
     RTVM_LAUNCH(c, k_warp_prep, dim3(n), dim3(64), 0, d_H, c->d_wp, c->d_jobs, c->d_jobs + RTVM_MAX_BATCH, c->fh, c->fw,
                 c->ch, c->cw, 0, d_skip, c->d_state);
+    RTVM_LAUNCH(c, k_old_rects, dim3(1), dim3(64), 0, (const WarpParams*)c->d_wp, c->d_jobs + RTVM_MAX_BATCH, n, c->d_cbox,
+                c->ch, c->cw);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
