@@ -372,18 +372,13 @@ __global__ __launch_bounds__(64) void k_sift_describe(const SPyr* __restrict__ P
         }
         s_idx[lane] = idx;
         __syncthreads();
-        if (lane == 0) {
+        // the eight shares of a sample go to eight different bins: lane e < 8 adds share e of every
+        // sample, in sample order, so every bin still receives its terms in scan order
+        if (lane < 8) {
+            const int ofs = (lane & 1) + ((lane >> 1) & 1) * (nb + 2) + (lane >> 2) * (d + 2) * (nb + 2);
             for (int l = 0; l < 64; l++) {
                 const int k = s_idx[l];
-                if (k < 0) continue;
-                hist[k] += s_v[l][0];
-                hist[k + 1] += s_v[l][1];
-                hist[k + (nb + 2)] += s_v[l][2];
-                hist[k + (nb + 3)] += s_v[l][3];
-                hist[k + (d + 2) * (nb + 2)] += s_v[l][4];
-                hist[k + (d + 2) * (nb + 2) + 1] += s_v[l][5];
-                hist[k + (d + 3) * (nb + 2)] += s_v[l][6];
-                hist[k + (d + 3) * (nb + 2) + 1] += s_v[l][7];
+                if (k >= 0) hist[k + ofs] += s_v[l][lane];
             }
         }
         __syncthreads();
