@@ -252,7 +252,7 @@ int alloc_all(rtvm_ctx* c) {
     ALLOC(c, d_gk, 32);
     ALLOC(c, d_H, RTVM_MAX_BATCH * 9 + 16);
     ALLOC(c, d_wp, RTVM_MAX_BATCH);
-    ALLOC(c, d_cbox, 4);
+    ALLOC(c, d_cbox, 8);
     ALLOC(c, d_jobs, 2 * RTVM_MAX_BATCH + 2);
     ALLOC(c, d_side, RTVM_MAX_BATCH);
     c->h_side = (SideDev*)calloc(RTVM_MAX_BATCH, sizeof(SideDev));

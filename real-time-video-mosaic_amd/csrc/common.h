@@ -228,7 +228,8 @@ struct rtvm_ctx {
     hipEvent_t ev_feat[RTVM_NSETS];   // detection + matching of the batch in slot set k is complete
     hipEvent_t ev_front[RTVM_NSETS];  // RANSAC polish of the batch in slot set k is complete
     hipEvent_t ev_back[RTVM_NSETS];   // canvas half of the batch that used slot set k is complete
-    int* d_cbox;               // bounding box of everything pasted or warped onto the canvas: x0, y0, x1, y1
+    int* d_cbox;               // [8] bounding box of everything pasted or warped onto the canvas: x0, y0, x1, y1;
+                               // then that of the regions of interest of the batch being stitched
     // rtvm_sift's device buffers (pyramids, frame, candidate keys, ...), kept between calls and
     // grown on demand
     void* sift_buf[8];

@@ -163,7 +163,14 @@ __global__ __launch_bounds__(64) void k_old_rects(const WarpParams* __restrict__
                 b[0] = min(b[0], wp[i].rx0), b[1] = min(b[1], wp[i].ry0);
                 b[2] = max(b[2], wp[i].rx1), b[3] = max(b[3], wp[i].ry1);
             }
-        for (int k = 0; k < 4; k++) cbox[k] = b[k];
+        // cbox[4..7]: the box of this batch alone (the commit kernel leaves everything outside it alone)
+        int u[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0, 0};
+        for (int i = 0; i < n; i++)
+            if (wp[i].rx1 > wp[i].rx0) {
+                u[0] = min(u[0], wp[i].rx0), u[1] = min(u[1], wp[i].ry0);
+                u[2] = max(u[2], wp[i].rx1), u[3] = max(u[3], wp[i].ry1);
+            }
+        for (int k = 0; k < 4; k++) cbox[k] = b[k], cbox[4 + k] = u[k];
     }
 }
 
@@ -532,13 +539,15 @@ __global__ __launch_bounds__(256) void k_commit(const WarpParams* __restrict__ w
                                                 int n, uint8_t* __restrict__ mask_old, uint8_t* __restrict__ canvas,
                                                 uint8_t* __restrict__ snap_mask, uint8_t* __restrict__ snap_canvas,
                                                 uint32_t* __restrict__ bold, int wpitch, int ch, int cw,
-                                                StreamState* __restrict__ st) {
+                                                StreamState* __restrict__ st, const int* __restrict__ ubox) {
     int last = n - 1;
     if (REDO) {
         last = st->bad_frame;
         if (last >= n - 1) return;  // every frame was applied with the right weights
     }
     const int bx = blockIdx.x * 64, by = blockIdx.y * 4;
+    // outside the box of the batch's regions of interest nothing happens (most of a large canvas)
+    if (bx >= ubox[2] || bx + 64 <= ubox[0] || by >= ubox[3] || by + 4 <= ubox[1]) return;
     const int x = bx + (threadIdx.x & 63), y = by + (threadIdx.x >> 6);
     // does any frame of the batch touch this wave's 64 pixels?
     bool touched = false;
@@ -759,10 +768,11 @@ int rtvm_launch_commit(rtvm_ctx* c, int n) {
     const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4);
     const int wpitch = (c->cw + 31) / 32 + 2;
     RTVM_LAUNCH(c, k_commit<false>, grid, dim3(256), 0, c->d_wp, c->d_side, n, c->d_mask_old, c->d_canvas, c->d_snap_mask,
-                c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state);
+                c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state, (const int*)(c->d_cbox + 4));
     if (n > 1)
         RTVM_LAUNCH(c, k_commit<true>, grid, dim3(256), 0, c->d_wp, c->d_side, n, c->d_mask_old, c->d_canvas,
-                    c->d_snap_mask, c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state);
+                    c->d_snap_mask, c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state,
+                    (const int*)(c->d_cbox + 4));
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
