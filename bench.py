@@ -176,7 +176,7 @@ def main():
     ctx.reserve_batch(B)
 
     def run(first, count):
-        # frames first .. first+count-1 in batches of up to B, three batches in flight; frames that
+        # frames first .. first+count-1: detection in batches of up to B, the canvas half in pieces; frames that
         # come back pending (see Context.process_video) are queued again, so every frame is stitched
         st = ctx.process_video([base + (first + j) * stride for j in range(count)], batch=B,
                                canvas_batch=args.canvas_batch)
