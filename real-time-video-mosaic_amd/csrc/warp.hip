@@ -445,33 +445,36 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
 // the canvas (main.py:897-898), stored over the distance planes.  A lane takes 4 consecutive
 // rows of one column: a window of 34 row-blurred weight pairs serves the 4 column sums, both
 // weights in one packed operation.  blockIdx.z = frame of the batch.
+// rows per lane in the column pass of the blur (a workgroup of four waves covers 64 x 4*BC_ROWS pixels)
+constexpr int BC_ROWS = 12;
+
 template <bool EDGE>
 __device__ __forceinline__ void blur_cols_window(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
                                                  const SideDev& side, int ch, int cw, int x, int ya,
-                                                 const bool (&need)[4]) {
+                                                 const bool (&need)[BC_ROWS]) {
     const auto rb = as_global<const f32x2>(side.rb);
     const auto out_n = as_global(side.dist_new), out_o = as_global(side.dist_old);
-    f32x2 v[34];
+    f32x2 v[30 + BC_ROWS];
 #pragma unroll
-    for (int j = 0; j < 34; j++) {
+    for (int j = 0; j < 30 + BC_ROWS; j++) {
         const int y = EDGE ? reflect101(ya - 15 + j, ch) : ya - 15 + j;
         v[j] = rb[(size_t)y * cw + x];
     }
-    f32x2 a[4];
+    f32x2 a[BC_ROWS];
     {
         const float k0 = gk[15];
 #pragma unroll
-        for (int i = 0; i < 4; i++) a[i] = f32x2{k0, k0} * v[15 + i];
+        for (int i = 0; i < BC_ROWS; i++) a[i] = f32x2{k0, k0} * v[15 + i];
     }
 #pragma unroll
     for (int t = 1; t <= 15; t++) {
         const float kt = gk[15 + t];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < BC_ROWS; i++)
             a[i] = __builtin_elementwise_fma(v[15 + i + t] + v[15 + i - t], f32x2{kt, kt}, a[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < BC_ROWS; i++)
         if (need[i]) {
             out_n[(size_t)(ya + i) * cw + x] = a[i].x;
             out_o[(size_t)(ya + i) * cw + x] = a[i].y;
@@ -481,41 +484,41 @@ __device__ __forceinline__ void blur_cols_window(const WarpParams* __restrict__ 
 __device__ __forceinline__ void blur_cols_tile(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
                                                const SideDev& side, int ch, int cw, int bx, int by) {
     const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
-    // a wave is 64 columns of 4 rows: the row is the same for all its lanes, and saying so keeps
+    // a wave is 64 columns of BC_ROWS rows: the row is the same for all its lanes, and saying so keeps
     // the row addresses in scalar registers
-    const int x = bx + (threadIdx.x & 63), ya = by + 4 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (x < rx0 || x >= rx1 || ya >= ry1 || ya + 4 <= ry0) return;
+    const int x = bx + (threadIdx.x & 63), ya = by + BC_ROWS * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (x < rx0 || x >= rx1 || ya >= ry1 || ya + BC_ROWS <= ry0) return;
     // every pixel of the ROI gets its weights (only those under the frame's mask are ever read):
     // asking the mask first would put one more memory round trip in front of the window loads
-    bool need[4];
+    bool need[BC_ROWS];
 #pragma unroll
-    for (int i = 0; i < 4; i++) need[i] = ya + i >= ry0 && ya + i < ry1;
+    for (int i = 0; i < BC_ROWS; i++) need[i] = ya + i >= ry0 && ya + i < ry1;
     // only the tiles at the top and bottom of the canvas reflect rows (the same for the whole workgroup)
-    if (by - 15 >= 0 && by + 16 + 15 <= ch)
+    if (by - 15 >= 0 && by + 4 * BC_ROWS + 15 <= ch)
         blur_cols_window<false>(wp, gk, side, ch, cw, x, ya, need);
     else
         blur_cols_window<true>(wp, gk, side, ch, cw, x, ya, need);
 }
 
-// blockIdx.z = frame of the batch.  Tiles of 64 x 16 pixels of the ROI; REST as in k_blur_rows.
+// blockIdx.z = frame of the batch.  Tiles of 64 x 4*BC_ROWS pixels of the ROI; REST as in k_blur_rows.
 template <bool REST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_blur_cols(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_blur_cols(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
                                                    const SideDev* __restrict__ sides, int ch, int cw, int ex, int ey) {
     const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const SideDev side = sides[blockIdx.z];
     const int rx1 = wp->rx1, ry1 = wp->ry1;
     const int ox = wp->rx0 & ~63, oy = wp->ry0;
     if (!REST) {
-        const int bx = ox + 64 * (int)blockIdx.x, by = oy + 16 * (int)blockIdx.y;
+        const int bx = ox + 64 * (int)blockIdx.x, by = oy + 4 * BC_ROWS * (int)blockIdx.y;
         if (bx < rx1 && by < ry1) blur_cols_tile(wp, gk, side, ch, cw, bx, by);
         return;
     }
-    const int ntx = rx1 > ox ? (rx1 - ox + 63) / 64 : 0, nty = ry1 > oy ? (ry1 - oy + 15) / 16 : 0;
+    const int ntx = rx1 > ox ? (rx1 - ox + 63) / 64 : 0, nty = ry1 > oy ? (ry1 - oy + 4 * BC_ROWS - 1) / (4 * BC_ROWS) : 0;
     if (ntx <= ex && nty <= ey) return;
     for (int ty = blockIdx.y; ty < nty; ty += gridDim.y)
         for (int tx = blockIdx.x; tx < ntx; tx += gridDim.x) {
             if (tx < ex && ty < ey) continue;
-            blur_cols_tile(wp, gk, side, ch, cw, ox + 64 * tx, oy + 16 * ty);
+            blur_cols_tile(wp, gk, side, ch, cw, ox + 64 * tx, oy + 4 * BC_ROWS * ty);
         }
 }
 
@@ -753,7 +756,7 @@ int rtvm_launch_weights(rtvm_ctx* c, int n) {
                     (int)ey);
     }
     {
-        const unsigned ex = roi_tiles(c->cw, bw, 64), ey = roi_tiles(c->ch, bh, 16);
+        const unsigned ex = roi_tiles(c->cw, bw, 64), ey = roi_tiles(c->ch, bh, 4 * BC_ROWS);
         RTVM_LAUNCH(c, k_blur_cols<false>, dim3(ex, ey, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw,
                     (int)ex, (int)ey);
         RTVM_LAUNCH(c, k_blur_cols<true>, dim3(8, 8, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw, (int)ex,
