@@ -343,10 +343,13 @@ __global__ __launch_bounds__(256) void k_pred_bits(const uint32_t* __restrict__ 
 // (main.py:897-898) for both weights: s = k0*x0, then s = fma(x_i, k_i, s) left to right in
 // float32, BORDER_REFLECT_101 at the canvas edge.  dn is zero outside the ROI.  The two
 // weights of a pixel travel as one pair {new, old}, so every tap is one packed fma.  One
-// wave = 256 consecutive pixels of one row staged through LDS, 4 outputs per lane from a
+// wave = BR_TILE consecutive pixels of one row staged through LDS, BR_OUT outputs per lane from a
 // window of 34 staged pairs; a workgroup takes 4 rows; blockIdx.z = frame of the batch.
+// outputs per lane in the row pass of the blur: a wave takes BR_TILE consecutive pixels of a row
+constexpr int BR_OUT = 4, BR_TILE = 64 * BR_OUT, BR_STAGE = BR_TILE + 32, BR_LOADS = (BR_TILE + 30 + 63) / 64;
+
 __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
-                                               const SideDev& side, int cw, int bx, int by, f32x2 (*s_w)[288]) {
+                                               const SideDev& side, int cw, int bx, int by, f32x2 (*s_w)[BR_STAGE]) {
     const int rx0 = wp->rx0, rx1 = wp->rx1, wy0 = wp->wy0, wy1 = wp->wy1;
     const auto dn = as_global<const float>(side.dist_new);
     const auto dold = as_global<const float>(side.dist_old);
@@ -358,20 +361,20 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
         const bool row_in_roi = y >= wp->ry0 && y < wp->ry1;
         const int wx0 = wp->wx0, wx1 = wp->wx1;
         // all distances of the lane requested first, the divisions after: one wait, not five
-        float a[5], b[5];
-        bool ok[5];
+        float a[BR_LOADS], b[BR_LOADS];
+        bool ok[BR_LOADS];
 #pragma unroll
-        for (int q = 0; q < 5; q++) {
+        for (int q = 0; q < BR_LOADS; q++) {
             const int i = lane + 64 * q;
             const int xs = reflect101(bx - 15 + i, cw);
             // distances exist on [wx0, wx1); columns this row pass never needs may lie outside
-            ok[q] = i < 256 + 30 && xs >= wx0 && xs < wx1;
+            ok[q] = i < BR_TILE + 30 && xs >= wx0 && xs < wx1;
             const int xc = min(max(xs, wx0), wx1 - 1);
             b[q] = dold[row + xc];
             a[q] = (row_in_roi && xs >= rx0 && xs < rx1) ? dn[row + xc] : 0.f;
         }
 #pragma unroll
-        for (int q = 0; q < 5; q++) {
+        for (int q = 0; q < BR_LOADS; q++) {
             const int i = lane + 64 * q;
             float wn = 0.f, wo = 0.f;
             if (ok[q]) {
@@ -379,40 +382,40 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
                 wn = a[q] / sum;
                 wo = b[q] / sum;
             }
-            if (i < 288) s_w[wv][i] = f32x2{wn, wo};
+            if (i < BR_STAGE) s_w[wv][i] = f32x2{wn, wo};
         }
     }
     __syncthreads();
     if (!row_ok) return;
-    const int x = bx + 4 * lane;
-    if (x + 4 <= rx0 || x >= rx1) return;
-    f32x2 v[36];
+    const int x = bx + BR_OUT * lane;
+    if (x + BR_OUT <= rx0 || x >= rx1) return;
+    f32x2 v[BR_OUT + 32];
 #pragma unroll
-    for (int q = 0; q < 18; q++) {
-        const float4 a = *reinterpret_cast<const float4*>(&s_w[wv][4 * lane + 2 * q]);
+    for (int q = 0; q < (BR_OUT + 32) / 2; q++) {
+        const float4 a = *reinterpret_cast<const float4*>(&s_w[wv][BR_OUT * lane + 2 * q]);
         v[2 * q] = f32x2{a.x, a.y};
         v[2 * q + 1] = f32x2{a.z, a.w};
     }
     const auto outp = as_global(side.rb) + row + x;
-    // the four sums advance tap by tap side by side: no packed operation waits for the one before it
-    f32x2 a[4];
+    // the sums of the lane advance tap by tap side by side: no packed operation waits for the one before it
+    f32x2 a[BR_OUT];
     {
         const float k0 = gk[0];
 #pragma unroll
-        for (int o = 0; o < 4; o++) a[o] = f32x2{k0, k0} * v[o];
+        for (int o = 0; o < BR_OUT; o++) a[o] = f32x2{k0, k0} * v[o];
     }
 #pragma unroll
     for (int i = 1; i < 31; i++) {
         const float ki = gk[i];
 #pragma unroll
-        for (int o = 0; o < 4; o++) a[o] = __builtin_elementwise_fma(v[o + i], f32x2{ki, ki}, a[o]);
+        for (int o = 0; o < BR_OUT; o++) a[o] = __builtin_elementwise_fma(v[o + i], f32x2{ki, ki}, a[o]);
     }
 #pragma unroll
-    for (int o = 0; o < 4; o++)
+    for (int o = 0; o < BR_OUT; o++)
         if (x + o >= rx0 && x + o < rx1) outp[o] = a[o];
 }
 
-// blockIdx.z = frame of the batch.  Tiles of 256 x 4 pixels of the frame's region (rows of
+// blockIdx.z = frame of the batch.  Tiles of BR_TILE x 4 pixels of the frame's region (rows of
 // the blend window, columns of the ROI), tile (0,0) holding the region's first pixel.
 // REST = false: one tile per workgroup, the grid (ex x ey tiles) sized for a region of about
 // the frame's size.  REST = true: a small grid that loops over the tiles beyond ex x ey, for
@@ -422,20 +425,20 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
                                                    const SideDev* __restrict__ sides, int cw, int ex, int ey) {
     const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const SideDev side = sides[blockIdx.z];
-    __shared__ __align__(16) f32x2 s_w[4][288];
+    __shared__ __align__(16) f32x2 s_w[4][BR_STAGE];
     const int rx1 = wp->rx1, wy1 = wp->wy1;
     const int ox = wp->rx0 & ~3, oy = wp->wy0;
     if (!REST) {
-        const int bx = ox + 256 * (int)blockIdx.x, by = oy + 4 * (int)blockIdx.y;
+        const int bx = ox + BR_TILE * (int)blockIdx.x, by = oy + 4 * (int)blockIdx.y;
         if (bx < rx1 && by < wy1) blur_rows_tile(wp, gk, side, cw, bx, by, s_w);
         return;
     }
-    const int ntx = rx1 > ox ? (rx1 - ox + 255) / 256 : 0, nty = wy1 > oy ? (wy1 - oy + 3) / 4 : 0;
+    const int ntx = rx1 > ox ? (rx1 - ox + BR_TILE - 1) / BR_TILE : 0, nty = wy1 > oy ? (wy1 - oy + 3) / 4 : 0;
     if (ntx <= ex && nty <= ey) return;
     for (int ty = blockIdx.y; ty < nty; ty += gridDim.y)
         for (int tx = blockIdx.x; tx < ntx; tx += gridDim.x) {
             if (tx < ex && ty < ey) continue;  // done by the one-tile-per-workgroup launch
-            blur_rows_tile(wp, gk, side, cw, ox + 256 * tx, oy + 4 * ty, s_w);
+            blur_rows_tile(wp, gk, side, cw, ox + BR_TILE * tx, oy + 4 * ty, s_w);
             __syncthreads();  // the staging area is reused by the next tile
         }
 }
@@ -749,7 +752,7 @@ int rtvm_launch_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n) {
 int rtvm_launch_weights(rtvm_ctx* c, int n) {
     const int bw = c->fw + c->fh / 2, bh = c->fh + c->fw / 2;  // a region of about the frame's size
     {
-        const unsigned ex = roi_tiles(c->cw, bw, 256), ey = roi_tiles(c->ch, bh + 30, 4);
+        const unsigned ex = roi_tiles(c->cw, bw, BR_TILE), ey = roi_tiles(c->ch, bh + 30, 4);
         RTVM_LAUNCH(c, k_blur_rows<false>, dim3(ex, ey, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
                     (int)ey);
         RTVM_LAUNCH(c, k_blur_rows<true>, dim3(4, 16, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
