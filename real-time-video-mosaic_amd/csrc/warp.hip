@@ -755,14 +755,14 @@ int rtvm_launch_weights(rtvm_ctx* c, int n) {
         const unsigned ex = roi_tiles(c->cw, bw, BR_TILE), ey = roi_tiles(c->ch, bh + 30, 4);
         RTVM_LAUNCH(c, k_blur_rows<false>, dim3(ex, ey, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
                     (int)ey);
-        RTVM_LAUNCH(c, k_blur_rows<true>, dim3(4, 16, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
+        RTVM_LAUNCH(c, k_blur_rows<true>, dim3(2, 8, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
                     (int)ey);
     }
     {
         const unsigned ex = roi_tiles(c->cw, bw, 64), ey = roi_tiles(c->ch, bh, 4 * BC_ROWS);
         RTVM_LAUNCH(c, k_blur_cols<false>, dim3(ex, ey, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw,
                     (int)ex, (int)ey);
-        RTVM_LAUNCH(c, k_blur_cols<true>, dim3(8, 8, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw, (int)ex,
+        RTVM_LAUNCH(c, k_blur_cols<true>, dim3(4, 2, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw, (int)ex,
                     (int)ey);
     }
     HIP_TRY(c, hipGetLastError());
