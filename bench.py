@@ -127,7 +127,7 @@ def main():
                          "'drift' moves 2 px/frame right and up for ever (leaves the 1.2x-wide canvas after ~64 frames)")
     ap.add_argument("--canvas-batch", type=int, default=0,
                     help="frames per canvas-half piece (0 = half a batch)")
-    ap.add_argument("--host-frames", type=int, default=256,
+    ap.add_argument("--host-frames", type=int, default=512,
                     help="frames of the video also run from host memory through the ingest ring (0 = skip)")
     ap.add_argument("--dropin-frames", type=int, default=32,
                     help="frames of the PCIe-inclusive sample through the Python VideMosaic class (0 = skip)")
@@ -292,7 +292,7 @@ def main():
             th = time.perf_counter() - th0
             host_ingest = {"value": nh / th, "unit": "frames/s", "frames": nh, "frames_not_ok": int((sth != 0).sum()),
                            "note": "Context.process_host_video: host frames -> pinned ring -> device, batches of %d; "
-                                   "one Python memcpy per frame included" % B}
+                                   "one memcpy per frame into the pinned slot (4 threads) and the PCIe copy included" % B}
             ctx2.close()
         cpu = None
         if args.cpu_frames > 0 and world == 1:   # reported at N = 1 only

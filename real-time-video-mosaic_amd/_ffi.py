@@ -141,27 +141,50 @@ def ptr(a):
 class HostFrameRing:
     """Frame source for Context.process_video: frame i of `frames` (host arrays) is copied into
     pinned slot i % n_slots and from there to the device when its batch is about to be detected.
-    n_slots must cover the frames process_video keeps alive (four batches); one more slot holds
-    the first frame of the stream."""
+    n_slots must cover the frames process_video keeps alive (four batches) plus the batch that is
+    copied ahead; one more slot holds the first frame of the stream.  The copies into the pinned
+    slots run on a few threads (numpy releases the GIL for them; one thread moves about 10 GB/s,
+    some 3.5 K 720p frames/s), and the batch after the one just handed out is copied in the
+    background while the device works."""
 
-    def __init__(self, ctx, n_slots):
+    def __init__(self, ctx, n_slots, copy_threads=4):
+        from concurrent.futures import ThreadPoolExecutor
         ctx.ingest_reserve(n_slots + 1)
         self.ctx, self.n_slots, self.frames = ctx, n_slots, []
         self.views = [ctx.ingest_host_slot(i) for i in range(n_slots + 1)]
+        self.pool = ThreadPoolExecutor(max_workers=max(1, copy_threads))
+        self.ahead = None   # (first, k, futures) of the batch being copied ahead
 
     def __len__(self):
         return len(self.frames)
 
     def upload_first(self, frame):
+        self._settle()
         np.copyto(self.views[self.n_slots], frame)
         return self.ctx.ingest_submit(self.n_slots)
 
+    def _copy(self, first, k):
+        return [self.pool.submit(np.copyto, self.views[i % self.n_slots], self.frames[i]) for i in range(first, first + k)]
+
+    def _settle(self):
+        if self.ahead is not None:
+            for f in self.ahead[2]:
+                f.result()
+            self.ahead = None
+
     def acquire(self, first, k):
-        ptrs = []
-        for i in range(first, first + k):
-            slot = i % self.n_slots
-            np.copyto(self.views[slot], self.frames[i])
-            ptrs.append(self.ctx.ingest_submit(slot))
+        if self.ahead is not None and self.ahead[:2] == (first, k):
+            futures, self.ahead = self.ahead[2], None
+        else:
+            self._settle()   # a different range is wanted (detection started over): let the stray copy finish
+            futures = self._copy(first, k)
+        for f in futures:
+            f.result()
+        ptrs = [self.ctx.ingest_submit(i % self.n_slots) for i in range(first, first + k)]
+        # the next batch, if its slots are not those of a batch that may still be alive (four before it)
+        nxt, k2 = first + k, min(k, len(self.frames) - first - k)
+        if k2 > 0 and 5 * k <= self.n_slots:
+            self.ahead = (nxt, k2, self._copy(nxt, k2))
         return ptrs
 
 
@@ -631,10 +654,14 @@ class Context:
         Returns the per-frame status codes."""
         ring = getattr(self, "_ring", None)
         if ring is None:
-            ring = self._ring = HostFrameRing(self, 4 * 32)
+            ring = self._ring = HostFrameRing(self, 5 * 32)
+        ring.frames = []
         self.stream_begin(ring.upload_first(first_frame), row_off, col_off)
         ring.frames = frames
-        return self.process_video(ring, batch, trace)
+        try:
+            return self.process_video(ring, batch, trace)
+        finally:
+            ring._settle()
 
     def frame_status(self):
         st, nk, nm = C.c_int(0), C.c_int(0), C.c_int(0)

@@ -338,14 +338,16 @@ def test_detection_queued_ahead_of_the_canvas_half():
 
 
 @pytest.mark.gpu
-def test_host_frames_through_the_ingest_ring_give_the_same_mosaic():
+@pytest.mark.parametrize("slots", [12, 15])
+def test_host_frames_through_the_ingest_ring_give_the_same_mosaic(slots):
     """rtvm_ingest_*: frames in host memory, copied through pinned slots on a stream of their own while
     earlier batches are stitched, against the oracle frame by frame (more frames than ring slots per
-    batch set, so slots are reused)."""
+    batch set, so slots are reused; with five batches of slots the next batch is copied ahead in the
+    background)."""
     frames, _ = video(23, seed=14)
     ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=500)
     om = OracleMosaic(frames[0], nfeatures=500, glue="explicit")
-    ctx._ring = rtvm._ffi.HostFrameRing(ctx, 12)      # four batches of 3
+    ctx._ring = rtvm._ffi.HostFrameRing(ctx, slots)   # four or five batches of 3
     st = ctx.process_host_video(frames[0], frames[1:], om.w_offset, om.h_offset, batch=3)
     want = []
     for f in frames[1:]:
