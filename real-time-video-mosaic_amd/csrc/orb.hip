@@ -236,11 +236,11 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P, const FrameSlot* __restr
     __shared__ uint8_t sc[34][68];
     __shared__ int s_hist[256];
     __shared__ uint32_t s_list[512];
-    __shared__ uint16_t s_surv[34 * 66];
-    __shared__ int s_cnt, s_base, s_nsurv;
+    __shared__ uint16_t s_surv[34 * 66], s_quick[34 * 66];
+    __shared__ int s_cnt, s_base, s_nsurv, s_nquick;
     const int tid = threadIdx.x;
     s_hist[tid] = 0;
-    if (tid == 0) s_cnt = 0, s_nsurv = 0;
+    if (tid == 0) s_cnt = 0, s_nsurv = 0, s_nquick = 0;
     for (int i = tid; i < 40 * 20; i += 256) {
         const int r = i / 20, q = i % 20;
         const int y = min(ty0 - 4 + r, H - 1), x = min(tx0 - 7 + 4 * q, pitch - 4);
@@ -248,22 +248,44 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P, const FrameSlot* __restr
     }
     __syncthreads();
     // score-tile position (r, c) is pixel (tx0 - 1 + c, ty0 - 1 + r) = LDS (r + 3, c + 6).
-    // First the cheap necessary test on every position, survivors into a list ...
+    // First the two axis pairs on every position (five pixels), the few positions that pass into a
+    // list; then the eight-pair necessary test on that list, its survivors into a second list ...
     for (int i0 = 0; i0 < 34 * 66; i0 += 256) {
         const int i = i0 + tid;
-        bool cand = false;
+        bool quick = false;
         int r = 0, c = 0;
         if (i < 34 * 66) {
             r = i / 66, c = i % 66;
             sc[r][c] = 0;
-            cand = fast_candidate<80>(s, r + 3, c + 6);
+            const int v = s[r + 3][c + 6];
+            const int d0 = v - s[r + 6][c + 6], d8 = v - s[r][c + 6];
+            const int d4 = v - s[r + 3][c + 9], d12 = v - s[r + 3][c + 3];
+            quick = (max(d0, d8) > FAST_T || min(d0, d8) < -FAST_T) && (max(d4, d12) > FAST_T || min(d4, d12) < -FAST_T);
+        }
+        const unsigned long long m = __ballot(quick);
+        if (m) {
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&s_nquick, __popcll(m));
+            base = __shfl(base, 0);
+            if (quick) s_quick[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)(r * 68 + c);
+        }
+    }
+    __syncthreads();
+    const int nquick = s_nquick;
+    for (int i0 = 0; i0 < nquick; i0 += 256) {
+        const int i = i0 + tid;
+        bool cand = false;
+        int pos = 0;
+        if (i < nquick) {
+            pos = s_quick[i];
+            cand = fast_candidate<80>(s, pos / 68 + 3, pos % 68 + 6);
         }
         const unsigned long long m = __ballot(cand);
         if (m) {
             int base = 0;
             if ((tid & 63) == 0) base = atomicAdd(&s_nsurv, __popcll(m));
             base = __shfl(base, 0);
-            if (cand) s_surv[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)(r * 68 + c);
+            if (cand) s_surv[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)pos;
         }
     }
     __syncthreads();
