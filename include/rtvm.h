@@ -256,6 +256,43 @@ int rtvm_resize_linear(rtvm_ctx* ctx, const uint8_t* bgr, int h, int w, uint8_t*
  * pass, only the scaled image crosses PCIe. */
 int rtvm_canvas_read_scaled(rtvm_ctx* ctx, int x, int y, int w, int h, uint8_t* out, int nh, int nw);
 
+/* ---- classical passes on the finished mosaic before path planning (the step after
+ * finalisation; reference analyze_for_navigation, main.py:1051-1232) ------------------ */
+
+#define RTVM_MORPH_ERODE 0 /* cv2.MORPH_ERODE .. cv2.MORPH_CLOSE */
+#define RTVM_MORPH_DILATE 1
+#define RTVM_MORPH_OPEN 2
+#define RTVM_MORPH_CLOSE 3
+#define RTVM_SHAPE_RECT 0 /* cv2.MORPH_RECT, MORPH_CROSS, MORPH_ELLIPSE */
+#define RTVM_SHAPE_CROSS 1
+#define RTVM_SHAPE_ELLIPSE 2
+
+/* cv2.cvtColor(frame, cv2.COLOR_BGR2HSV) on 8-bit pixels (main.py:471,1065): H in [0,180).
+ * Host image h x w x 3 in, h x w x 3 out.  Allocates scratch; syncs. */
+int rtvm_bgr2hsv(rtvm_ctx* ctx, const uint8_t* bgr, int h, int w, uint8_t* hsv);
+/* cv2.erode / cv2.dilate / cv2.morphologyEx(OPEN, CLOSE) of a mask (0 / non-zero, out is
+ * 0 / 255) with cv2.getStructuringElement(shape, (ksize, ksize)), default anchor and border,
+ * `iterations` times (main.py:1142-1150,1188-1190,1197-1198,1207-1210,1231-1232 and the masks
+ * of main.py:492-498,528-529,647-649).  ksize 1..31.  Allocates scratch; syncs. */
+int rtvm_morphology(rtvm_ctx* ctx, const uint8_t* mask, int h, int w, int op, int shape, int ksize,
+                    int iterations, uint8_t* out);
+/* The obstacle masks of analyze_for_navigation (main.py:1065-1232) for a host image h x w x 3:
+ * boxes = n_boxes rectangles x1, y1, x2, y2 as main.py:1106 hands them to cv2.rectangle (the
+ * detections with their class buffer already applied, both corners included).  Outputs, each
+ * h x w u8 of 0 / 255 and each may be NULL: mask_fire and mask_smoke after their morphology
+ * (main.py:1150,1190), texture_mask (main.py:1210, the input of findContours), obstacles
+ * (main.py:1228, what is_path_clear reads), obstacles_nav (main.py:1232, dilated by the 15x15
+ * ellipse).  grid (may be NULL): find_path_astar's occupancy matrix of obstacles_nav at
+ * grid_scale (main.py:1346-1359), max(1,h/scale) x max(1,w/scale) bytes of 0 / 1.
+ * cv2.Canny of main.py:1141 is not computed: its edges enter the result only as
+ * mask | (dilated_edges & mask), which is mask.  Allocates scratch; syncs. */
+int rtvm_nav_obstacles(rtvm_ctx* ctx, const uint8_t* bgr, int h, int w, const int32_t* boxes, int n_boxes,
+                       uint8_t* mask_fire, uint8_t* mask_smoke, uint8_t* texture_mask, uint8_t* obstacles,
+                       uint8_t* obstacles_nav, int grid_scale, uint8_t* grid);
+/* find_path_astar's matrix alone (main.py:1346-1359) for any mask h x w: cell (gy, gx) is 1
+ * when more than 30 % of scale*scale pixels of its block are non-zero. */
+int rtvm_occupancy_grid(rtvm_ctx* ctx, const uint8_t* mask, int h, int w, int scale, uint8_t* grid);
+
 /* ---- two-call form of process_frame for hosts that keep the validate / smooth /
  * chain arithmetic of main.py:733-746 on their side (the Python VideMosaic) ----- */
 

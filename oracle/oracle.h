@@ -74,6 +74,21 @@ int rtvm_oracle_crop_rect(const uint8_t* bgr, int h, int w, int threshold, int r
 /* main.py:1037: cv2.resize(image, (nw, nh), INTER_LINEAR) on 8UC3 (scale_to_screen) */
 int rtvm_oracle_resize_linear(const uint8_t* bgr, int h, int w, uint8_t* out, int nh, int nw);
 
+/* main.py:471,1065: cv2.cvtColor(BGR2HSV), 8 bit */
+int rtvm_oracle_bgr2hsv(const uint8_t* bgr, int h, int w, uint8_t* hsv);
+/* cv2.erode/dilate/morphologyEx on a 0/255 mask; op 0 erode 1 dilate 2 open 3 close,
+ * shape 0 rect 1 cross 2 ellipse */
+int rtvm_oracle_morphology(const uint8_t* mask, int h, int w, int op, int shape, int ksize, int iterations,
+                           uint8_t* out);
+/* main.py:1065-1232: the masks of analyze_for_navigation; any output may be NULL */
+int rtvm_oracle_nav_obstacles(const uint8_t* bgr, int h, int w, const int32_t* boxes, int n_boxes,
+                              uint8_t* mask_fire, uint8_t* mask_smoke, uint8_t* texture_mask,
+                              uint8_t* obstacles, uint8_t* obstacles_nav);
+/* main.py:1201: cv2.GaussianBlur(gray, (11,11), 0) on 8-bit pixels */
+int rtvm_oracle_gauss11_u8(const uint8_t* src, int h, int w, uint8_t* dst);
+/* main.py:1346-1359: occupancy matrix of find_path_astar */
+int rtvm_oracle_occupancy_grid(const uint8_t* mask, int h, int w, int scale, uint8_t* grid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,10 @@ SIGNATURES = {
     "rtvm_canvas_crop_rect": (C.c_int, [_vp, C.c_int, _vp, _intp]),
     "rtvm_resize_linear": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
     "rtvm_canvas_read_scaled": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
+    "rtvm_bgr2hsv": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
+    "rtvm_morphology": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "rtvm_nav_obstacles": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "rtvm_occupancy_grid": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "rtvm_stream_begin": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_process_frame": (C.c_int, [_vp, _vp]),
     "rtvm_frame_status": (C.c_int, [_vp, _intp, _intp, _intp, _vp]),
@@ -370,6 +374,52 @@ class Context:
         self._check(lib().rtvm_canvas_read_scaled(self._h, int(x), int(y), int(w), int(h), ptr(out), int(new_h),
                                                   int(new_w)))
         return out
+
+    # ---- classical passes before path planning (main.py:1051-1232, 1344-1359) ----
+    def bgr2hsv(self, image):
+        """cv2.cvtColor(image, cv2.COLOR_BGR2HSV) of a BGR u8 image."""
+        image = _c_u8(image)
+        out = np.empty_like(image)
+        self._check(lib().rtvm_bgr2hsv(self._h, ptr(image), image.shape[0], image.shape[1], ptr(out)))
+        return out
+
+    def morphology(self, mask, op, shape, ksize, iterations=1):
+        """cv2.erode / dilate / morphologyEx(OPEN, CLOSE) of a 0/255 mask with
+        getStructuringElement(shape, (ksize, ksize)); op 0..3 = cv2.MORPH_ERODE..MORPH_CLOSE,
+        shape 0..2 = cv2.MORPH_RECT, MORPH_CROSS, MORPH_ELLIPSE."""
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert mask.ndim == 2
+        out = np.empty_like(mask)
+        self._check(lib().rtvm_morphology(self._h, ptr(mask), mask.shape[0], mask.shape[1], int(op), int(shape),
+                                          int(ksize), int(iterations), ptr(out)))
+        return out
+
+    def nav_obstacles(self, image, boxes=(), grid_scale=None):
+        """The obstacle masks of analyze_for_navigation for a BGR u8 image and filled rectangles
+        (x1, y1, x2, y2, both corners included): dict with mask_fire, mask_smoke, texture_mask,
+        obstacles, obstacles_nav and, with grid_scale, the occupancy grid."""
+        image = _c_u8(image)
+        h, w = image.shape[:2]
+        boxes = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 4))
+        names = ("mask_fire", "mask_smoke", "texture_mask", "obstacles", "obstacles_nav")
+        out = {k: np.empty((h, w), np.uint8) for k in names}
+        grid = None
+        if grid_scale is not None:
+            grid = np.empty((max(1, h // int(grid_scale)), max(1, w // int(grid_scale))), np.uint8)
+        self._check(lib().rtvm_nav_obstacles(self._h, ptr(image), h, w, ptr(boxes) if len(boxes) else None, len(boxes),
+                                             *[ptr(out[k]) for k in names], int(grid_scale or 0),
+                                             ptr(grid) if grid is not None else None))
+        if grid is not None:
+            out["grid"] = grid
+        return out
+
+    def occupancy_grid(self, mask, scale=4):
+        """find_path_astar's matrix: 1 where more than 30 % of a scale x scale block is set."""
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        h, w = mask.shape
+        grid = np.empty((max(1, h // int(scale)), max(1, w // int(scale))), np.uint8)
+        self._check(lib().rtvm_occupancy_grid(self._h, ptr(mask), h, w, int(scale), ptr(grid)))
+        return grid
 
     # ---- two-call stream form (host frames, glue on the host) ---------------
     def first_frame(self, bgr, row_off, col_off):

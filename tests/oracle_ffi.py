@@ -189,3 +189,46 @@ def sift(bgr, nfeatures):
     k = n.value
     return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=angle[:k].copy(), response=resp[:k].copy(),
                 octave=octave[:k].copy(), desc=desc[:k].copy())
+
+
+def bgr2hsv(bgr):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty_like(bgr)
+    assert lib().rtvm_oracle_bgr2hsv(_p(bgr), bgr.shape[0], bgr.shape[1], _p(out)) == 0
+    return out
+
+
+def morphology(mask, op, shape, ksize, iterations=1):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    out = np.empty_like(mask)
+    rc = lib().rtvm_oracle_morphology(_p(mask), mask.shape[0], mask.shape[1], int(op), int(shape), int(ksize),
+                                      int(iterations), _p(out))
+    assert rc == 0
+    return out
+
+
+def nav_obstacles(bgr, boxes=()):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w = bgr.shape[:2]
+    boxes = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 4))
+    names = ("mask_fire", "mask_smoke", "texture_mask", "obstacles", "obstacles_nav")
+    out = {k: np.empty((h, w), np.uint8) for k in names}
+    rc = lib().rtvm_oracle_nav_obstacles(_p(bgr), h, w, _p(boxes) if len(boxes) else None, len(boxes),
+                                         *[_p(out[k]) for k in names])
+    assert rc == 0
+    return out
+
+
+def occupancy_grid(mask, scale=4):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    grid = np.empty((max(1, h // scale), max(1, w // scale)), np.uint8)
+    assert lib().rtvm_oracle_occupancy_grid(_p(mask), h, w, int(scale), _p(grid)) == 0
+    return grid
+
+
+def gauss11_u8(gray):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    out = np.empty_like(gray)
+    assert lib().rtvm_oracle_gauss11_u8(_p(gray), gray.shape[0], gray.shape[1], _p(out)) == 0
+    return out
