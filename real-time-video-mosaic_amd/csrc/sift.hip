@@ -7,10 +7,11 @@
 //                    cv::resize(INTER_LINEAR) on floats
 //   k_sift_blur_rows / k_sift_blur_cols
 //                    cv::GaussianBlur(Size(), sigma) on floats: row pass s = k0*x0,
-//                    fma(x_i, k_i, s); column pass centre then fma(r[+i] + r[-i], k_i, s)
+//                    fma(x_i, k_i, s); column pass centre then fma(r[+i] + r[-i], k_i, s); the
+//                    column pass also writes the difference of Gaussians to the layer below
 //   k_sift_decimate  next octave = every second pixel of layer 3
-//   k_sift_sub       difference of Gaussians
-//   k_sift_extrema   26-neighbour extrema above the contrast floor -> candidate keys
+//   k_sift_extrema   26-neighbour extrema above the contrast floor -> candidate keys (every
+//                    octave and layer in one launch)
 //   k_sift_refine    one wave per candidate (keys sorted on the host: octave, layer, row,
 //                    column): adjustLocalExtrema, orientation histogram, peaks
 //   k_sift_describe  one wave per keypoint: calcSIFTDescriptor (samples in parallel, sums in order)
@@ -96,8 +97,10 @@ __global__ __launch_bounds__(256) void k_sift_blur_rows(const float* __restrict_
     dst[(size_t)y * w + x] = a;
 }
 
+// Column pass; with `below` (the Gaussian layer under the one being made) it also writes the
+// difference of the two layers, dog = this - below, the value a separate subtraction would give.
 __global__ __launch_bounds__(256) void k_sift_blur_cols(const float* __restrict__ src, float* __restrict__ dst, int h, int w,
-                                                        Taps t) {
+                                                        Taps t, const float* __restrict__ below, float* __restrict__ dog) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const int half = t.n / 2;
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(256) void k_sift_blur_cols(const float* __restrict_
         a = __builtin_fmaf(src[(size_t)reflect101s(y + i, h) * w + x] + src[(size_t)reflect101s(y - i, h) * w + x],
                            t.k[half + i], a);
     dst[(size_t)y * w + x] = a;
+    if (below) dog[(size_t)y * w + x] = a - below[(size_t)y * w + x];
 }
 
 __global__ __launch_bounds__(256) void k_sift_decimate(const float* __restrict__ src, int sw, float* __restrict__ dst, int h,
@@ -115,15 +119,24 @@ __global__ __launch_bounds__(256) void k_sift_decimate(const float* __restrict__
     dst[(size_t)y * w + x] = src[(size_t)(2 * y) * sw + 2 * x];
 }
 
-__global__ __launch_bounds__(256) void k_sift_sub(const float* __restrict__ a, const float* __restrict__ b,
-                                                  float* __restrict__ d, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) d[i] = b[i] - a[i];
-}
+// Tiles of 64x4 positions of every octave in one launch: tile_start[o] is the first linear tile
+// of octave o, blockIdx.y + 1 the layer.
+struct ExtremaTiles {
+    int n_oct;
+    int tile_start[MAX_OCT + 1];
+    int tiles_x[MAX_OCT];
+};
 
-__global__ __launch_bounds__(256) void k_sift_extrema(SImg prev, SImg img, SImg next, int octave, int layer, float threshold,
+__global__ __launch_bounds__(256) void k_sift_extrema(const SPyr* __restrict__ P, ExtremaTiles T, float threshold,
                                                       unsigned long long* __restrict__ keys, int* __restrict__ count, int cap) {
-    const int c = SBORDER + blockIdx.x * 64 + (threadIdx.x & 63), r = SBORDER + blockIdx.y * 4 + (threadIdx.x >> 6);
+    int octave = 0;
+    while (octave + 1 < T.n_oct && (int)blockIdx.x >= T.tile_start[octave + 1]) octave++;
+    const int tile = blockIdx.x - T.tile_start[octave], layer = blockIdx.y + 1;
+    const int ty = tile / T.tiles_x[octave], tx = tile - ty * T.tiles_x[octave];
+    const SImg img = P->dog[octave * (SL + 2) + layer];
+    const float* __restrict__ prev = P->dog[octave * (SL + 2) + layer - 1].px;
+    const float* __restrict__ next = P->dog[octave * (SL + 2) + layer + 1].px;
+    const int c = SBORDER + tx * 64 + (threadIdx.x & 63), r = SBORDER + ty * 4 + (threadIdx.x >> 6);
     if (c >= img.w - SBORDER || r >= img.h - SBORDER) return;
     const float val = img.px[(size_t)r * img.w + c];
     if (!(fabsf(val) > threshold)) return;
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(256) void k_sift_extrema(SImg prev, SImg img, SImg 
     for (int dy = -1; dy <= 1; dy++)
         for (int dx = -1; dx <= 1; dx++) {
             const size_t p = (size_t)(r + dy) * img.w + c + dx;
-            const float v0 = img.px[p], v1 = prev.px[p], v2 = next.px[p];
+            const float v0 = img.px[p], v1 = prev[p], v2 = next[p];
             mx &= val >= v0 && val >= v1 && val >= v2;
             mn &= val <= v0 && val <= v1 && val <= v2;
         }
@@ -529,7 +542,8 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
         const float sig_diff = std::sqrt(std::max(SSIGMA * SSIGMA - 1.f, 0.01f));
         const Taps t = gauss_taps((double)sig_diff);
         RTVM_LAUNCH(c, k_sift_blur_rows, grid2(bw, bh), dim3(256), 0, (const float*)dbl, scratch, bh, bw, t);
-        RTVM_LAUNCH(c, k_sift_blur_cols, grid2(bw, bh), dim3(256), 0, (const float*)scratch, P.gp[0].px, bh, bw, t);
+        RTVM_LAUNCH(c, k_sift_blur_cols, grid2(bw, bh), dim3(256), 0, (const float*)scratch, P.gp[0].px, bh, bw, t,
+                    (const float*)nullptr, (float*)nullptr);
     }
     Taps taps[SL + 3];
     for (int i = 1; i < SL + 3; i++) taps[i] = gauss_taps(sig[i]);
@@ -545,19 +559,26 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
             } else {
                 const SImg& src = P.gp[o * (SL + 3) + i - 1];
                 RTVM_LAUNCH(c, k_sift_blur_rows, grid2(ow, oh), dim3(256), 0, (const float*)src.px, scratch, oh, ow, taps[i]);
-                RTVM_LAUNCH(c, k_sift_blur_cols, grid2(ow, oh), dim3(256), 0, (const float*)scratch, dst.px, oh, ow, taps[i]);
+                RTVM_LAUNCH(c, k_sift_blur_cols, grid2(ow, oh), dim3(256), 0, (const float*)scratch, dst.px, oh, ow, taps[i],
+                            (const float*)src.px, P.dog[o * (SL + 2) + i - 1].px);
             }
         }
-        const size_t npx = (size_t)oh * ow;
-        for (int i = 0; i < SL + 2; i++)
-            RTVM_LAUNCH(c, k_sift_sub, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0,
-                        (const float*)P.gp[o * (SL + 3) + i].px, (const float*)P.gp[o * (SL + 3) + i + 1].px,
-                        P.dog[o * (SL + 2) + i].px, npx);
-        if (oh > 2 * SBORDER && ow > 2 * SBORDER)
-            for (int i = 1; i <= SL; i++)
-                RTVM_LAUNCH(c, k_sift_extrema, grid2(ow - 2 * SBORDER, oh - 2 * SBORDER), dim3(256), 0, P.dog[o * (SL + 2) + i - 1],
-                            P.dog[o * (SL + 2) + i], P.dog[o * (SL + 2) + i + 1], o, i, threshold,
-                            (unsigned long long*)keys.p, (int*)count.p, cand_cap);
+    }
+    {
+        ExtremaTiles T;
+        memset(&T, 0, sizeof(T));
+        T.n_oct = 0;
+        for (int o = 0; o < n_oct; o++) {
+            const int oh = P.gp[o * (SL + 3)].h, ow = P.gp[o * (SL + 3)].w;
+            if (!(oh > 2 * SBORDER && ow > 2 * SBORDER)) break;  // the octaves only get smaller
+            const dim3 g = grid2(ow - 2 * SBORDER, oh - 2 * SBORDER);
+            T.tiles_x[o] = (int)g.x;
+            T.tile_start[o + 1] = T.tile_start[o] + (int)(g.x * g.y);
+            T.n_oct = o + 1;
+        }
+        if (T.n_oct > 0)
+            RTVM_LAUNCH(c, k_sift_extrema, dim3(T.tile_start[T.n_oct], SL), dim3(256), 0, (const SPyr*)pyr.p, T, threshold,
+                        (unsigned long long*)keys.p, (int*)count.p, cand_cap);
     }
     HIP_TRY(c, hipGetLastError());
     int n_cand = 0;

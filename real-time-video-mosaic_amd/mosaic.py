@@ -80,7 +80,7 @@ class VideMosaic:
             # stage by stage, the way the reference itself runs: features, canvas
             self._sift_prev = self._ctx.sift(first_image, self._nfeatures)
             self._sift_cur = self._sift_prev
-            self._sift_matches = []
+            self._sift_matches = (np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
             self._ctx.canvas_init(first_image, self.w_offset, self.h_offset)
         else:
             self._ctx.first_frame(first_image, self.w_offset, self.h_offset)
@@ -94,11 +94,13 @@ class VideMosaic:
             # main.py:716-731 with the SIFT branch of match(): detect, knn-2 + ratio, RANSAC
             cur = self._sift_cur = self._ctx.sift(frame_cur, self._nfeatures)
             prev = self._sift_prev
-            ms = self._sift_matches = self.match(cur["desc"], prev["desc"]) if len(cur["xy"]) and len(prev["xy"]) >= 2 else []
-            n_matches, found, H_relative = len(ms), False, None
+            if len(cur["xy"]) and len(prev["xy"]) >= 2:
+                self._sift_matches = self._match_sift_arrays(cur["desc"], prev["desc"])
+            else:
+                self._sift_matches = (np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
+            qi, ti, _ = self._sift_matches
+            n_matches, found, H_relative = len(qi), False, None
             if n_matches >= 4:
-                qi = np.array([m.queryIdx for m in ms])
-                ti = np.array([m.trainIdx for m in ms])
                 H_relative, _ = _stage_ctx().find_homography(cur["xy"][qi], prev["xy"][ti], 2.0)
                 found = H_relative is not None
         else:
@@ -159,7 +161,9 @@ class VideMosaic:
     @property
     def matches(self):
         if self.detector_type == "sift":
-            return self._sift_matches
+            if "matches" not in self._cache:
+                self._cache["matches"] = matches_from_arrays(*self._sift_matches)
+            return self._cache["matches"]
         if "matches" not in self._cache:
             self._cache["matches"] = matches_from_arrays(*self._ctx.get_matches())
         return self._cache["matches"]
@@ -177,20 +181,23 @@ class VideMosaic:
     # ------------------------------------------------------------------ stages
     def match(self, des_cur, des_prev):
         """main.py:676-708: matches sorted by distance."""
-        ctx = _stage_ctx()
         if self.detector_type == "sift":
-            des_cur = np.asarray(des_cur, np.float32)
-            des_prev = np.asarray(des_prev, np.float32)
-            idx, dist = ctx.match_l2_knn2(des_cur, des_prev)
-            if len(des_prev) < 2:
-                raise ValueError("not enough values to unpack (expected 2, got %d)" % len(des_prev))
-            keep = dist[:, 0].astype(np.float64) < 0.7 * dist[:, 1].astype(np.float64)
-            qi = np.nonzero(keep)[0]
-            order = np.argsort(dist[qi, 0], kind="stable")
-            qi = qi[order]
-            return [DMatch(q, idx[q, 0], dist[q, 0]) for q in qi.tolist()]
-        qi, ti, di = ctx.match_hamming(des_cur, des_prev, sorted_by_distance=True)
+            return matches_from_arrays(*self._match_sift_arrays(des_cur, des_prev))
+        qi, ti, di = _stage_ctx().match_hamming(des_cur, des_prev, sorted_by_distance=True)
         return matches_from_arrays(qi, ti, di)
+
+    @staticmethod
+    def _match_sift_arrays(des_cur, des_prev):
+        """main.py:688-698: knn-2, ratio test at 0.7, sorted by distance; (queryIdx, trainIdx, distance) arrays."""
+        des_cur = np.asarray(des_cur, np.float32)
+        des_prev = np.asarray(des_prev, np.float32)
+        if len(des_prev) < 2:
+            raise ValueError("not enough values to unpack (expected 2, got %d)" % len(des_prev))
+        idx, dist = _stage_ctx().match_l2_knn2(des_cur, des_prev)
+        keep = dist[:, 0].astype(np.float64) < 0.7 * dist[:, 1].astype(np.float64)
+        qi = np.nonzero(keep)[0]
+        qi = qi[np.argsort(dist[qi, 0], kind="stable")]
+        return qi, idx[qi, 0], dist[qi, 0]
 
     @staticmethod
     def findHomography(image_1_kp, image_2_kp, matches):
