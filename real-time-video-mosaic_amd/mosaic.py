@@ -178,6 +178,14 @@ class VideMosaic:
     def output_img_u8(self):
         return self._ctx.canvas_read()
 
+    def preview(self, width=400, height=300):
+        """The whole mosaic scaled to width x height on the device (bilinear, as cv2.resize
+        INTER_LINEAR), u8 BGR: what a progress display needs per frame (the reference's
+        update_callback gets a copy of the full float64 canvas, main.py:1630-1632, which its GUI
+        shrinks to 400 x 300, gui.py:143-155).  Only the small image crosses PCIe."""
+        ch, cw = self._ctx.canvas_h, self._ctx.canvas_w
+        return self._ctx.canvas_read_scaled(0, 0, cw, ch, int(width), int(height))
+
     # ------------------------------------------------------------------ stages
     def match(self, des_cur, des_prev):
         """main.py:676-708: matches sorted by distance."""

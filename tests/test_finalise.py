@@ -87,6 +87,8 @@ def test_hip_finalisation_of_a_device_canvas_and_the_drop_in_functions():
     x, y, w, h = rect
     got = vm._ctx.canvas_read_scaled(x, y, w, h, 300, 200)
     assert np.array_equal(got, orc.resize_linear(canvas[y:y + h, x:x + w], 300, 200))
+    assert np.array_equal(vm.preview(), orc.resize_linear(canvas, 400, 300))   # what gui.py:143-155 displays
+    assert np.array_equal(vm.preview(64, 50), orc.resize_linear(canvas, 64, 50))
     # the reference's two functions (main.py:980-1038), on a numpy image and on the mosaic object
     cropped = rtvm.crop_black_areas(canvas)
     assert np.array_equal(cropped, canvas[y + 5:y + 5 + h - 10, x + 5:x + 5 + w - 10])
