@@ -215,6 +215,7 @@ class Context:
         self.frame_h, self.frame_w = frame_h, frame_w
         self.canvas_h, self.canvas_w = canvas_h, canvas_w
         self.nfeatures = nfeatures
+        self.device = device
 
     def close(self):
         if getattr(self, "_h", None):

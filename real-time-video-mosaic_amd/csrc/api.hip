@@ -340,6 +340,13 @@ void free_all(rtvm_ctx* c) {
 
 extern "C" int rtvm_version(void) { return RTVM_VERSION; }
 
+static void destroy_streams(rtvm_ctx* c) {
+    if (c->stream_lm != c->stream_main) (void)hipStreamDestroy(c->stream_lm);
+    if (c->stream_rs != c->stream_main) (void)hipStreamDestroy(c->stream_rs);
+    if (c->stream_front != c->stream_main) (void)hipStreamDestroy(c->stream_front);
+    (void)hipStreamDestroy(c->stream_main);
+}
+
 extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w, int canvas_h,
                            int canvas_w, int detector, int nfeatures, int flags) {
     if (!out) return RTVM_E_ARG;
@@ -361,37 +368,31 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
     c->detector = detector;
     c->nfeatures = nfeatures;
     c->flags = flags;
+    // A context without a frame size serves the stage entry points only, one call at a time: it
+    // gets a single stream.  (A process has few hardware queues and streams are dealt onto them in
+    // turn; four streams per context would put the working streams of several such contexts, one
+    // per host thread, onto the same queue.)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream_main) != hipSuccess) {
         delete c;
         return RTVM_E_HIP;
     }
-    if (hipStreamCreate(&c->stream_front) != hipSuccess) {
-        (void)hipStreamDestroy(c->stream_main);
-        delete c;
-        return RTVM_E_HIP;
-    }
-    if (hipStreamCreate(&c->stream_rs) != hipSuccess) {
-        (void)hipStreamDestroy(c->stream_front);
-        (void)hipStreamDestroy(c->stream_main);
-        delete c;
-        return RTVM_E_HIP;
-    }
-    if (hipStreamCreate(&c->stream_lm) != hipSuccess) {
-        (void)hipStreamDestroy(c->stream_rs);
-        (void)hipStreamDestroy(c->stream_front);
-        (void)hipStreamDestroy(c->stream_main);
-        delete c;
-        return RTVM_E_HIP;
+    c->stream_front = c->stream_rs = c->stream_lm = c->stream_main;
+    if (frame_h > 0) {
+        hipStream_t* more[3] = {&c->stream_front, &c->stream_rs, &c->stream_lm};
+        for (hipStream_t* st : more)
+            if (hipStreamCreate(st) != hipSuccess) {
+                *st = c->stream_main;
+                destroy_streams(c);
+                delete c;
+                return RTVM_E_HIP;
+            }
     }
     c->stream = c->stream_main;
     int r = alloc_all(c);
     if (r != RTVM_OK) {
         fprintf(stderr, "rtvm_create: %s\n", c->err);
         free_all(c);
-        (void)hipStreamDestroy(c->stream_lm);
-        (void)hipStreamDestroy(c->stream_rs);
-        (void)hipStreamDestroy(c->stream_front);
-        (void)hipStreamDestroy(c->stream_main);
+        destroy_streams(c);
         delete c;
         return r;
     }
@@ -408,10 +409,7 @@ extern "C" void rtvm_destroy(rtvm_ctx* c) {
     (void)hipStreamSynchronize(c->stream_main);
     rtvm_prof_free(c);
     free_all(c);
-    (void)hipStreamDestroy(c->stream_lm);
-    (void)hipStreamDestroy(c->stream_rs);
-    (void)hipStreamDestroy(c->stream_front);
-    (void)hipStreamDestroy(c->stream_main);
+    destroy_streams(c);
     delete c;
 }
 

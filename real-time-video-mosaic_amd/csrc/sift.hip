@@ -588,7 +588,9 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
     std::vector<SKp> all;
     if (n_cand > 0) {
         std::vector<unsigned long long> hk(n_cand);
-        HIP_TRY(c, hipMemcpy(hk.data(), keys.p, (size_t)n_cand * 8, hipMemcpyDeviceToHost));
+        // on the context's stream: a copy on the null stream would wait for every other context's work
+        HIP_TRY(c, hipMemcpyAsync(hk.data(), keys.p, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
         std::sort(hk.begin(), hk.end());  // octave, layer, row, column
         HIP_TRY(c, hipMemcpyAsync(keys.p, hk.data(), (size_t)n_cand * 8, hipMemcpyHostToDevice, c->stream));
         SIFT_BUF(c, 5, cand_out, (size_t)n_cand * MAX_PEAKS * sizeof(SKp));

@@ -92,20 +92,35 @@ class VideMosaic:
         self.frame_cur = frame_cur
         if self.detector_type == "sift":
             # main.py:716-731 with the SIFT branch of match(): detect, knn-2 + ratio, RANSAC
-            cur = self._sift_cur = self._ctx.sift(frame_cur, self._nfeatures)
-            prev = self._sift_prev
-            if len(cur["xy"]) and len(prev["xy"]) >= 2:
-                self._sift_matches = self._match_sift_arrays(cur["desc"], prev["desc"])
-            else:
-                self._sift_matches = (np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
-            qi, ti, _ = self._sift_matches
-            n_matches, found, H_relative = len(qi), False, None
-            if n_matches >= 4:
-                H_relative, _ = _stage_ctx().find_homography(cur["xy"][qi], prev["xy"][ti], 2.0)
-                found = H_relative is not None
+            cur = self._ctx.sift(frame_cur, self._nfeatures)
+            registered = self._sift_register(_stage_ctx(), cur, self._sift_prev)
+            self._sift_finish(frame_cur, cur, registered)
         else:
             n_matches, found, H_relative = self._ctx.frame_register(frame_cur)
+            self._cache.clear()
+            self._finish_frame(frame_cur, n_matches, found, H_relative)
+
+    @classmethod
+    def _sift_register(cls, ctx, cur, prev):
+        """main.py:721-731 for SIFT features: (matches as arrays, H_relative or None)."""
+        if len(cur["xy"]) and len(prev["xy"]) >= 2:
+            matches = cls._match_sift_arrays(cur["desc"], prev["desc"], ctx)
+        else:
+            matches = (np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
+        qi, ti, _ = matches
+        H_relative = None
+        if len(qi) >= 4:
+            H_relative, _ = ctx.find_homography(cur["xy"][qi], prev["xy"][ti], 2.0)
+        return matches, H_relative
+
+    def _sift_finish(self, frame_cur, cur, registered):
+        self._sift_cur = cur
+        self._sift_matches, H_relative = registered
         self._cache.clear()
+        self._finish_frame(frame_cur, len(self._sift_matches[0]), H_relative is not None, H_relative)
+
+    def _finish_frame(self, frame_cur, n_matches, found, H_relative):
+        """main.py:722-759 after matching and RANSAC: skip rules, validate, smooth, chain, warp."""
         if n_matches < 4:
             print(f"Предупреждение: Недостаточно совпадений ({n_matches}), пропуск кадра")
             return
@@ -128,6 +143,63 @@ class VideMosaic:
         self.H_old = self.H
         self.frame_prev = self.frame_cur
         self._cache["advanced"] = True
+
+    def process_frames(self, frames, first_frame_count=1, workers=4):
+        """process_frame(frames[0], first_frame_count), process_frame(frames[1], ...), ... with the
+        same results, state and printed warnings, for callers that have several frames at hand
+        (a decoder's queue).  With the SIFT detector the frames' detection, matching and RANSAC
+        run on `workers` threads, each with a device context of its own, ahead of the
+        sequential part (skip rules, validate, smooth, chain, warp + blend), which keeps frame
+        order.  Every frame is matched against its predecessor on the assumption that the
+        predecessor is not skipped; after a skipped frame (main.py:722-731) the next one is
+        registered again against the frame the reference would have used.  ORB has the batched
+        device pipeline (Context.process_video) for this purpose; here its frames go one by one."""
+        frames = list(frames)
+        if self.detector_type != "sift" or workers < 2 or len(frames) < 2:
+            for i, frame in enumerate(frames):
+                self.process_frame(frame, first_frame_count + i)
+            return
+        import queue
+        from concurrent.futures import Future, ThreadPoolExecutor
+
+        if getattr(self, "_worker_ctxs", None) is None or len(self._worker_ctxs) < workers:
+            have = getattr(self, "_worker_ctxs", None) or []
+            self._worker_ctxs = have + [_ffi.Context(device=self._ctx.device) for _ in range(workers - len(have))]
+        free = queue.SimpleQueue()
+        for c in self._worker_ctxs[:workers]:
+            free.put(c)
+        n = len(frames)
+        detected = [Future() for _ in range(n)]
+        prev0 = self._sift_prev
+        nfeatures = self._nfeatures
+
+        def work(t):
+            ctx = free.get()
+            try:
+                try:
+                    cur = ctx.sift(np.ascontiguousarray(frames[t], dtype=np.uint8), nfeatures)
+                except BaseException as e:
+                    detected[t].set_exception(e)
+                    raise
+                detected[t].set_result(cur)
+                # the task of frame t-1 started before this one and waits only for earlier frames
+                prev = prev0 if t == 0 else detected[t - 1].result()
+                return cur, prev, self._sift_register(ctx, cur, prev)
+            finally:
+                free.put(ctx)
+
+        ahead = 4 * workers
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            tasks = [pool.submit(work, t) for t in range(min(ahead, n))]
+            for t in range(n):
+                cur, prev, registered = tasks[t].result()
+                tasks[t] = None
+                if t + ahead < n:
+                    tasks.append(pool.submit(work, t + ahead))
+                self.frame_cur = frames[t]
+                if prev is not self._sift_prev:   # the predecessor was skipped
+                    registered = self._sift_register(_stage_ctx(), cur, self._sift_prev)
+                self._sift_finish(frames[t], cur, registered)
 
     # ------------------------------------------------------------------ lazily fetched state
     def _features(self, slot):
@@ -195,13 +267,13 @@ class VideMosaic:
         return matches_from_arrays(qi, ti, di)
 
     @staticmethod
-    def _match_sift_arrays(des_cur, des_prev):
+    def _match_sift_arrays(des_cur, des_prev, ctx=None):
         """main.py:688-698: knn-2, ratio test at 0.7, sorted by distance; (queryIdx, trainIdx, distance) arrays."""
         des_cur = np.asarray(des_cur, np.float32)
         des_prev = np.asarray(des_prev, np.float32)
         if len(des_prev) < 2:
             raise ValueError("not enough values to unpack (expected 2, got %d)" % len(des_prev))
-        idx, dist = _stage_ctx().match_l2_knn2(des_cur, des_prev)
+        idx, dist = (ctx or _stage_ctx()).match_l2_knn2(des_cur, des_prev)
         keep = dist[:, 0].astype(np.float64) < 0.7 * dist[:, 1].astype(np.float64)
         qi = np.nonzero(keep)[0]
         qi = qi[np.argsort(dist[qi, 0], kind="stable")]
@@ -290,6 +362,9 @@ class VideMosaic:
         return []
 
     def close(self):
+        for c in getattr(self, "_worker_ctxs", None) or []:
+            c.close()
+        self._worker_ctxs = None
         self._ctx.close()
 
 

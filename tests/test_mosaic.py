@@ -388,6 +388,40 @@ def test_dropin_with_the_default_sift_detector_matches_oracle(capsys):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("detector,workers", [("sift", 3), ("sift", 1), ("orb", 4)])
+def test_process_frames_equals_frame_by_frame(capsys, detector, workers):
+    """process_frames (SIFT: detection, matching and RANSAC of several frames on worker threads ahead of the
+    sequential part) leaves the same mosaic, homographies, features, matches and printed warnings as one
+    process_frame call per frame, also across skipped frames (a black one, a repeated one that follows it)."""
+    frames, _ = video(9, seed=16)
+    frames = list(frames)
+    frames.insert(4, np.zeros_like(frames[0]))        # no features: skipped, the next frame matches frame 3
+    frames.insert(7, np.zeros_like(frames[0]))
+    frames.insert(8, np.zeros_like(frames[0]))        # two skipped frames in a row
+    kw = dict(detector_type=detector, visualize=False, show_intermediate=False, nfeatures=300)
+    a = rtvm.VideMosaic(frames[0], **kw)
+    Hs = []
+    for t, f in enumerate(frames[1:], 1):
+        a.process_frame(f, t)
+        Hs.append(None if a.H is None else a.H.copy())
+    out_a = capsys.readouterr().out
+    b = rtvm.VideMosaic(frames[0], **kw)
+    b.process_frames(frames[1:5], 1, workers=workers)
+    assert np.array_equal(b.H, Hs[3])
+    b.process_frames(frames[5:], 5, workers=workers)
+    out_b = capsys.readouterr().out
+    assert out_a == out_b and out_a.count("пропуск кадра") == 3
+    assert np.array_equal(a.H, b.H) and np.array_equal(a.H_old, b.H_old)
+    assert len(a.homography_history) == len(b.homography_history)
+    assert all(np.array_equal(x, y) for x, y in zip(a.homography_history, b.homography_history))
+    assert np.array_equal(a.des_prev, b.des_prev) and np.array_equal(a.des_cur, b.des_cur)
+    assert [(m.queryIdx, m.trainIdx, m.distance) for m in a.matches] == [(m.queryIdx, m.trainIdx, m.distance) for m in b.matches]
+    assert np.array_equal(a.output_img_u8(), b.output_img_u8())
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fh,fw,ch,cw,nf,batch", [(1080, 1920, 2160, 2304, 1000, 4), (2160, 3840, 4096, 16384, 4000, 3)])
 def test_full_size_configs_batched_equals_frame_by_frame(fh, fw, ch, cw, nf, batch):
     """At the 1080p and the 4K / 16384-wide-canvas sizes the oracle is too slow to run per test; what is checked

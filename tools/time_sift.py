@@ -36,3 +36,14 @@ for (fh, fw, nf) in [(720, 1280, 700), (1080, 1920, 2000)]:
     print("%dx%d n=%d: rtvm_sift %.1f ms (%d keypoints), oracle %.0f ms, equal %s; drop-in frame %.1f ms = %.1f frames/s, %d matches"
           % (fh, fw, nf, t_gpu * 1e3, len(got["xy"]), t_cpu * 1e3, same, t_vm * 1e3, 1 / t_vm, len(vm.matches)))
     vm.close()
+    for workers in ([2, 4, 6] if len(sys.argv) < 2 else [int(a) for a in sys.argv[1:]]):
+        reps = 8
+        seq = (frames[1:] + frames[-2:0:-1]) * reps      # back and forth over the same ground
+        vm = rtvm.VideMosaic(frames[0], visualize=False, show_intermediate=False, nfeatures=nf)
+        vm.process_frames(seq[:8], 1, workers=workers)
+        t0 = time.perf_counter()
+        vm.process_frames(seq[8:], 9, workers=workers)
+        vm.output_img_u8()
+        dt = (time.perf_counter() - t0) / len(seq[8:])
+        print("    process_frames, %d workers: %.2f ms per frame = %.0f frames/s" % (workers, dt * 1e3, 1 / dt))
+        vm.close()
