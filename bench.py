@@ -129,6 +129,8 @@ def main():
                     help="frames per canvas-half piece (0 = half a batch)")
     ap.add_argument("--host-frames", type=int, default=512,
                     help="frames of the video also run from host memory through the ingest ring (0 = skip)")
+    ap.add_argument("--sift-frames", type=int, default=144,
+                    help="frames of the PCIe-inclusive sample through VideMosaic with the SIFT detector (0 = skip)")
     ap.add_argument("--dropin-frames", type=int, default=32,
                     help="frames of the PCIe-inclusive sample through the Python VideMosaic class (0 = skip)")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel timing table to this JSON file")
@@ -287,6 +289,27 @@ def main():
                       "note": "Python VideMosaic.process_frame with host frames: PCIe copies and one host round trip "
                               "per frame included"}
             vm.close()
+        sift_leg = None
+        if args.sift_frames > 0 and world == 1:
+            # the reference's default detector (main.py:1603 passes "sift"): the drop-in class frame by frame,
+            # and process_frames with detection, matching and RANSAC on worker threads
+            ns = min(args.sift_frames, T - 1)
+            host_frames = list(frames[:ns + 1].cpu().numpy())
+            vm = rtvm.VideMosaic(host_frames[0], detector_type="sift", nfeatures=700, canvas_size=(ch, cw),
+                                 device=local_rank, warp_mode=args.warp_mode, show_intermediate=False, visualize=False)
+            n1 = min(16, ns)
+            ts0 = time.perf_counter()
+            for t, f in enumerate(host_frames[1:1 + n1], 1):
+                vm.process_frame(f, t)
+            ts1 = time.perf_counter()
+            vm.process_frames(host_frames[1 + n1:], 1 + n1, workers=4)
+            vm.output_img_u8()
+            ts2 = time.perf_counter()
+            sift_leg = {"process_frame": {"value": n1 / (ts1 - ts0), "frames": n1},
+                        "process_frames_4_workers": {"value": (ns - n1) / (ts2 - ts1), "frames": ns - n1} if ns > n1 else None,
+                        "unit": "frames/s", "nfeatures": 700,
+                        "note": "VideMosaic(detector_type='sift') with host frames, PCIe copies included"}
+            vm.close()
         host_ingest = None
         if args.host_frames > 0 and world == 1:
             # frames in host memory through the ingest ring (pinned slots, copies on a stream of their own)
@@ -325,7 +348,7 @@ def main():
                        "frames_void": vstats["frames_void"], "canvas_pieces": vstats["canvas_pieces"],
                        "canvas_batch": args.canvas_batch or (B + 1) // 2},
             "roofline": roof, "warp_blend_stage": warp_blend, "cpu_baseline": cpu, "dropin_pcie_inclusive": dropin,
-            "host_frames_pcie_inclusive": host_ingest,
+            "host_frames_pcie_inclusive": host_ingest, "sift_dropin_pcie_inclusive": sift_leg,
         }
         if args.kernel_table:
             rows = {k: {"launches": v[0], "total_ms": v[1], "avg_us": v[1] / v[0] * 1e3, "stream": v[2],
