@@ -302,7 +302,9 @@ int rtvm_first_frame(rtvm_ctx* ctx, const uint8_t* bgr, int row_off, int col_off
  * RANSAC.  *found = 0 when there are fewer than 4 matches or no model.  Syncs. */
 int rtvm_frame_register(rtvm_ctx* ctx, const uint8_t* bgr, int* n_matches, int* found, double H_rel[9]);
 /* main.py:748, 756-759: warp + blend the registered frame with the absolute
- * homography H, then make it the previous frame. */
+ * homography H, then make it the previous frame.  Asynchronous: the work is queued behind
+ * the registration on the context's stream; rtvm_frame_register, rtvm_canvas_read and the
+ * other reading calls wait for it. */
 int rtvm_frame_commit(rtvm_ctx* ctx, const double H[9]);
 /* kp_cur/des_cur (slot 0) or kp_prev/des_prev (slot 1) of the stream; any output may
  * be NULL; capacity rtvm_max_keypoints(). */

@@ -316,6 +316,7 @@ struct rtvm_ctx {
     int* d_skip;           // RTVM_MAX_BATCH flags: 1 when the frame is not to be stitched
     int stream_ready;
     void* h_pinned;        // small pinned host buffer for read-backs
+    int commit_parity;     // which of the two staging slots the last rtvm_frame_commit used
     int prof_mode;         // 0 off, 1 every kernel, 2 kernels whose name contains prof_filter
     char prof_filter[64];
     void* prof;            // timing records (prof.hip)

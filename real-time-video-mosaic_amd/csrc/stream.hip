@@ -704,7 +704,10 @@ extern "C" int rtvm_frame_commit(rtvm_ctx* c, const double H[9]) {
     if (!H) RTVM_FAIL(c, RTVM_E_ARG, "frame_commit: null homography");
     if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "frame_commit: no registered frame");
     HIP_TRY(c, hipSetDevice(c->device));
-    double* hp = (double*)c->h_pinned + 32;
+    // No sync: the warp and blend run while the host fetches the next frame.  Two pinned staging
+    // slots for H taken in turn are enough, because rtvm_frame_register (which every commit
+    // follows) ends with a sync of this stream and so leaves at most one commit in flight.
+    double* hp = (double*)c->h_pinned + 32 + 16 * (c->commit_parity ^= 1);
     memcpy(hp, H, 9 * sizeof(double));
     HIP_TRY(c, hipMemcpyAsync(c->d_H, hp, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int r;
@@ -712,7 +715,6 @@ extern "C" int rtvm_frame_commit(rtvm_ctx* c, const double H[9]) {
     RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
                 c->feat_prev, c->orb.max_kp);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the pinned staging of H is reused by the next call
     return RTVM_OK;
 }
 
