@@ -37,6 +37,8 @@ constexpr float SSIGMA = 1.6f;
 constexpr float SCONTRAST = 0.04f, SEDGE = 10.f;
 constexpr int MAX_OCT = 16;
 constexpr int MAX_TAPS = 33;
+constexpr int SMALL_OCTAVE_PX = 4000;  // octaves of at most this many pixels share one launch (2 x 4 bytes each in LDS);
+                                       // measured: one workgroup is slower than eleven launches from 160 x 90 up
 
 struct SImg {
     float* px;
@@ -81,10 +83,53 @@ __global__ __launch_bounds__(256) void k_sift_base(const uint8_t* __restrict__ b
     out[(size_t)y * 2 * w + x] = r0 * b0 + r1 * b1;
 }
 
+constexpr int MAX_HALF = MAX_TAPS / 2;
+
+// k[0..n-1]: the kernel in row order; c[q] = k[n/2 + q]: the same taps counted from the centre
 struct Taps {
     float k[MAX_TAPS];
+    float c[MAX_HALF + 1];
     int n;
 };
+
+// The tap loops are unrolled to the maximum length with an early exit, so that the taps sit in
+// scalar registers loaded once per kernel instead of one scalar load (and wait) per tap.
+__device__ __forceinline__ float row_taps(const Taps& t, const float* p) {  // p: leftmost sample of the window
+    float a = t.k[0] * p[0];
+#pragma unroll
+    for (int q = 1; q < MAX_TAPS; q++) {
+        if (q >= t.n) break;
+        a = __builtin_fmaf(p[q], t.k[q], a);
+    }
+    return a;
+}
+
+__device__ __forceinline__ float col_taps(const Taps& t, const float* p, int pitch) {  // p: the centre sample
+    const int half = t.n / 2;
+    float a = t.c[0] * p[0];
+#pragma unroll
+    for (int q = 1; q <= MAX_HALF; q++) {
+        if (q > half) break;
+        a = __builtin_fmaf(p[q * pitch] + p[-q * pitch], t.c[q], a);
+    }
+    return a;
+}
+
+// The same sums where the window crosses the border (BORDER_REFLECT_101); rare, plain loops.
+__device__ __forceinline__ float row_taps_border(const Taps& t, const float* row, int x, int w) {
+    const int half = t.n / 2;
+    float a = t.k[0] * row[reflect101s(x - half, w)];
+    for (int q = 1; q < t.n; q++) a = __builtin_fmaf(row[reflect101s(x - half + q, w)], t.k[q], a);
+    return a;
+}
+
+__device__ __forceinline__ float col_taps_border(const Taps& t, const float* col, int y, int h, int pitch) {
+    const int half = t.n / 2;
+    float a = t.c[0] * col[(size_t)y * pitch];
+    for (int q = 1; q <= half; q++)
+        a = __builtin_fmaf(col[(size_t)reflect101s(y + q, h) * pitch] + col[(size_t)reflect101s(y - q, h) * pitch], t.c[q], a);
+    return a;
+}
 
 __global__ __launch_bounds__(256) void k_sift_blur_rows(const float* __restrict__ src, float* __restrict__ dst, int h, int w,
                                                         Taps t) {
@@ -92,8 +137,12 @@ __global__ __launch_bounds__(256) void k_sift_blur_rows(const float* __restrict_
     if (x >= w || y >= h) return;
     const int half = t.n / 2;
     const float* __restrict__ row = src + (size_t)y * w;
-    float a = t.k[0] * row[reflect101s(x - half, w)];
-    for (int i = 1; i < t.n; i++) a = __builtin_fmaf(row[reflect101s(x - half + i, w)], t.k[i], a);
+    float a;
+    if (x >= half && x + half < w) {  // no border in reach: the same sum without the index folding
+        a = row_taps(t, row + (x - half));
+    } else {
+        a = row_taps_border(t, row, x, w);
+    }
     dst[(size_t)y * w + x] = a;
 }
 
@@ -104,10 +153,13 @@ __global__ __launch_bounds__(256) void k_sift_blur_cols(const float* __restrict_
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const int half = t.n / 2;
-    float a = t.k[half] * src[(size_t)y * w + x];
-    for (int i = 1; i <= half; i++)
-        a = __builtin_fmaf(src[(size_t)reflect101s(y + i, h) * w + x] + src[(size_t)reflect101s(y - i, h) * w + x],
-                           t.k[half + i], a);
+    const float* __restrict__ c0 = src + (size_t)y * w + x;
+    float a;
+    if (y >= half && y + half < h) {  // wave-uniform: a wave is one row
+        a = col_taps(t, c0, w);
+    } else {
+        a = col_taps_border(t, src + x, y, h, w);
+    }
     dst[(size_t)y * w + x] = a;
     if (below) dog[(size_t)y * w + x] = a - below[(size_t)y * w + x];
 }
@@ -117,6 +169,65 @@ __global__ __launch_bounds__(256) void k_sift_decimate(const float* __restrict__
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     dst[(size_t)y * w + x] = src[(size_t)(2 * y) * sw + 2 * x];
+}
+
+// The small octaves (a few thousand pixels each) are launch-latency bound as eleven kernels per
+// octave: here one workgroup builds all of them, octave after octave and layer after layer, with
+// the arithmetic of k_sift_decimate / k_sift_blur_rows / k_sift_blur_cols.  The layer being
+// blurred and its row pass live in LDS (2 x h x w floats of the first of these octaves, dynamic);
+// the finished layers and differences go to the pyramid in global memory.
+struct TapsAll {
+    Taps t[SL + 3];
+};
+
+// Layer i of octave o from the layer below it in `cur` (LDS): row pass into rowp, column pass
+// into the pyramid, the difference of the two layers, and `cur` replaced by the new layer.
+__device__ __forceinline__ void small_layer(const SPyr* P, int o, int i, const Taps& t, float* cur, float* rowp, int h, int w) {
+    const int tid = threadIdx.x, npx = h * w, half = t.n / 2;
+    float* dst = P->gp[o * (SL + 3) + i].px;
+    float* dog = P->dog[o * (SL + 2) + i - 1].px;
+    for (int p = tid; p < npx; p += 1024) {
+        const int y = p / w, x = p - y * w;
+        const float* row = cur + y * w;
+        rowp[p] = (x >= half && x + half < w) ? row_taps(t, row + (x - half)) : row_taps_border(t, row, x, w);
+    }
+    __syncthreads();
+    for (int p = tid; p < npx; p += 1024) {
+        const int y = p / w, x = p - y * w;
+        const float a = (y >= half && y + half < h) ? col_taps(t, rowp + p, w) : col_taps_border(t, rowp + x, y, h, w);
+        dst[p] = a;
+        dog[p] = a - cur[p];
+        cur[p] = a;  // only this thread reads cur[p] in this pass
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_sift_small_octaves(const SPyr* P, int o0, int o1, TapsAll T, int lds_px) {
+    extern __shared__ float s_small[];
+    float* cur = s_small;            // the layer below the one being made
+    float* rowp = s_small + lds_px;  // its row pass
+    const int tid = threadIdx.x;
+    for (int o = o0; o < o1; o++) {
+        const int h = P->gp[o * (SL + 3)].h, w = P->gp[o * (SL + 3)].w, npx = h * w;
+        {
+            // global memory written by this workgroup is visible to it after the barrier below
+            const SImg src = P->gp[(o - 1) * (SL + 3) + SL];
+            float* dst = P->gp[o * (SL + 3)].px;
+            for (int p = tid; p < npx; p += 1024) {
+                const int y = p / w, x = p - y * w;
+                const float v = src.px[(size_t)(2 * y) * src.w + 2 * x];
+                dst[p] = v;
+                cur[p] = v;
+            }
+        }
+        __syncthreads();
+        small_layer(P, o, 1, T.t[1], cur, rowp, h, w);
+        small_layer(P, o, 2, T.t[2], cur, rowp, h, w);
+        small_layer(P, o, 3, T.t[3], cur, rowp, h, w);
+        small_layer(P, o, 4, T.t[4], cur, rowp, h, w);
+        small_layer(P, o, 5, T.t[5], cur, rowp, h, w);
+        static_assert(SL + 3 == 6, "one call per layer above");
+    }
 }
 
 // Tiles of 64x4 positions of every octave in one launch: tile_start[o] is the first linear tile
@@ -241,13 +352,13 @@ __device__ float orientation_hist(const SImg img, int px, int py, int radius, fl
     const float expf_scale = -1.f / (2.f * sigma * sigma);
     if (lane < n) temphist[lane] = 0.f;
     const int side = 2 * radius + 1;
-    const long long total = (long long)side * side;
+    const unsigned total = (unsigned)side * (unsigned)side;  // side <= 2 * 23170 + 1: fits 32 bits unsigned
     __syncthreads();
-    for (long long base = 0; base < total; base += 64) {
-        const long long t = base + lane;
+    for (unsigned base = 0; base < total; base += 64) {
+        const unsigned t = base + lane;
         int bin = -1;
         if (t < total) {
-            const int i = (int)(t / side) - radius, j = (int)(t % side) - radius;
+            const int i = (int)(t / (unsigned)side) - radius, j = (int)(t % (unsigned)side) - radius;
             const int y = py + i, x = px + j;
             if (!(y <= 0 || y >= img.h - 1 || x <= 0 || x >= img.w - 1)) {
                 const float dx = AT(img, y, x + 1) - AT(img, y, x - 1);
@@ -281,37 +392,44 @@ __device__ float orientation_hist(const SImg img, int px, int py, int radius, fl
 }
 
 // One wave per candidate; out: per candidate MAX_PEAKS keypoints, npeaks[candidate] of them valid.
+// One wave per candidate, a fixed grid striding over the candidates the extrema kernel counted
+// (the host does not know the count yet).  Keypoints go to `list` in whatever order the waves
+// finish: the host sorts them (KeyPointsFilter::removeDuplicatedSorted), so the order of the
+// candidates and of the list does not reach the result.
 __global__ __launch_bounds__(64) void k_sift_refine(const SPyr* __restrict__ P, const unsigned long long* __restrict__ keys,
-                                                    int n, SKp* __restrict__ out, int* __restrict__ npeaks) {
-    const int q = blockIdx.x, lane = threadIdx.x;
-    const unsigned long long key = keys[q];
-    const int o = (int)(key >> 56), c0 = (int)(key & 0xFFFFFF), r0 = (int)((key >> 24) & 0xFFFFFF);
-    int layer = (int)((key >> 48) & 0xFF), r = r0, c = c0;
-    SKp kp;
-    if (!adjust_extremum(P, o, layer, r, c, kp)) {  // the same in every lane
-        if (lane == 0) npeaks[q] = 0;
-        return;
-    }
+                                                    const int* __restrict__ count, int cap, SKp* __restrict__ list,
+                                                    int* __restrict__ list_count, int list_cap) {
     __shared__ float temphist[ORI_BINS], hist[ORI_BINS], s_val[64];
     __shared__ int s_bin[64];
-    const float scl_octv = kp.size * 0.5f / (float)(1 << o);
-    const float omax = orientation_hist(P->gp[o * (SL + 3) + layer], c, r, __float2int_rn(4.5f * scl_octv), 1.5f * scl_octv,
-                                        temphist, hist, s_val, s_bin);
-    if (lane != 0) return;
-    const float mag_thr = omax * 0.8f;
-    int peaks = 0;
-    for (int j = 0; j < ORI_BINS && peaks < MAX_PEAKS; j++) {
-        const int l = j > 0 ? j - 1 : ORI_BINS - 1, r2 = j < ORI_BINS - 1 ? j + 1 : 0;
-        if (hist[j] > hist[l] && hist[j] > hist[r2] && hist[j] >= mag_thr) {
-            float bin = j + 0.5f * (hist[l] - hist[r2]) / (hist[l] - 2 * hist[j] + hist[r2]);
-            bin = bin < 0 ? ORI_BINS + bin : bin >= ORI_BINS ? bin - ORI_BINS : bin;
-            kp.angle = 360.f - (360.f / ORI_BINS) * bin;
-            if (fabsf(kp.angle - 360.f) < FLT_EPSILON) kp.angle = 0.f;
-            out[(size_t)q * MAX_PEAKS + peaks] = kp;
-            peaks++;
+    const int lane = threadIdx.x;
+    const int n = min(*count, cap);
+    for (int q = blockIdx.x; q < n; q += gridDim.x) {
+        const unsigned long long key = keys[q];
+        const int o = (int)(key >> 56), c0 = (int)(key & 0xFFFFFF), r0 = (int)((key >> 24) & 0xFFFFFF);
+        int layer = (int)((key >> 48) & 0xFF), r = r0, c = c0;
+        SKp kp;
+        if (!adjust_extremum(P, o, layer, r, c, kp)) continue;  // the same in every lane
+        const float scl_octv = kp.size * 0.5f / (float)(1 << o);
+        const float omax = orientation_hist(P->gp[o * (SL + 3) + layer], c, r, __float2int_rn(4.5f * scl_octv),
+                                            1.5f * scl_octv, temphist, hist, s_val, s_bin);
+        if (lane == 0) {
+            const float mag_thr = omax * 0.8f;
+            int peaks = 0;
+            for (int j = 0; j < ORI_BINS && peaks < MAX_PEAKS; j++) {
+                const int l = j > 0 ? j - 1 : ORI_BINS - 1, r2 = j < ORI_BINS - 1 ? j + 1 : 0;
+                if (hist[j] > hist[l] && hist[j] > hist[r2] && hist[j] >= mag_thr) {
+                    float bin = j + 0.5f * (hist[l] - hist[r2]) / (hist[l] - 2 * hist[j] + hist[r2]);
+                    bin = bin < 0 ? ORI_BINS + bin : bin >= ORI_BINS ? bin - ORI_BINS : bin;
+                    kp.angle = 360.f - (360.f / ORI_BINS) * bin;
+                    if (fabsf(kp.angle - 360.f) < FLT_EPSILON) kp.angle = 0.f;
+                    const int pos = atomicAdd(list_count, 1);
+                    if (pos < list_cap) list[pos] = kp;
+                    peaks++;
+                }
+            }
         }
+        __syncthreads();  // the histograms are reused by the next candidate
     }
-    npeaks[q] = peaks;
 }
 
 // One wave per keypoint.  The lanes evaluate 64 consecutive sample positions of the window at a
@@ -342,15 +460,15 @@ __global__ __launch_bounds__(64) void k_sift_describe(const SPyr* __restrict__ P
     constexpr int HLEN = (SD + 2) * (SD + 2) * (SNB + 2);
     __shared__ float hist[HLEN];
     __shared__ float s_v[64][8];
-    __shared__ int s_idx[64];
+    __shared__ __align__(16) int s_idx[64];
     for (int i = lane; i < HLEN; i += 64) hist[i] = 0.f;
     const int side = 2 * radius + 1;
-    const long long total = (long long)side * side;
-    for (long long base = 0; base < total; base += 64) {
-        const long long t = base + lane;
+    const unsigned total = (unsigned)side * (unsigned)side;  // side <= 2 * 23170 + 1: fits 32 bits unsigned
+    for (unsigned base = 0; base < total; base += 64) {
+        const unsigned t = base + lane;
         int idx = -1;
         if (t < total) {
-            const int i = (int)(t / side) - radius, j = (int)(t % side) - radius;
+            const int i = (int)(t / (unsigned)side) - radius, j = (int)(t % (unsigned)side) - radius;
             const float c_rot = j * cos_t - i * sin_t;
             const float r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f;
@@ -389,9 +507,17 @@ __global__ __launch_bounds__(64) void k_sift_describe(const SPyr* __restrict__ P
         // sample, in sample order, so every bin still receives its terms in scan order
         if (lane < 8) {
             const int ofs = (lane & 1) + ((lane >> 1) & 1) * (nb + 2) + (lane >> 2) * (d + 2) * (nb + 2);
-            for (int l = 0; l < 64; l++) {
-                const int k = s_idx[l];
-                if (k >= 0) hist[k + ofs] += s_v[l][lane];
+            for (int l0 = 0; l0 < 64; l0 += 8) {
+                // indices and shares of eight samples first, then the additions one after the other
+                const int4 ka = *reinterpret_cast<const int4*>(&s_idx[l0]);
+                const int4 kb = *reinterpret_cast<const int4*>(&s_idx[l0 + 4]);
+                const int k[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = s_v[l0 + u][lane];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (k[u] >= 0) hist[k[u] + ofs] += v[u];
             }
         }
         __syncthreads();
@@ -438,6 +564,7 @@ Taps gauss_taps(double sigma) {
     }
     sum = 1. / sum;
     for (int i = 0; i < MAX_TAPS; i++) t.k[i] = i < t.n ? (float)(e[i] * sum) : 0.f;
+    for (int q = 0; q <= MAX_HALF; q++) t.c[q] = t.n / 2 + q < t.n ? t.k[t.n / 2 + q] : 0.f;
     return t;
 }
 
@@ -522,11 +649,11 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
     const size_t scratch_off = total;
     total += (size_t)bh * bw;
     const int cand_cap = 1 << 18;
-    Dev arena, frame, keys, count, pyr, cand_out, cand_np, kp_dev, desc_dev;
+    Dev arena, frame, keys, count, pyr, cand_out, kp_dev, desc_dev;
     SIFT_BUF(c, 0, arena, total * sizeof(float));
     SIFT_BUF(c, 1, frame, (size_t)h * w * 3);
     SIFT_BUF(c, 2, keys, (size_t)cand_cap * 8);
-    SIFT_BUF(c, 3, count, sizeof(int));
+    SIFT_BUF(c, 3, count, 2 * sizeof(int));  // extrema found, keypoints listed
     SIFT_BUF(c, 4, pyr, sizeof(SPyr));
     float* A = (float*)arena.p;
     for (size_t i = 0; i < off_gp.size(); i++) P.gp[i].px = A + off_gp[i];
@@ -534,7 +661,7 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
     float* scratch = A + scratch_off;
     HIP_TRY(c, hipMemcpyAsync(frame.p, bgr, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(pyr.p, &P, sizeof(SPyr), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(count.p, 0, sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(count.p, 0, 2 * sizeof(int), c->stream));
     // base image: doubled, blurred by sqrt(sigma^2 - 1) (into gp[0] via the last DoG plane as a temporary)
     {
         float* dbl = P.dog[SL + 1].px;  // free until the DoG of octave 0 is formed
@@ -548,7 +675,10 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
     Taps taps[SL + 3];
     for (int i = 1; i < SL + 3; i++) taps[i] = gauss_taps(sig[i]);
     const float threshold = (float)(int)std::floor(0.5 * SCONTRAST / SL * 255);
-    for (int o = 0; o < n_oct; o++) {
+    // octaves from o_small on are built by one workgroup in one launch
+    int o_small = n_oct;
+    for (int o = n_oct - 1; o >= 1 && P.gp[o * (SL + 3)].h * P.gp[o * (SL + 3)].w <= SMALL_OCTAVE_PX; o--) o_small = o;
+    for (int o = 0; o < o_small; o++) {
         const int oh = P.gp[o * (SL + 3)].h, ow = P.gp[o * (SL + 3)].w;
         for (int i = 0; i < SL + 3; i++) {
             SImg& dst = P.gp[o * (SL + 3) + i];
@@ -563,6 +693,16 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
                             (const float*)src.px, P.dog[o * (SL + 2) + i - 1].px);
             }
         }
+    }
+    if (o_small < n_oct) {
+        TapsAll ta;
+        memset(&ta, 0, sizeof(ta));
+        for (int i = 1; i < SL + 3; i++) ta.t[i] = taps[i];
+        const int lds_px = P.gp[o_small * (SL + 3)].h * P.gp[o_small * (SL + 3)].w;
+        const size_t lds_bytes = (size_t)2 * lds_px * sizeof(float);
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sift_small_octaves),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        RTVM_LAUNCH(c, k_sift_small_octaves, dim3(1), dim3(1024), lds_bytes, (const SPyr*)pyr.p, o_small, n_oct, ta, lds_px);
     }
     {
         ExtremaTiles T;
@@ -581,33 +721,30 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
                         (unsigned long long*)keys.p, (int*)count.p, cand_cap);
     }
     HIP_TRY(c, hipGetLastError());
-    int n_cand = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n_cand, count.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // refinement of every candidate, queued behind the extrema without a host round trip
+    const int list_cap = 1 << 16, list_first = 1 << 13;
+    SIFT_BUF(c, 5, cand_out, (size_t)list_cap * sizeof(SKp));
+    int* d_list_count = (int*)count.p + 1;
+    RTVM_LAUNCH(c, k_sift_refine, dim3(4096), dim3(64), 0, (const SPyr*)pyr.p, (const unsigned long long*)keys.p,
+                (const int*)count.p, cand_cap, (SKp*)cand_out.p, d_list_count, list_cap);
+    HIP_TRY(c, hipGetLastError());
+    int counts[2] = {0, 0};
+    std::vector<SKp> all(list_first);
+    HIP_TRY(c, hipMemcpyAsync(counts, count.p, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(all.data(), cand_out.p, (size_t)list_first * sizeof(SKp), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (n_cand > cand_cap) RTVM_FAIL(c, RTVM_E_NOMEM, "sift: %d scale-space extrema, room for %d", n_cand, cand_cap);
-    std::vector<SKp> all;
-    if (n_cand > 0) {
-        std::vector<unsigned long long> hk(n_cand);
-        // on the context's stream: a copy on the null stream would wait for every other context's work
-        HIP_TRY(c, hipMemcpyAsync(hk.data(), keys.p, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
+    if (counts[0] > cand_cap) RTVM_FAIL(c, RTVM_E_NOMEM, "sift: %d scale-space extrema, room for %d", counts[0], cand_cap);
+    if (counts[1] > list_cap) RTVM_FAIL(c, RTVM_E_NOMEM, "sift: %d keypoints before filtering, room for %d", counts[1], list_cap);
+    if (counts[1] > list_first) {
+        all.resize(counts[1]);
+        HIP_TRY(c, hipMemcpyAsync(all.data() + list_first, (const SKp*)cand_out.p + list_first,
+                                  (size_t)(counts[1] - list_first) * sizeof(SKp), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        std::sort(hk.begin(), hk.end());  // octave, layer, row, column
-        HIP_TRY(c, hipMemcpyAsync(keys.p, hk.data(), (size_t)n_cand * 8, hipMemcpyHostToDevice, c->stream));
-        SIFT_BUF(c, 5, cand_out, (size_t)n_cand * MAX_PEAKS * sizeof(SKp));
-        SIFT_BUF(c, 6, cand_np, (size_t)n_cand * sizeof(int));
-        RTVM_LAUNCH(c, k_sift_refine, dim3(n_cand), dim3(64), 0, (const SPyr*)pyr.p,
-                    (const unsigned long long*)keys.p, n_cand, (SKp*)cand_out.p, (int*)cand_np.p);
-        HIP_TRY(c, hipGetLastError());
-        std::vector<SKp> ho((size_t)n_cand * MAX_PEAKS);
-        std::vector<int> hn(n_cand);
-        HIP_TRY(c, hipMemcpyAsync(ho.data(), cand_out.p, ho.size() * sizeof(SKp), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(hn.data(), cand_np.p, hn.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        for (int q = 0; q < n_cand; q++)
-            for (int p = 0; p < hn[q]; p++) all.push_back(ho[(size_t)q * MAX_PEAKS + p]);
     }
-    // KeyPointsFilter::removeDuplicatedSorted, retainBest(nfeatures)
-    std::stable_sort(all.begin(), all.end(), kp_less);
+    all.resize(counts[1]);
+    // KeyPointsFilter::removeDuplicatedSorted, retainBest(nfeatures); keypoints that compare equal
+    // are equal in every field, so the order they arrived in does not matter
+    std::sort(all.begin(), all.end(), kp_less);
     std::vector<SKp> uniq;
     for (const SKp& q : all)
         if (uniq.empty() || uniq.back().x != q.x || uniq.back().y != q.y || uniq.back().size != q.size ||
