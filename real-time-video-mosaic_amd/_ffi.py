@@ -597,6 +597,19 @@ class Context:
         Returns the per-frame status codes; self.video_stats counts what was queued.  trace: a
         list that receives (seconds, first frame, length, frames consumed, reason) for every
         canvas half whose outcome was read."""
+        # The loop allocates only short-lived tuples and lists (no reference cycles), but their
+        # number sets off the cyclic collector now and then, and a full collection in a process that
+        # has imported numpy and torch walks a million objects: 40 ms, the time of 500 frames.
+        import gc
+        collector_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._process_video(bgr_dev_ptrs, batch, trace, canvas_batch)
+        finally:
+            if collector_was_on:
+                gc.enable()
+
+    def _process_video(self, bgr_dev_ptrs, batch, trace, canvas_batch):
         self.reserve_batch(batch)
         n = len(bgr_dev_ptrs)
         cb = max(1, min(batch, canvas_batch if canvas_batch else (batch + 1) // 2))
