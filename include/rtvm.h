@@ -237,6 +237,9 @@ int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_match
 int rtvm_ingest_reserve(rtvm_ctx* ctx, int n_slots);
 int rtvm_ingest_host_slot(rtvm_ctx* ctx, int slot, uint8_t** host);
 int rtvm_ingest_submit(rtvm_ctx* ctx, int slot, const uint8_t** dev);
+/* The same for `count` consecutive slots in one copy (a whole batch moves at about twice the
+ * rate of frame-sized copies); dev receives the `count` device addresses. */
+int rtvm_ingest_submit_range(rtvm_ctx* ctx, int first_slot, int count, const uint8_t** dev);
 
 /* ---- mosaic finalisation: the step after the path, once per video ---------------- */
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "rtvm_ingest_reserve": (C.c_int, [_vp, C.c_int]),
     "rtvm_ingest_host_slot": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
     "rtvm_ingest_submit": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
+    "rtvm_ingest_submit_range": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rtvm_crop_rect": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _intp]),
     "rtvm_canvas_crop_rect": (C.c_int, [_vp, C.c_int, _vp, _intp]),
     "rtvm_resize_linear": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
@@ -184,7 +185,11 @@ class HostFrameRing:
             futures = self._copy(first, k)
         for f in futures:
             f.result()
-        ptrs = [self.ctx.ingest_submit(i % self.n_slots) for i in range(first, first + k)]
+        s0 = first % self.n_slots
+        if s0 + k <= self.n_slots:   # consecutive slots: one copy for the whole batch
+            ptrs = self.ctx.ingest_submit_range(s0, k)
+        else:
+            ptrs = [self.ctx.ingest_submit(i % self.n_slots) for i in range(first, first + k)]
         # the next batch, if its slots are not those of a batch that may still be alive (four before it)
         nxt, k2 = first + k, min(k, len(self.frames) - first - k)
         if k2 > 0 and 5 * k <= self.n_slots:
@@ -710,6 +715,12 @@ class Context:
         p = C.c_void_p()
         self._check(lib().rtvm_ingest_submit(self._h, int(slot), C.byref(p)))
         return p.value
+
+    def ingest_submit_range(self, first_slot, count):
+        """Queues one copy of `count` consecutive slots; returns their device addresses."""
+        out = (C.c_void_p * int(count))()
+        self._check(lib().rtvm_ingest_submit_range(self._h, int(first_slot), int(count), out))
+        return [int(v) for v in out]
 
     def process_host_video(self, first_frame, frames, row_off, col_off, batch=16, trace=None):
         """The reference's loop (main.py:1596-1634) for frames in host memory: stream_begin with

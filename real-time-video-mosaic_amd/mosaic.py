@@ -189,17 +189,26 @@ class VideMosaic:
                 free.put(ctx)
 
         ahead = 4 * workers
-        with ThreadPoolExecutor(max_workers=workers) as pool:
-            tasks = [pool.submit(work, t) for t in range(min(ahead, n))]
-            for t in range(n):
-                cur, prev, registered = tasks[t].result()
-                tasks[t] = None
-                if t + ahead < n:
-                    tasks.append(pool.submit(work, t + ahead))
-                self.frame_cur = frames[t]
-                if prev is not self._sift_prev:   # the predecessor was skipped
-                    registered = self._sift_register(_stage_ctx(), cur, self._sift_prev)
-                self._sift_finish(frames[t], cur, registered)
+        # a full pass of the cyclic garbage collector stops every thread for tens of milliseconds in a
+        # process that has imported numpy and torch; what this loop allocates is freed by reference counts
+        import gc
+        collector_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                tasks = [pool.submit(work, t) for t in range(min(ahead, n))]
+                for t in range(n):
+                    cur, prev, registered = tasks[t].result()
+                    tasks[t] = None
+                    if t + ahead < n:
+                        tasks.append(pool.submit(work, t + ahead))
+                    self.frame_cur = frames[t]
+                    if prev is not self._sift_prev:   # the predecessor was skipped
+                        registered = self._sift_register(_stage_ctx(), cur, self._sift_prev)
+                    self._sift_finish(frames[t], cur, registered)
+        finally:
+            if collector_was_on:
+                gc.enable()
 
     # ------------------------------------------------------------------ lazily fetched state
     def _features(self, slot):
