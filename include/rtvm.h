@@ -151,7 +151,9 @@ int rtvm_warp_perspective(rtvm_ctx* ctx, const uint8_t* bgr, const double H[9], 
 int rtvm_distance_transform(rtvm_ctx* ctx, const uint8_t* mask, int h, int w, float* dist);
 
 /* The whole of VideMosaic.warp(): warp, masks, distance transforms, weights,
- * 31x31 blur, blend and commit into the canvas  main.py:871-927. */
+ * 31x31 blur, blend and commit into the canvas  main.py:871-927.  Returns once the frame and H
+ * have been copied (the caller may reuse both); the blend itself is queued on the context's
+ * stream and rtvm_canvas_read and the other reading calls wait for it. */
 int rtvm_warp_blend(rtvm_ctx* ctx, const uint8_t* bgr, const double H[9]);
 
 /* output_img readers  main.py:1632,1649: canvas_h*canvas_w*3 u8 (the reference's

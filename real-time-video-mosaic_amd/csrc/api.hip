@@ -323,6 +323,7 @@ void free_all(rtvm_ctx* c) {
         if (c->side_arena[i]) (void)hipFree(c->side_arena[i]);
     free(c->h_side);
     free(c->h_slots);
+    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (int k = 0; k < RTVM_NSETS; k++) {
         if (c->ev_feat[k]) (void)hipEventDestroy(c->ev_feat[k]);
@@ -662,8 +663,13 @@ extern "C" int rtvm_warp_blend(rtvm_ctx* c, const uint8_t* bgr, const double H[9
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
     if ((r = upload_H(c, H))) return r;
+    // The host waits for the two uploads only (the caller's frame and the staging of H may be
+    // written again on return); the warp and blend stay queued, and whatever reads the canvas
+    // next is ordered behind them on the same stream.
+    if (!c->ev_upload) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_upload, c->stream));
     if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H))) return r;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev_upload));
     return RTVM_OK;
 }
 

@@ -317,6 +317,7 @@ struct rtvm_ctx {
     int stream_ready;
     void* h_pinned;        // small pinned host buffer for read-backs
     int commit_parity;     // which of the two staging slots the last rtvm_frame_commit used
+    hipEvent_t ev_upload;  // rtvm_warp_blend: the uploads of the frame and of H have been consumed
     int prof_mode;         // 0 off, 1 every kernel, 2 kernels whose name contains prof_filter
     char prof_filter[64];
     void* prof;            // timing records (prof.hip)
