@@ -209,17 +209,25 @@ __global__ __launch_bounds__(256) void k_nav_morph(const uint8_t* __restrict__ s
     }
     __syncthreads();
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    bool any[4] = {false, false, false, false}, all[4] = {true, true, true, true};
+    // unrolled to the largest element with an early exit: the spans are then read from the kernel
+    // arguments at fixed offsets (scalar registers) instead of one scalar load per row and output
+#pragma unroll
+    for (int i = 0; i < 31; i++) {
+        if (i >= e.rows) break;
+        const int lo = e.lo[i], hi = e.hi[i];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int oy = ly + 4 * q;
+            const int cnt = (int)s_p[oy + i][lx + R + hi] - (int)s_p[oy + i][lx + R + lo];
+            any[q] |= cnt > 0;
+            all[q] &= cnt == hi - lo;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int oy = ly + 4 * q, x = blockIdx.x * NAV_TW + lx, y = blockIdx.y * NAV_TH + oy;
-        bool any = false, all = true;
-        for (int i = 0; i < e.rows; i++) {
-            const int lo = e.lo[i], hi = e.hi[i];
-            const int cnt = (int)s_p[oy + i][lx + R + hi] - (int)s_p[oy + i][lx + R + lo];
-            any |= cnt > 0;
-            all &= cnt == hi - lo;
-        }
-        if (x < w && y < h) dst[(size_t)y * w + x] = (dilate ? any : all) ? 255 : 0;
+        const int x = blockIdx.x * NAV_TW + lx, y = blockIdx.y * NAV_TH + ly + 4 * q;
+        if (x < w && y < h) dst[(size_t)y * w + x] = (dilate ? any[q] : all[q]) ? 255 : 0;
     }
 }
 
