@@ -152,29 +152,26 @@ __device__ void jacobi_wave(double* A, double* W, double* V, int* indR, int* ind
                 V[n * l + i] = a0 * s + b0 * c;
             }
             __syncthreads();
-            if (lane < 4) {
-                const int idx = (lane & 2) ? l : k;
-                if ((lane & 1) == 0) {
-                    if (idx < n - 1) {
-                        int m = idx + 1;
-                        double mv = fabs(A[n * idx + m]);
-                        for (int i = idx + 2; i < n; i++) {
-                            const double v2 = fabs(A[n * idx + i]);
-                            if (mv < v2) mv = v2, m = i;
-                        }
-                        indR[idx] = m;
-                    }
+            // indR[k], indC[k], indR[l], indC[l] again: the sequential scans "first largest |a| of row
+            // idx right of the diagonal" / "... of column idx above it", each by one group of 16 lanes
+            // (lane i looks at element i, then a first-maximum reduction inside the group)
+            {
+                const int g = lane >> 4, i = lane & 15;
+                const int idx = (g & 2) ? l : k;
+                double val = -1.;
+                if ((g & 1) == 0) {
+                    if (idx < n - 1 && i > idx && i < n) val = fabs(A[n * idx + i]);
                 } else {
-                    if (idx > 0) {
-                        int m = 0;
-                        double mv = fabs(A[idx]);
-                        for (int i = 1; i < idx; i++) {
-                            const double v2 = fabs(A[n * i + idx]);
-                            if (mv < v2) mv = v2, m = i;
-                        }
-                        indC[idx] = m;
-                    }
+                    if (idx > 0 && i < idx) val = fabs(A[n * i + idx]);
                 }
+                int bi = i;
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) {
+                    const double ov = __shfl_xor(val, m, 16);
+                    const int oi = __shfl_xor(bi, m, 16);
+                    if (ov > val || (ov == val && oi < bi)) val = ov, bi = oi;
+                }
+                if (i == 0 && val >= 0.) ((g & 1) ? indC : indR)[idx] = bi;
             }
             __syncthreads();
         }
