@@ -61,6 +61,39 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+// Lane j of a row of 16 lanes receives the value of lane j - N of the same row (row_shr:N on the
+// data-parallel-primitive path of the vector ALU: no trip through LDS as a shuffle would make);
+// lanes without a source keep `fill`.
+template <int N>
+__device__ __forceinline__ int row_shr_i32(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x110 + N, 0xF, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ double row_shr_f64(double v, double fill) {
+    const int lo = row_shr_i32<N>(__double2loint(v), __double2loint(fill));
+    const int hi = row_shr_i32<N>(__double2hiint(v), __double2hiint(fill));
+    return __hiloint2double(hi, lo);
+}
+// largest value of lanes 0..15, the same in every lane of the wave (values >= 0 or -1)
+__device__ __forceinline__ double row0_max(double v) {
+    v = fmax(v, row_shr_f64<1>(v, -1.));
+    v = fmax(v, row_shr_f64<2>(v, -1.));
+    v = fmax(v, row_shr_f64<4>(v, -1.));
+    v = fmax(v, row_shr_f64<8>(v, -1.));
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 15), hi = __builtin_amdgcn_readlane(__double2hiint(v), 15);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane: the same in every lane
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// one step of the first-maximum reduction: (value, index) of this lane against those N lanes down the row
+template <int N>
+__device__ __forceinline__ void first_max_step(double& val, int& bi) {
+    const double ov = row_shr_f64<N>(val, -2.);
+    const int oi = row_shr_i32<N>(bi, 1 << 20);
+    if (ov > val || (ov == val && oi < bi)) val = ov, bi = oi;
+}
+
 // cv::JacobiImpl_<double> executed by one full wave on LDS-resident matrices
 // (A: n x n, only the upper triangle is used and it is destroyed; V: rows are the
 // eigenvectors; W: eigenvalues, descending).  The pivot choice, the rotation
@@ -97,24 +130,28 @@ __device__ void jacobi_wave(double* A, double* W, double* V, int* indR, int* ind
     if (n > 1)
         for (int iters = 0; iters < maxIters; iters++) {
             // pivot: first maximum over rows 0..n-2 (through indR), then columns 1..n-1 (through indC)
-            double val = -1.;
+            double val = -1., sval = 0., wck = 0., wcl = 0.;
             int ck = 0, cl = 0;
             if (lane < n - 1) {
                 ck = lane;
                 cl = indR[lane];
-                val = fabs(A[n * ck + cl]);
             } else if (lane < 2 * n - 2) {
                 cl = lane - (n - 1) + 1;
                 ck = indC[cl];
-                val = fabs(A[n * ck + cl]);
             }
-            const double mx = wave_max(val);
+            if (lane < 2 * n - 2) {  // the candidate element and the two eigenvalue estimates it would touch
+                sval = A[n * ck + cl];
+                wck = W[ck];
+                wcl = W[cl];
+                val = fabs(sval);
+            }
+            const double mx = row0_max(val);  // the 2n-2 <= 16 candidates sit in lanes 0..15
             const unsigned long long hit = __ballot(val == mx);
-            const int win = __ffsll((long long)hit) - 1;
-            const int k = __shfl(ck, win), l = __shfl(cl, win);
-            const double p = A[n * k + l];
+            const int win = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+            const int k = __builtin_amdgcn_readlane(ck, win), l = __builtin_amdgcn_readlane(cl, win);
+            const double p = readlane_f64(sval, win);
             if (fabs(p) <= eps) break;
-            const double y = (W[l] - W[k]) * 0.5;
+            const double y = (readlane_f64(wcl, win) - readlane_f64(wck, win)) * 0.5;
             double t = fabs(y) + cv_hypot(p, y);
             double s = cv_hypot(p, t);
             const double c = t / s;
@@ -165,13 +202,11 @@ __device__ void jacobi_wave(double* A, double* W, double* V, int* indR, int* ind
                     if (idx > 0 && i < idx) val = fabs(A[n * i + idx]);
                 }
                 int bi = i;
-#pragma unroll
-                for (int m = 8; m >= 1; m >>= 1) {
-                    const double ov = __shfl_xor(val, m, 16);
-                    const int oi = __shfl_xor(bi, m, 16);
-                    if (ov > val || (ov == val && oi < bi)) val = ov, bi = oi;
-                }
-                if (i == 0 && val >= 0.) ((g & 1) ? indC : indR)[idx] = bi;
+                first_max_step<1>(val, bi);
+                first_max_step<2>(val, bi);
+                first_max_step<4>(val, bi);
+                first_max_step<8>(val, bi);  // lane 15 of the group now holds the group's result
+                if (i == 15 && val >= 0.) ((g & 1) ? indC : indR)[idx] = bi;
             }
             __syncthreads();
         }
