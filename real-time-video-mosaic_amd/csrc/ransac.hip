@@ -618,28 +618,32 @@ __device__ void eig8_apply(RefineLds* S, const double* Asrc, bool solve) {
     S->J.A[lane] = Asrc[lane];
     __syncthreads();
     jacobi_wave(S->J.A, S->J.W, S->J.V, S->J.indR, S->J.indC, S->J.perm, 8);
-    if (lane == 0) {
-        double threshold = 0;
-        for (int i = 0; i < 8; i++) threshold += S->J.W[i];
-        threshold *= DBL_EPSILON * 2;
-        double out[8];
-        for (int j = 0; j < 8; j++) out[j] = 0;
-        for (int i = 0; i < 8; i++) {
-            double wi = S->J.W[i];
-            if (fabs(wi) <= threshold) continue;
-            wi = 1 / wi;
-            const double* vi = &S->J.V[i * 8];
-            if (solve) {
-                double s = 0;
-                for (int j = 0; j < 8; j++) s += vi[j] * S->v[j];
-                s *= wi;
-                for (int j = 0; j < 8; j++) out[j] = out[j] + s * vi[j];
-            } else {
-                for (int j = 0; j < 8; j++) out[j] = out[j] + vi[j] * (vi[j] * wi);
-            }
-        }
-        for (int j = 0; j < 8; j++) (solve ? S->d : S->diag)[j] = out[j];
+    // back-substitution through the eigenvectors, as cv::solve(DECOMP_EIG) does it: for every
+    // eigenpair above the threshold, s = (v_i . b) / w_i and x += s v_i, the pairs taken in order.
+    // Lane i < 8 forms s of pair i (its own sequential dot product); lane j < 8 then adds the
+    // eight terms of x[j] in that order.
+    double threshold = 0;
+    for (int i = 0; i < 8; i++) threshold += S->J.W[i];
+    threshold *= DBL_EPSILON * 2;
+    const int r = lane & 7;
+    const double* vi = &S->J.V[r * 8];
+    double wi = S->J.W[r];
+    const bool keep = fabs(wi) > threshold;
+    wi = 1 / wi;
+    double si = 0;
+    if (solve) {
+        for (int j = 0; j < 8; j++) si += vi[j] * S->v[j];
+        si *= wi;
     }
+    double out = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const double s_i = readlane_f64(si, i), w_i = readlane_f64(wi, i);
+        const bool keep_i = __builtin_amdgcn_readlane((int)keep, i) != 0;
+        const double vij = S->J.V[i * 8 + r];
+        if (keep_i) out = solve ? out + s_i * vij : out + vij * (vij * w_i);
+    }
+    if (lane < 8) (solve ? S->d : S->diag)[lane] = out;
     __syncthreads();
 }
 
