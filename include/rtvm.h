@@ -111,7 +111,8 @@ int rtvm_orb(rtvm_ctx* ctx, const uint8_t* bgr, int* n_out, float* xy, float* si
  * size, angle_deg, response n f32, octave n i32 (OpenCV's packed octave | layer << 8 | ...),
  * desc n*128 f32 (integer-valued 0..255).  Keypoints come sorted by (x, y), duplicates removed,
  * the nfeatures strongest kept (ties included).  Allocates its pyramids on the first call (and
- * again for a larger frame); syncs. */
+ * again for a larger frame); syncs.  Frames 16..8192 pixels a side; RTVM_E_NOMEM when a frame
+ * has more than 262144 scale-space extrema or 65536 keypoints before the filtering. */
 int rtvm_sift_max_keypoints(int nfeatures);
 int rtvm_sift(rtvm_ctx* ctx, const uint8_t* bgr, int h, int w, int nfeatures, int* n_out, float* xy,
               float* size, float* angle_deg, float* response, int32_t* octave, float* desc);
