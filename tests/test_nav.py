@@ -266,7 +266,10 @@ def test_hip_nav_obstacles_match_oracle(ctx, h, w, seed):
 def test_hip_nav_obstacles_on_noise_and_flat_images(ctx):
     rng = np.random.default_rng(9)
     for img in (rng.integers(0, 256, (150, 211, 3)).astype(np.uint8), np.full((90, 70, 3), 128, np.uint8),
-                np.zeros((33, 65, 3), np.uint8), rng.integers(100, 140, (200, 100, 3)).astype(np.uint8)):
+                np.zeros((33, 65, 3), np.uint8), rng.integers(100, 140, (200, 100, 3)).astype(np.uint8),
+                # smaller than the 11x11 windows: the borders fold more than once
+                rng.integers(90, 160, (5, 7, 3)).astype(np.uint8), rng.integers(0, 256, (1, 40, 3)).astype(np.uint8),
+                rng.integers(60, 200, (11, 3, 3)).astype(np.uint8), rng.integers(0, 256, (1, 1, 3)).astype(np.uint8)):
         got, want = ctx.nav_obstacles(img), orc.nav_obstacles(img)
         for k in want:
             assert np.array_equal(got[k], want[k]), k
