@@ -70,3 +70,34 @@ def test_hip_sift_flat_image_and_bad_arguments():
     with pytest.raises(RuntimeError):
         ctx.sift(np.zeros((8, 8, 3), np.uint8), 100)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,nf", [((16, 16), 50), ((17, 40), 100), ((32, 24), 100), ((45, 80), 2000)])
+def test_hip_sift_small_frames_match_oracle(shape, nf):
+    """Frames whose whole pyramid is a few small octaves (built by the one-workgroup kernel from octave 1 on)."""
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, (shape[0], shape[1], 3)).astype(np.uint8)
+    img = np.repeat(np.repeat(img[::2, ::2], 2, 0), 2, 1)[:shape[0], :shape[1]]   # 2x2 blocks: some structure
+    ctx = rtvm.Context()
+    got, want = ctx.sift(img, nf), orc.sift(img, nf)
+    assert len(got["xy"]) == len(want["xy"])
+    for k in ("xy", "size", "angle", "response", "octave", "desc"):
+        assert np.array_equal(got[k], want[k]), k
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_sift_many_keypoints_match_oracle():
+    """A field of blobs: more than 8192 keypoints, so the keypoint list comes back in two copies."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(77)
+    f = ndi.gaussian_filter(rng.normal(size=(720, 1280)), 1.6)
+    g = np.clip(128 + f / f.std() * 60, 0, 255).astype(np.uint8)
+    img = np.repeat(g[:, :, None], 3, 2)
+    ctx = rtvm.Context()
+    got, want = ctx.sift(img, 30000), orc.sift(img, 30000)
+    assert len(got["xy"]) == len(want["xy"]) and len(want["xy"]) > 8192
+    for k in ("xy", "size", "angle", "response", "octave", "desc"):
+        assert np.array_equal(got[k], want[k]), k
+    ctx.close()
