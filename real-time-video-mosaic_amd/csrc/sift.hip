@@ -344,13 +344,13 @@ __device__ __forceinline__ float angle_deg(float y, float x) {
 }
 
 // calcOrientationHist by one wave: 64 window positions at a time (gradient, exp, atan2, bin),
-// lane 0 adds the weighted magnitudes to the 36 bins in scan order.  Returns the largest
+// lane b adds the weighted magnitudes that fall into bin b in scan order.  Returns the largest
 // smoothed bin; hist (LDS) holds the smoothed histogram.
 __device__ float orientation_hist(const SImg img, int px, int py, int radius, float sigma, float* temphist, float* hist,
                                   float* s_val, int* s_bin) {
     const int n = ORI_BINS, lane = threadIdx.x;
     const float expf_scale = -1.f / (2.f * sigma * sigma);
-    if (lane < n) temphist[lane] = 0.f;
+    float acc = 0.f;  // bin `lane` of the raw histogram
     const int side = 2 * radius + 1;
     const unsigned total = (unsigned)side * (unsigned)side;  // side <= 2 * 23170 + 1: fits 32 bits unsigned
     __syncthreads();
@@ -374,11 +374,21 @@ __device__ float orientation_hist(const SImg img, int px, int py, int radius, fl
         }
         s_bin[lane] = bin;
         __syncthreads();
-        if (lane == 0)
-            for (int l = 0; l < 64; l++)
-                if (s_bin[l] >= 0) temphist[s_bin[l]] += s_val[l];
+        // lane b owns bin b in a register and takes the samples in scan order: every bin receives its
+        // terms in the order of the sequential loop
+#pragma unroll
+        for (int l0 = 0; l0 < 64; l0 += 8) {
+            const int4 ba = *reinterpret_cast<const int4*>(&s_bin[l0]), bb = *reinterpret_cast<const int4*>(&s_bin[l0 + 4]);
+            const float4 va = *reinterpret_cast<const float4*>(&s_val[l0]), vb = *reinterpret_cast<const float4*>(&s_val[l0 + 4]);
+            const int b[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+            const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = b[u] == lane ? acc + v[u] : acc;
+        }
         __syncthreads();
     }
+    if (lane < n) temphist[lane] = acc;
+    __syncthreads();
     if (lane < n) {
         const int i = lane;
         const float m2 = temphist[(i + n - 2) % n], m1 = temphist[(i + n - 1) % n];
@@ -399,8 +409,9 @@ __device__ float orientation_hist(const SImg img, int px, int py, int radius, fl
 __global__ __launch_bounds__(64) void k_sift_refine(const SPyr* __restrict__ P, const unsigned long long* __restrict__ keys,
                                                     const int* __restrict__ count, int cap, SKp* __restrict__ list,
                                                     int* __restrict__ list_count, int list_cap) {
-    __shared__ float temphist[ORI_BINS], hist[ORI_BINS], s_val[64];
-    __shared__ int s_bin[64];
+    __shared__ float temphist[ORI_BINS], hist[ORI_BINS];
+    __shared__ __align__(16) float s_val[64];
+    __shared__ __align__(16) int s_bin[64];
     const int lane = threadIdx.x;
     const int n = min(*count, cap);
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
