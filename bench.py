@@ -289,6 +289,17 @@ def main():
                       "note": "Python VideMosaic.process_frame with host frames: PCIe copies and one host round trip "
                               "per frame included"}
             vm.close()
+            if nd >= 16:
+                # the same frames through process_frames: detection, matching and RANSAC on four worker threads
+                vm = rtvm.VideMosaic(host_frames[0], detector_type="orb", nfeatures=nf, canvas_size=(ch, cw),
+                                     device=local_rank, warp_mode=args.warp_mode, show_intermediate=False,
+                                     visualize=False)
+                vm.process_frames(list(host_frames[1:9]), 1, workers=4)
+                td0 = time.perf_counter()
+                vm.process_frames(list(host_frames[9:]), 9, workers=4)
+                vm.output_img_u8()
+                dropin["process_frames_4_workers"] = {"value": (nd - 8) / (time.perf_counter() - td0), "frames": nd - 8}
+                vm.close()
         sift_leg = None
         if args.sift_frames > 0 and world == 1:
             # the reference's default detector (main.py:1603 passes "sift"): the drop-in class frame by frame,

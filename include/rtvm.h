@@ -307,6 +307,12 @@ int rtvm_first_frame(rtvm_ctx* ctx, const uint8_t* bgr, int row_off, int col_off
 /* main.py:716-731: upload the frame, detect, match against the previous frame,
  * RANSAC.  *found = 0 when there are fewer than 4 matches or no model.  Syncs. */
 int rtvm_frame_register(rtvm_ctx* ctx, const uint8_t* bgr, int* n_matches, int* found, double H_rel[9]);
+/* main.py:757-758 alone (frame_prev, kp_prev, des_prev = this frame): detects on the host frame
+ * and makes its features the previous ones; canvas, homographies and history are left as they
+ * are.  For hosts that stitched some frames through the stage entry points (rtvm_orb,
+ * rtvm_match_*, rtvm_find_homography_ransac, rtvm_warp_blend) and go back to the two-call
+ * form.  Syncs. */
+int rtvm_stream_set_prev(rtvm_ctx* ctx, const uint8_t* bgr);
 /* main.py:748, 756-759: warp + blend the registered frame with the absolute
  * homography H, then make it the previous frame.  Asynchronous: the work is queued behind
  * the registration on the context's stream; rtvm_frame_register, rtvm_canvas_read and the

@@ -75,6 +75,7 @@ SIGNATURES = {
     "rtvm_first_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_frame_register": (C.c_int, [_vp, _vp, _intp, _intp, _vp]),
     "rtvm_frame_commit": (C.c_int, [_vp, _vp]),
+    "rtvm_stream_set_prev": (C.c_int, [_vp, _vp]),
     "rtvm_get_features": (C.c_int, [_vp, C.c_int, _intp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtvm_get_matches": (C.c_int, [_vp, _intp, _vp, _vp, _vp]),
     "rtvm_profile_start": (C.c_int, [_vp, C.c_char_p]),
@@ -440,6 +441,12 @@ class Context:
         H = np.zeros(9, np.float64)
         self._check(lib().rtvm_frame_register(self._h, ptr(bgr), C.byref(m), C.byref(found), ptr(H)))
         return m.value, bool(found.value), H.reshape(3, 3)
+
+    def stream_set_prev(self, bgr):
+        """Makes the features of this host frame kp_prev/des_prev of the stream (nothing else changes)."""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        assert bgr.shape == (self.frame_h, self.frame_w, 3)
+        self._check(lib().rtvm_stream_set_prev(self._h, ptr(bgr)))
 
     def frame_commit(self, H):
         H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)

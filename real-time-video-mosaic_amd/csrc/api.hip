@@ -369,8 +369,8 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
     c->detector = detector;
     c->nfeatures = nfeatures;
     c->flags = flags;
-    // A context without a frame size serves the stage entry points only, one call at a time: it
-    // gets a single stream.  (A process has few hardware queues and streams are dealt onto them in
+    // A context without a frame size (or with RTVM_FLAG_SINGLE_STREAM) serves the stage entry
+    // points only, one call at a time: it gets a single stream.  (A process has few hardware queues and streams are dealt onto them in
     // turn; four streams per context would put the working streams of several such contexts, one
     // per host thread, onto the same queue.)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream_main) != hipSuccess) {
@@ -378,7 +378,7 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
         return RTVM_E_HIP;
     }
     c->stream_front = c->stream_rs = c->stream_lm = c->stream_main;
-    if (frame_h > 0) {
+    if (frame_h > 0 && !(flags & RTVM_FLAG_SINGLE_STREAM)) {
         hipStream_t* more[3] = {&c->stream_front, &c->stream_rs, &c->stream_lm};
         for (hipStream_t* st : more)
             if (hipStreamCreate(st) != hipSuccess) {

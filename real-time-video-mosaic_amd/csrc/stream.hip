@@ -699,6 +699,25 @@ extern "C" int rtvm_frame_register(rtvm_ctx* c, const uint8_t* bgr, int* n_match
     return RTVM_OK;
 }
 
+extern "C" int rtvm_stream_set_prev(rtvm_ctx* c, const uint8_t* bgr) {
+    if (!c) return RTVM_E_ARG;
+    if (!bgr) RTVM_FAIL(c, RTVM_E_ARG, "stream_set_prev: null frame");
+    int r = need_stream_ctx(c, "stream_set_prev");
+    if (r) return r;
+    if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "stream_set_prev: call rtvm_first_frame first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bgr, bgr, (size_t)c->fh * c->fw * 3, hipMemcpyHostToDevice, c->stream));
+    const uint8_t* p = c->d_bgr;
+    c->spec_tail = -1;
+    if ((r = bind_batch(c, 0, &p, 1, c->feat_prev))) return r;
+    if ((r = rtvm_launch_orb(c, 0, 1))) return r;
+    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
+                c->feat_prev, c->orb.max_kp);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTVM_OK;
+}
+
 extern "C" int rtvm_frame_commit(rtvm_ctx* c, const double H[9]) {
     if (!c) return RTVM_E_ARG;
     if (!H) RTVM_FAIL(c, RTVM_E_ARG, "frame_commit: null homography");

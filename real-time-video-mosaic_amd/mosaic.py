@@ -119,8 +119,9 @@ class VideMosaic:
         self._cache.clear()
         self._finish_frame(frame_cur, len(self._sift_matches[0]), H_relative is not None, H_relative)
 
-    def _finish_frame(self, frame_cur, n_matches, found, H_relative):
-        """main.py:722-759 after matching and RANSAC: skip rules, validate, smooth, chain, warp."""
+    def _finish_frame(self, frame_cur, n_matches, found, H_relative, staged=False):
+        """main.py:722-759 after matching and RANSAC: skip rules, validate, smooth, chain, warp.
+        staged: an ORB frame that was registered through the stage entry points, not frame_register."""
         if n_matches < 4:
             print(f"Предупреждение: Недостаточно совпадений ({n_matches}), пропуск кадра")
             return
@@ -137,6 +138,8 @@ class VideMosaic:
         if self.detector_type == "sift":
             self._ctx.warp_blend(frame_cur, self.H)   # main.py:748
             self._sift_prev = self._sift_cur          # main.py:757-758
+        elif staged:
+            self._ctx.warp_blend(frame_cur, self.H)
         else:
             self._ctx.frame_commit(self.H)
         self._canvas_cache = None
@@ -147,51 +150,78 @@ class VideMosaic:
     def process_frames(self, frames, first_frame_count=1, workers=4):
         """process_frame(frames[0], first_frame_count), process_frame(frames[1], ...), ... with the
         same results, state and printed warnings, for callers that have several frames at hand
-        (a decoder's queue).  With the SIFT detector the frames' detection, matching and RANSAC
-        run on `workers` threads, each with a device context of its own, ahead of the
-        sequential part (skip rules, validate, smooth, chain, warp + blend), which keeps frame
-        order.  Every frame is matched against its predecessor on the assumption that the
-        predecessor is not skipped; after a skipped frame (main.py:722-731) the next one is
-        registered again against the frame the reference would have used.  ORB has the batched
-        device pipeline (Context.process_video) for this purpose; here its frames go one by one."""
+        (a decoder's queue).  Detection, matching and RANSAC of a frame depend only on the frame
+        and its predecessor, so they run on `workers` threads, each with a device context of its
+        own, ahead of the sequential part (skip rules, validate, smooth, chain, warp + blend), which
+        keeps frame order.  Every frame is matched against its predecessor on the assumption that
+        the predecessor is not skipped; after a skipped frame (main.py:722-731) the next one is
+        registered again against the frame the reference would have used.  With ORB the last frame
+        goes through process_frame itself, after the previous features of the device stream have
+        been set to those of the last stitched frame, so that the object is left exactly as by
+        per-frame calls.  (Frames already on the GPU: Context.process_video is the faster path.)"""
         frames = list(frames)
-        if self.detector_type != "sift" or workers < 2 or len(frames) < 2:
+        sift = self.detector_type == "sift"
+        n = len(frames) if sift else len(frames) - 1   # ORB: the last frame takes the ordinary path
+        if workers < 2 or n < 2:
             for i, frame in enumerate(frames):
                 self.process_frame(frame, first_frame_count + i)
             return
+        import gc
         import queue
         from concurrent.futures import Future, ThreadPoolExecutor
 
+        fh, fw = self._ctx.frame_h, self._ctx.frame_w
         if getattr(self, "_worker_ctxs", None) is None or len(self._worker_ctxs) < workers:
             have = getattr(self, "_worker_ctxs", None) or []
-            self._worker_ctxs = have + [_ffi.Context(device=self._ctx.device) for _ in range(workers - len(have))]
+            make = (lambda: _ffi.Context(device=self._ctx.device)) if sift else \
+                (lambda: _ffi.Context(fh, fw, 0, 0, _ffi.DET_ORB, self._nfeatures, _ffi.FLAG_SINGLE_STREAM, self._ctx.device))
+            self._worker_ctxs = have + [make() for _ in range(workers - len(have))]
         free = queue.SimpleQueue()
         for c in self._worker_ctxs[:workers]:
             free.put(c)
-        n = len(frames)
         detected = [Future() for _ in range(n)]
-        prev0 = self._sift_prev
         nfeatures = self._nfeatures
+        if sift:
+            prev0 = self._sift_prev
+            detect = lambda ctx, frame: ctx.sift(frame, nfeatures)
+            register = self._sift_register
+        else:
+            prev0 = self._ctx.get_features(1)
+            detect = lambda ctx, frame: ctx.orb(frame)
+            register = self._orb_register
+        state = {"prev": prev0, "prev_frame": None}
 
         def work(t):
             ctx = free.get()
             try:
                 try:
-                    cur = ctx.sift(np.ascontiguousarray(frames[t], dtype=np.uint8), nfeatures)
+                    cur = detect(ctx, np.ascontiguousarray(frames[t], dtype=np.uint8))
                 except BaseException as e:
                     detected[t].set_exception(e)
                     raise
                 detected[t].set_result(cur)
                 # the task of frame t-1 started before this one and waits only for earlier frames
                 prev = prev0 if t == 0 else detected[t - 1].result()
-                return cur, prev, self._sift_register(ctx, cur, prev)
+                return cur, prev, register(ctx, cur, prev)
             finally:
                 free.put(ctx)
+
+        def finish(frame, cur, registered):
+            if sift:
+                self._sift_finish(frame, cur, registered)
+                return
+            # the ORB frame, stitched through the stage entry points: same arithmetic as
+            # frame_register / frame_commit, the previous features kept here instead of on the device
+            (qi, ti, di), H_relative = registered
+            self._cache.clear()
+            before = self.H_old
+            self._finish_frame(frame, len(qi), H_relative is not None, H_relative, staged=True)
+            if self.H_old is not before:   # the frame was stitched: it is the previous frame now
+                state["prev"], state["prev_frame"] = cur, frame
 
         ahead = 4 * workers
         # a full pass of the cyclic garbage collector stops every thread for tens of milliseconds in a
         # process that has imported numpy and torch; what this loop allocates is freed by reference counts
-        import gc
         collector_was_on = gc.isenabled()
         gc.disable()
         try:
@@ -203,12 +233,30 @@ class VideMosaic:
                     if t + ahead < n:
                         tasks.append(pool.submit(work, t + ahead))
                     self.frame_cur = frames[t]
-                    if prev is not self._sift_prev:   # the predecessor was skipped
-                        registered = self._sift_register(_stage_ctx(), cur, self._sift_prev)
-                    self._sift_finish(frames[t], cur, registered)
+                    actual_prev = self._sift_prev if sift else state["prev"]
+                    if prev is not actual_prev:   # the predecessor was skipped
+                        registered = register(_stage_ctx(), cur, actual_prev)
+                    finish(frames[t], cur, registered)
         finally:
             if collector_was_on:
                 gc.enable()
+        if not sift:
+            if state["prev_frame"] is not None:
+                self._ctx.stream_set_prev(state["prev_frame"])
+            self.process_frame(frames[-1], first_frame_count + len(frames) - 1)
+
+    @staticmethod
+    def _orb_register(ctx, cur, prev):
+        """main.py:721-731 for ORB features: (matches as arrays sorted by distance, H_relative or None)."""
+        if len(cur["xy"]) and len(prev["xy"]):
+            matches = ctx.match_hamming(cur["desc"], prev["desc"], sorted_by_distance=True)
+        else:
+            matches = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+        qi, ti, _ = matches
+        H_relative = None
+        if len(qi) >= 4:
+            H_relative, _ = ctx.find_homography(cur["xy"][qi], prev["xy"][ti], 2.0)
+        return matches, H_relative
 
     # ------------------------------------------------------------------ lazily fetched state
     def _features(self, slot):

@@ -422,6 +422,30 @@ def test_process_frames_equals_frame_by_frame(capsys, detector, workers):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("detector,nf", [("orb", 1000), ("sift", 700)])
+def test_process_frames_at_720p_equals_frame_by_frame(detector, nf):
+    """The bench's video at full size: 24 frames through process_frames in two calls against process_frame."""
+    import torch
+    fh, fw = 720, 1280
+    Gs, wh, ww = rtvm.synth.bounded_path(25, fh, fw, seed=2)
+    world = rtvm.synth.make_world(wh, ww, seed=0)
+    frames = list(rtvm.synth.render_video_torch(world, Gs, fh, fw, torch.device("cuda", 0)).cpu().numpy())
+    kw = dict(detector_type=detector, visualize=False, show_intermediate=False, nfeatures=nf)
+    a = rtvm.VideMosaic(frames[0], **kw)
+    for t, f in enumerate(frames[1:], 1):
+        a.process_frame(f, t)
+    b = rtvm.VideMosaic(frames[0], **kw)
+    b.process_frames(frames[1:14], 1, workers=4)
+    b.process_frames(frames[14:], 14, workers=3)
+    assert np.array_equal(a.H, b.H) and len(a.homography_history) == len(b.homography_history)
+    assert np.array_equal(a.des_prev, b.des_prev) and np.array_equal(a.des_cur, b.des_cur)
+    assert [(m.queryIdx, m.trainIdx, m.distance) for m in a.matches] == [(m.queryIdx, m.trainIdx, m.distance) for m in b.matches]
+    assert np.array_equal(a.output_img_u8(), b.output_img_u8())
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fh,fw,ch,cw,nf,batch", [(1080, 1920, 2160, 2304, 1000, 4), (2160, 3840, 4096, 16384, 4000, 3)])
 def test_full_size_configs_batched_equals_frame_by_frame(fh, fw, ch, cw, nf, batch):
     """At the 1080p and the 4K / 16384-wide-canvas sizes the oracle is too slow to run per test; what is checked
