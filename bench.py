@@ -131,7 +131,7 @@ def main():
                     help="frames of the video also run from host memory through the ingest ring (0 = skip)")
     ap.add_argument("--sift-frames", type=int, default=144,
                     help="frames of the PCIe-inclusive sample through VideMosaic with the SIFT detector (0 = skip)")
-    ap.add_argument("--dropin-frames", type=int, default=32,
+    ap.add_argument("--dropin-frames", type=int, default=136,
                     help="frames of the PCIe-inclusive sample through the Python VideMosaic class (0 = skip)")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel timing table to this JSON file")
     args = ap.parse_args()
