@@ -49,8 +49,11 @@ enum {
                                       (1/32-pixel fixed point); default is the
                                       fp32 arithmetic of OpenCV >= 4.11 */
     RTVM_FLAG_MATCH_LEGACY = 1 << 1, /* reserved: one-sided cross-check of OpenCV < 4.2 */
-    RTVM_FLAG_SINGLE_STREAM = 1 << 2 /* rtvm_process_batch queues everything on one HIP
-                                        stream (no overlap of consecutive batches) */
+    RTVM_FLAG_SINGLE_STREAM = 1 << 2 /* the context owns one HIP stream: rtvm_process_batch
+                                        queues everything on it (no overlap of consecutive
+                                        batches).  Also the choice for contexts that only serve
+                                        stage calls from a thread of their own: a process has few
+                                        hardware queues and every stream takes a share of one */
 };
 
 /* per-frame status bits reported by rtvm_process_frame / rtvm_frame_status */
