@@ -142,6 +142,14 @@ int rtvm_find_homography_ransac(rtvm_ctx* ctx, const float* src_xy, const float*
                                 double thresh, int max_iters, double confidence, double H[9],
                                 uint8_t* inlier_mask, int* found);
 
+/* VideMosaic.validate_homography(H)  main.py:761-801 with the thresholds of main.py:100-101
+ * (50 px, 0.3): *ok = 1 when H passes.  The arithmetic is the one the device-resident stream
+ * path applies to every frame (the 2x2 determinant as an LU factorisation with partial pivoting
+ * evaluates it, like numpy.linalg.det; sqrt of a negative determinant is NaN and fails no
+ * comparison).  Stage parity only.  Syncs. */
+int rtvm_validate_homography(rtvm_ctx* ctx, const double H[9], double translation_threshold,
+                             double scale_threshold, int* ok);
+
 /* Canvas zero-fill and paste of the first frame at (row_off, col_off)  main.py:80-90. */
 int rtvm_canvas_init(rtvm_ctx* ctx, const uint8_t* first_bgr, int row_off, int col_off);
 

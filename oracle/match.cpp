@@ -8,6 +8,13 @@
 #include <cstring>
 #include <vector>
 
+int rtvm_oracle_nthreads = 1;
+extern "C" int rtvm_oracle_set_threads(int n) {
+    const int old = rtvm_oracle_nthreads;
+    rtvm_oracle_nthreads = n < 1 ? 1 : n;
+    return old;
+}
+
 namespace {
 
 inline int hamming32(const uint8_t* a, const uint8_t* b) {
@@ -22,6 +29,7 @@ void nearest(const uint8_t* A, int nA, const uint8_t* B, int nB, std::vector<int
              std::vector<int>& dst) {
     idx.assign(nA, -1);
     dst.assign(nA, 0x7fffffff);
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (int i = 0; i < nA; i++)
         for (int j = 0; j < nB; j++) {
             int d = hamming32(A + 32 * i, B + 32 * j);
@@ -71,6 +79,7 @@ extern "C" int rtvm_oracle_match_hamming_xcheck(const uint8_t* q, int nq, const 
 extern "C" int rtvm_oracle_match_l2_knn2(const float* q, int nq, const float* t, int nt, int dim,
                                          int32_t* idx, float* dist) {
     if (nq < 0 || nt < 2 || dim <= 0) return -1;
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (int i = 0; i < nq; i++) {
         float d0 = INFINITY, d1 = INFINITY;
         int i0 = -1, i1 = -1;

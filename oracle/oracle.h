@@ -25,6 +25,11 @@
 extern "C" {
 #endif
 
+/* Threads the per-pixel and per-row loops may use (OpenMP; default 1).  Only loops whose
+ * iterations are independent are split, so the results do not depend on the count. */
+extern int rtvm_oracle_nthreads;
+int rtvm_oracle_set_threads(int n);
+
 /* main.py:111,717  cv2.cvtColor(BGR2GRAY) */
 void rtvm_oracle_gray(const uint8_t* bgr, int h, int w, uint8_t* gray);
 

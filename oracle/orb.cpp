@@ -76,6 +76,7 @@ void resize_exact(const Img& s, Img& d, int dw, int dh) {
         if (xc[x] < 0) return (unsigned)s.at(sy, xo[x]) << 8;
         return (unsigned)(256 - xc[x]) * s.at(sy, xo[x]) + (unsigned)xc[x] * s.at(sy, xo[x] + 1);
     };
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (int y = 0; y < dh; y++)
         for (int x = 0; x < dw; x++) {
             unsigned v;
@@ -107,12 +108,14 @@ void blur7(const Img& s, Img& d) {
     d.h = s.h;
     d.px.assign(s.px.size(), 0);
     std::vector<int> rows((size_t)s.w * s.h);
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (int y = 0; y < s.h; y++)
         for (int x = 0; x < s.w; x++) {
             int a = 0;
             for (int i = 0; i < 7; i++) a += k[i] * s.at(y, reflect101(x + i - 3, s.w));
             rows[(size_t)y * s.w + x] = a;
         }
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (int y = 0; y < s.h; y++)
         for (int x = 0; x < s.w; x++) {
             unsigned a = 0;
@@ -135,6 +138,7 @@ void fast9(const Img& im, std::vector<KP>& out, int level) {
                                     {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
     const int w = im.w, h = im.h;
     std::vector<uint8_t> score((size_t)w * h, 0);
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (int y = 3; y < h - 3; y++)
         for (int x = 3; x < w - 3; x++) {
             const int v = im.at(y, x);
@@ -330,6 +334,7 @@ extern "C" void rtvm_oracle_set_orb_pattern(const int32_t* pattern1024) {
 
 // cvtColor(BGR2GRAY), 8-bit: (B*3735 + G*19235 + R*9798 + 16384) >> 15
 extern "C" void rtvm_oracle_gray(const uint8_t* bgr, int h, int w, uint8_t* gray) {
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (size_t p = 0; p < (size_t)h * w; p++)
         gray[p] = (uint8_t)((bgr[3 * p] * 3735 + bgr[3 * p + 1] * 19235 + bgr[3 * p + 2] * 9798 + (1 << 14)) >> 15);
 }
@@ -399,6 +404,7 @@ extern "C" int rtvm_oracle_orb(const uint8_t* bgr, int h, int w, int nfeatures, 
     if ((int)all.size() > cap) return -3;
     std::vector<Img> blur(NLEVELS);
     for (int l = 0; l < NLEVELS; l++) blur7(pyr[l], blur[l]);
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (size_t i = 0; i < all.size(); i++) {
         const KP& k = all[i];
         const float sf = scale[k.level];

@@ -59,6 +59,7 @@ void gauss_blur(const ImgF& s, double sigma, ImgF& d) {
     }
     ImgF rows;
     rows.h = s.h, rows.w = s.w, rows.px.resize(s.px.size());
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (int y = 0; y < s.h; y++)
         for (int x = 0; x < s.w; x++) {
             float a = k[0] * s.at(y, reflect101(x - half, s.w));
@@ -66,6 +67,7 @@ void gauss_blur(const ImgF& s, double sigma, ImgF& d) {
             rows.px[(size_t)y * s.w + x] = a;
         }
     d.h = s.h, d.w = s.w, d.px.resize(s.px.size());
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (int y = 0; y < s.h; y++)
         for (int x = 0; x < s.w; x++) {
             float a = k[half] * rows.at(y, x);
@@ -420,6 +422,7 @@ extern "C" int rtvm_oracle_sift(const uint8_t* bgr, int h, int w, int nfeatures,
     const int cap = rtvm_oracle_sift_max_keypoints(nfeatures);
     const int n = std::min((int)uniq.size(), cap);
     *n_out = n;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(rtvm_oracle_nthreads)
     for (int q = 0; q < n; q++) {
         Kp kp = uniq[q];
         // descriptor on the pyramid image the keypoint was found in

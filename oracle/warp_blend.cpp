@@ -57,6 +57,7 @@ extern "C" int rtvm_oracle_warp_perspective(const uint8_t* bgr, int fh, int fw, 
     if (fixed) {
         const int bh0 = ch < 16 ? ch : 16;
         const int bw0 = (1024 / bh0) < cw ? (1024 / bh0) : cw;
+    #pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
         for (int y = 0; y < ch; y++)
             for (int x = 0; x < cw; x++) {
                 const int xb = (x / bw0) * bw0, x1 = x - xb;
@@ -84,6 +85,7 @@ extern "C" int rtvm_oracle_warp_perspective(const uint8_t* bgr, int fh, int fw, 
     } else {
         float Mf[9];
         for (int i = 0; i < 9; i++) Mf[i] = (float)M[i];
+    #pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
         for (int y = 0; y < ch; y++)
             for (int x = 0; x < cw; x++) {
                 const float fx = (float)x, fy = (float)y;
@@ -197,12 +199,14 @@ extern "C" __attribute__((target_clones("fma", "default"))) void rtvm_oracle_gau
     float k[31];
     gauss31(k);
     std::vector<float> rows((size_t)h * w);
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             float s = k[0] * src[(size_t)y * w + reflect101(x - 15, w)];
             for (int i = 1; i < 31; i++) s = __builtin_fmaf(src[(size_t)y * w + reflect101(x - 15 + i, w)], k[i], s);
             rows[(size_t)y * w + x] = s;
         }
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             float s = k[15] * rows[(size_t)y * w + x];
@@ -220,7 +224,8 @@ extern "C" int rtvm_oracle_warp_blend(uint8_t* canvas, int ch, int cw, const uin
     const size_t n = (size_t)ch * cw;
     std::vector<uint8_t> warped(n * 3), mnew(n), mold(n), overlap(n);
     if (rtvm_oracle_warp_perspective(bgr, fh, fw, H, ch, cw, fixed, warped.data())) return -1;
-    bool any = false;
+    int any = 0;
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads) reduction(| : any)
     for (size_t p = 0; p < n; p++) {  // :878-882
         mnew[p] = (warped[3 * p] | warped[3 * p + 1] | warped[3 * p + 2]) ? 255 : 0;
         mold[p] = (canvas[3 * p] | canvas[3 * p + 1] | canvas[3 * p + 2]) ? 255 : 0;
@@ -229,15 +234,23 @@ extern "C" int rtvm_oracle_warp_blend(uint8_t* canvas, int ch, int cw, const uin
     }
     if (any) {  // :885
         std::vector<float> dn(n), dold(n), wn(n), wo(n), bn(n), bo(n);
-        rtvm_oracle_distance_transform(mnew.data(), ch, cw, dn.data());  // :888
-        rtvm_oracle_distance_transform(mold.data(), ch, cw, dold.data());  // :889
-        for (size_t p = 0; p < n; p++) {                                  // :892-894
+        // the two raster scans are sequential inside; with threads they run side by side
+#pragma omp parallel sections num_threads(rtvm_oracle_nthreads > 1 ? 2 : 1)
+        {
+#pragma omp section
+            rtvm_oracle_distance_transform(mnew.data(), ch, cw, dn.data());  // :888
+#pragma omp section
+            rtvm_oracle_distance_transform(mold.data(), ch, cw, dold.data());  // :889
+        }
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
+        for (size_t p = 0; p < n; p++) {  // :892-894
             const float sum = (dn[p] + dold[p]) + 1e-6f;
             wn[p] = dn[p] / sum;
             wo[p] = dold[p] / sum;
         }
         rtvm_oracle_gaussian_blur31(wn.data(), ch, cw, bn.data());  // :897
         rtvm_oracle_gaussian_blur31(wo.data(), ch, cw, bo.data());  // :898
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
         for (size_t p = 0; p < n; p++) {
             if (overlap[p]) {  // :905-910, astype(uint8) truncates
                 for (int c = 0; c < 3; c++) {
@@ -249,6 +262,7 @@ extern "C" int rtvm_oracle_warp_blend(uint8_t* canvas, int ch, int cw, const uin
             }
         }
     } else {  // :927
+#pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
         for (size_t p = 0; p < 3 * n; p++)
             if (warped[p] > 0) canvas[p] = warped[p];
     }

@@ -41,6 +41,7 @@ SIGNATURES = {
     "rtvm_match_hamming_xcheck_sorted": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _intp]),
     "rtvm_match_l2_knn2": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rtvm_find_homography_ransac": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, C.c_double, _vp, _vp, _intp]),
+    "rtvm_validate_homography": (C.c_int, [_vp, _vp, C.c_double, C.c_double, _intp]),
     "rtvm_canvas_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_warp_perspective": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rtvm_distance_transform": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
@@ -243,14 +244,13 @@ class Context:
         return lib().rtvm_max_keypoints(self._h)
 
     def gray(self, bgr):
-        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        bgr = self._frame(bgr, "gray")
         out = np.empty(bgr.shape[:2], np.uint8)
         self._check(lib().rtvm_gray(self._h, ptr(bgr), ptr(out)))
         return out
 
     def orb(self, bgr):
-        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
-        assert bgr.shape == (self.frame_h, self.frame_w, 3)
+        bgr = self._frame(bgr, "orb")
         cap = self.max_keypoints()
         n = C.c_int(0)
         xy = np.empty((cap, 2), np.float32)
@@ -301,12 +301,28 @@ class Context:
             return None, mask[:m]
         return H.reshape(3, 3), mask[:m]
 
+    def _frame(self, bgr, who):
+        """The frame as the C side reads it: C-contiguous u8 of exactly frame_h x frame_w x 3."""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        if bgr.shape != (self.frame_h, self.frame_w, 3):
+            raise ValueError("%s: frame of shape %s, the context was created for %s"
+                             % (who, bgr.shape, (self.frame_h, self.frame_w, 3)))
+        return bgr
+
+    def validate_homography(self, H, translation_threshold=50.0, scale_threshold=0.3):
+        """validate_homography (main.py:761-801) as the device-resident stream path evaluates it."""
+        H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
+        ok = C.c_int(0)
+        self._check(lib().rtvm_validate_homography(self._h, ptr(H), float(translation_threshold),
+                                                   float(scale_threshold), C.byref(ok)))
+        return bool(ok.value)
+
     def canvas_init(self, first_bgr, row_off, col_off):
-        first_bgr = np.ascontiguousarray(first_bgr, dtype=np.uint8)
+        first_bgr = self._frame(first_bgr, "canvas_init")
         self._check(lib().rtvm_canvas_init(self._h, ptr(first_bgr), int(row_off), int(col_off)))
 
     def warp_perspective(self, bgr, H):
-        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        bgr = self._frame(bgr, "warp_perspective")
         H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
         out = np.empty((self.canvas_h, self.canvas_w, 3), np.uint8)
         self._check(lib().rtvm_warp_perspective(self._h, ptr(bgr), ptr(H), ptr(out)))
@@ -320,7 +336,7 @@ class Context:
         return out
 
     def warp_blend(self, bgr, H):
-        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        bgr = self._frame(bgr, "warp_blend")
         H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
         self._check(lib().rtvm_warp_blend(self._h, ptr(bgr), ptr(H)))
 
@@ -430,13 +446,11 @@ class Context:
 
     # ---- two-call stream form (host frames, glue on the host) ---------------
     def first_frame(self, bgr, row_off, col_off):
-        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
-        assert bgr.shape == (self.frame_h, self.frame_w, 3)
+        bgr = self._frame(bgr, "first_frame")
         self._check(lib().rtvm_first_frame(self._h, ptr(bgr), int(row_off), int(col_off)))
 
     def frame_register(self, bgr):
-        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
-        assert bgr.shape == (self.frame_h, self.frame_w, 3)
+        bgr = self._frame(bgr, "frame_register")
         m, found = C.c_int(0), C.c_int(0)
         H = np.zeros(9, np.float64)
         self._check(lib().rtvm_frame_register(self._h, ptr(bgr), C.byref(m), C.byref(found), ptr(H)))
@@ -444,8 +458,7 @@ class Context:
 
     def stream_set_prev(self, bgr):
         """Makes the features of this host frame kp_prev/des_prev of the stream (nothing else changes)."""
-        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
-        assert bgr.shape == (self.frame_h, self.frame_w, 3)
+        bgr = self._frame(bgr, "stream_set_prev")
         self._check(lib().rtvm_stream_set_prev(self._h, ptr(bgr)))
 
     def frame_commit(self, H):

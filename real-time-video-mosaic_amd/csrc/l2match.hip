@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void k_l2_knn2_direct(const float* __restrict_
 int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim, int32_t* d_idx,
                         float* d_dist, float* d_norms, int* d_flag) {
     if (nq <= 0) return RTVM_OK;
-    const size_t lds_bytes = (size_t)2 * 64 * (dim + 1) * sizeof(float);
+    // two 64-row tiles; the same memory then holds the 256 partial results of the final merge
+    size_t lds_bytes = (size_t)2 * 64 * (dim + 1) * sizeof(float);
+    if (lds_bytes < 256 * sizeof(Top2)) lds_bytes = 256 * sizeof(Top2);
     if (lds_bytes > 160 * 1024) RTVM_FAIL(c, RTVM_E_ARG, "match_l2_knn2: descriptor dimension %d is too large", dim);
     const bool mfma = dim == 128 || dim == 64;
     if (mfma) {

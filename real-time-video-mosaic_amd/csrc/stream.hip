@@ -54,7 +54,9 @@ __device__ bool validate_h(const double* H, double trans_thr, double scale_thr) 
     const double translation = sqrt(tx * tx + ty * ty);
     const double a = H[0], b = H[1], c = H[3], d = H[4];
     double det;
-    if (fabs(a) >= fabs(c)) {
+    if (a == 0. && c == 0.) {
+        det = 0.;  // a zero pivot: the factorisation stops, the product of the diagonal is 0
+    } else if (fabs(a) >= fabs(c)) {
         const double l = c * (1. / a);
         det = a * (d - l * b);
     } else {
@@ -66,6 +68,14 @@ __device__ bool validate_h(const double* H, double trans_thr, double scale_thr) 
     if (fabs(scale - 1.0) > scale_thr) return false;
     if (fabs(H[6]) > 0.001 || fabs(H[7]) > 0.001) return false;
     return true;
+}
+
+// validate_homography of one matrix, for the stage entry point: out[0] = 1 when H passes.
+__global__ void k_validate(const double* __restrict__ H, double trans_thr, double scale_thr, int* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double h[9];
+    for (int i = 0; i < 9; i++) h[i] = H[i];
+    out[0] = validate_h(h, trans_thr, scale_thr) ? 1 : 0;
 }
 
 // main.py:722-746 and 756 for the n frames of a batch, in order: skip rules,
@@ -496,6 +506,25 @@ int rtvm_stream_setup(rtvm_ctx* c) {
         for (int i = 0; i < n; i++) w[n * 5 + i] = v[i] / sum;
     }
     HIP_TRY(c, hipMemcpy(c->d_wtab, w, sizeof(w), hipMemcpyHostToDevice));
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_validate_homography(rtvm_ctx* c, const double H[9], double translation_threshold,
+                                        double scale_threshold, int* ok) {
+    if (!c) return RTVM_E_ARG;
+    if (!H || !ok) RTVM_FAIL(c, RTVM_E_ARG, "validate_homography: null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double* hp = (double*)c->h_pinned + 80;
+    memcpy(hp, H, 9 * sizeof(double));
+    double* dH = c->d_H + RTVM_MAX_BATCH * 9;   // the spare entries behind the batch's homographies
+    int* d_ok = (int*)(dH + 12);
+    HIP_TRY(c, hipMemcpyAsync(dH, hp, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RTVM_LAUNCH(c, k_validate, dim3(1), dim3(64), 0, dH, translation_threshold, scale_threshold, d_ok);
+    HIP_TRY(c, hipGetLastError());
+    int* hr = (int*)(hp + 12);
+    HIP_TRY(c, hipMemcpyAsync(hr, d_ok, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *ok = *hr;
     return RTVM_OK;
 }
 

@@ -8,20 +8,25 @@ state advance); the validate / smooth / chain arithmetic between them is the
 reference's numpy, kept on the host so that the public thresholds, the history
 list and H_old behave exactly like the reference's attributes.
 """
+import threading
+
 import numpy as np
 
 from . import _ffi
 from .types import KeyPoint, DMatch, keypoints_from_arrays, matches_from_arrays
 
-_shared_ctx = None
+_stage_local = threading.local()
 
 
-def _stage_ctx():
-    """Context without frame/canvas for the stand-alone matcher / RANSAC calls."""
-    global _shared_ctx
-    if _shared_ctx is None:
-        _shared_ctx = _ffi.Context()
-    return _shared_ctx
+def _stage_ctx(device=0):
+    """Context without frame/canvas for the stand-alone matcher / RANSAC / finalisation calls:
+    one per (thread, device), since a context serves one call at a time and lives on one GPU."""
+    ctxs = getattr(_stage_local, "ctxs", None)
+    if ctxs is None:
+        ctxs = _stage_local.ctxs = {}
+    if device not in ctxs:
+        ctxs[device] = _ffi.Context(device=device)
+    return ctxs[device]
 
 
 class VideMosaic:
@@ -93,7 +98,7 @@ class VideMosaic:
         if self.detector_type == "sift":
             # main.py:716-731 with the SIFT branch of match(): detect, knn-2 + ratio, RANSAC
             cur = self._ctx.sift(frame_cur, self._nfeatures)
-            registered = self._sift_register(_stage_ctx(), cur, self._sift_prev)
+            registered = self._sift_register(self._ctx, cur, self._sift_prev)
             self._sift_finish(frame_cur, cur, registered)
         else:
             n_matches, found, H_relative = self._ctx.frame_register(frame_cur)
@@ -235,7 +240,7 @@ class VideMosaic:
                     self.frame_cur = frames[t]
                     actual_prev = self._sift_prev if sift else state["prev"]
                     if prev is not actual_prev:   # the predecessor was skipped
-                        registered = register(_stage_ctx(), cur, actual_prev)
+                        registered = register(self._ctx, cur, actual_prev)
                     finish(frames[t], cur, registered)
         finally:
             if collector_was_on:
@@ -319,8 +324,8 @@ class VideMosaic:
     def match(self, des_cur, des_prev):
         """main.py:676-708: matches sorted by distance."""
         if self.detector_type == "sift":
-            return matches_from_arrays(*self._match_sift_arrays(des_cur, des_prev))
-        qi, ti, di = _stage_ctx().match_hamming(des_cur, des_prev, sorted_by_distance=True)
+            return matches_from_arrays(*self._match_sift_arrays(des_cur, des_prev, self._ctx))
+        qi, ti, di = self._ctx.match_hamming(des_cur, des_prev, sorted_by_distance=True)
         return matches_from_arrays(qi, ti, di)
 
     @staticmethod

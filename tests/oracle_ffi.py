@@ -15,7 +15,23 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("oracle library missing: run `make oracle`")
         _lib = C.CDLL(LIB_PATH)
+        # loops over independent pixels, rows and descriptors run on several threads; the results
+        # do not depend on the count (tests/test_golden_stages.py checks 1 against many)
+        _lib.rtvm_oracle_set_threads(default_threads())
     return _lib
+
+
+def default_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def set_threads(n):
+    """Threads of the oracle's parallel loops; returns the previous count."""
+    return lib().rtvm_oracle_set_threads(int(n))
 
 
 def _p(a):

@@ -47,7 +47,9 @@ class OracleMosaic:
         else:
             translation = np.sqrt(H[0, 2] * H[0, 2] + H[1, 2] * H[1, 2])
             a, b, c, d = H[0, 0], H[0, 1], H[1, 0], H[1, 1]
-            if abs(a) >= abs(c):
+            if a == 0.0 and c == 0.0:
+                det = 0.0   # zero pivot column: LAPACK's LU leaves a zero on the diagonal
+            elif abs(a) >= abs(c):
                 det = a * (d - (c * (1.0 / a)) * b)
             else:
                 det = -(c * (b - (a * (1.0 / c)) * d))

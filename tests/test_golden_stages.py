@@ -7,6 +7,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 import oracle_ffi as orc
 
@@ -15,7 +16,18 @@ sys.path.insert(0, GOLD)
 import make_golden  # noqa: E402
 
 
-def test_oracle_stages_match_the_committed_checksums():
+@pytest.mark.parametrize("threads", [1, 5])
+def test_oracle_stages_match_the_committed_checksums(threads):
+    """With one thread (the sequential restatement) and with several (loops over independent pixels, rows and
+    descriptors split by OpenMP): the same bits."""
+    before = orc.set_threads(threads)
+    try:
+        _check_against_the_checksums()
+    finally:
+        orc.set_threads(before)
+
+
+def _check_against_the_checksums():
     with open(os.path.join(GOLD, "oracle_stage_checksums.json")) as fh:
         want = json.load(fh)
     got = make_golden.stage_outputs(orc, make_golden.stage_inputs())

@@ -91,15 +91,20 @@ def test_videmosaic_skip_rules(capsys):
     assert np.array_equal(vm.des_prev, des_prev)           # state not advanced
     vm.process_frame(frames[1], 2)                         # the stream continues afterwards
     assert vm.H is not None and not np.array_equal(vm.output_img, before)
-    # a large jump fails validate_homography: identity is used, frame still stitched
+    # a large jump fails validate_homography: the identity goes into the history, the frame is
+    # still stitched and the state still advances (main.py:734-759)
     world = synth.make_world(520, 620, seed=0)
-    far = synth.render_frame(world, synth.camera_matrix(0, 64 + 120.0, 520 - FH - 64.0), FH, FW)
-    h_before = vm.H_old.copy()
+    far = synth.render_frame(world, synth.camera_matrix(0, 64 + 60.0, 520 - FH - 64.0 - 25.0), FH, FW)
+    h_before, last_valid, canvas_before = vm.H_old.copy(), vm.last_valid_H.copy(), vm.output_img.copy()
+    n_hist = len(vm.homography_history)
     vm.process_frame(far, 3)
     out = capsys.readouterr().out
-    if "Невалидная гомография" in out:
-        assert np.array_equal(vm.homography_history[-1], np.eye(3))
-        assert not np.array_equal(vm.H_old, h_before) or True
+    assert "большое смещение" in out and "Невалидная гомография" in out
+    assert np.array_equal(vm.homography_history[-1], np.eye(3)) and len(vm.homography_history) == n_hist + 1
+    assert np.array_equal(vm.last_valid_H, last_valid)
+    assert np.array_equal(vm.H, vm.H_old) and not np.array_equal(vm.H_old, h_before)
+    assert not np.array_equal(vm.output_img, canvas_before)
+    assert np.array_equal(vm.des_prev, vm.des_cur)         # state advanced to the rejected frame
     vm.close()
 
 
