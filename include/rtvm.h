@@ -130,6 +130,25 @@ int rtvm_match_hamming_xcheck_sorted(rtvm_ctx* ctx, const uint8_t* q, int nq, co
                                      int nt, int32_t* qidx, int32_t* tidx, int32_t* dist,
                                      int* m_out);
 
+/* rtvm_match_hamming_xcheck[_sorted] for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in
+ * the reference.  It takes no context and calls no hipMalloc / hipFree or any routine that
+ * allocates: the work buffers of the matcher (slot descriptor, counts, nearest-neighbour keys of
+ * both directions, 129 KiB) are a fixed array in the library's device image, one copy per GPU,
+ * held until the process ends.  All pointers are DEVICE pointers on the current device:
+ * q_dev nq*32 u8, t_dev nt*32 u8; qidx_dev / tidx_dev / dist_dev have capacity nq; *m_out_dev
+ * receives the number of matches.  Matches come in ascending query index, or, with sorted != 0,
+ * stably sorted by distance (main.py:698).  nq, nt <= RTVM_NOALLOC_MAX_DESCRIPTORS, more is
+ * refused with RTVM_E_ARG.  The kernels are queued on hip_stream (a hipStream_t, NULL = the
+ * default stream) and the call returns without waiting.  Every call on a GPU uses that GPU's one
+ * array: calls that overlap on one GPU (other streams, other threads) race; order them.
+ * rtvm_noalloc_last_error() returns the message of the calling thread's last failure. */
+#define RTVM_NOALLOC_MAX_DESCRIPTORS 16384
+int rtvm_match_hamming_xcheck_noalloc(const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt,
+                                      int32_t* qidx_dev, int32_t* tidx_dev, int32_t* dist_dev,
+                                      int32_t* m_out_dev, int sorted, void* hip_stream);
+const char* rtvm_noalloc_last_error(void);
+
 /* cv2.BFMatcher().knnMatch(q, t, k=2)  main.py:34,688.
  * q: nq*dim f32, t: nt*dim f32 (nt >= 2); idx: nq*2 i32, dist: nq*2 f32 (ascending). */
 int rtvm_match_l2_knn2(rtvm_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim,

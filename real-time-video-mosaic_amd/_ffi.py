@@ -39,6 +39,8 @@ SIGNATURES = {
     "rtvm_orb": (C.c_int, [_vp, _vp, _intp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtvm_match_hamming_xcheck": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _intp]),
     "rtvm_match_hamming_xcheck_sorted": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _intp]),
+    "rtvm_match_hamming_xcheck_noalloc": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "rtvm_noalloc_last_error": (C.c_char_p, []),
     "rtvm_match_l2_knn2": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rtvm_find_homography_ransac": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, C.c_double, _vp, _vp, _intp]),
     "rtvm_validate_homography": (C.c_int, [_vp, _vp, C.c_double, C.c_double, _intp]),
@@ -143,6 +145,20 @@ def ptr(a):
         return None
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
+
+
+NOALLOC_MAX_DESCRIPTORS = 16384
+
+
+def match_hamming_noalloc(q_dev, nq, t_dev, nt, qidx_dev, tidx_dev, dist_dev, m_out_dev, sorted_by_distance=False,
+                          stream=0):
+    """rtvm_match_hamming_xcheck_noalloc: device addresses in and out (integers), queued on the HIP
+    stream `stream` of the current device; returns without waiting.  Allocates nothing."""
+    rc = lib().rtvm_match_hamming_xcheck_noalloc(C.c_void_p(q_dev), int(nq), C.c_void_p(t_dev), int(nt),
+                                                 C.c_void_p(qidx_dev), C.c_void_p(tidx_dev), C.c_void_p(dist_dev),
+                                                 C.c_void_p(m_out_dev), int(bool(sorted_by_distance)), C.c_void_p(stream))
+    if rc != OK:
+        raise RtvmError(rc, lib().rtvm_noalloc_last_error().decode("utf-8", "replace"))
 
 
 class HostFrameRing:

@@ -7,6 +7,8 @@
 // main.py:37,695,698).
 #include "common.h"
 
+#include <mutex>
+
 namespace {
 
 // One wave per (64 rows of A) x (64 rows of B).  Lane l keeps row l of the A
@@ -165,5 +167,108 @@ int rtvm_launch_hamming(rtvm_ctx* c, int sb, int nb, int cap_q, int cap_t, int s
     }
     RTVM_LAUNCH(c, k_xcheck_compact, dim3(nb), dim3(1024), 0, c->d_slots, sb, sorted);
     HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}
+
+// ---- the matcher for callers that cannot allocate ------------------------------------------
+//
+// Same kernels as rtvm_match_hamming_xcheck[_sorted]; what that entry point keeps in buffers of
+// its context (the slot descriptor the kernels read, the two descriptor counts, the nearest-
+// neighbour keys of both directions) lives in one file-scope device array instead, so the call
+// needs no context and allocates nothing.  Every GPU holds its own copy of the array at its own
+// address: the address is looked up once per device (hipGetSymbolAddress, with that device
+// current) and kept; host code uses only that pointer.
+
+namespace {
+
+struct NoAllocScratch {
+    FrameSlot slot;                  // what the kernels read as slots[0]
+    int counts[4];                   // nq, nt
+    uint32_t qkey[RTVM_NOALLOC_MAX_DESCRIPTORS];
+    uint32_t tkey[RTVM_NOALLOC_MAX_DESCRIPTORS];
+};
+
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices];   // device address of `scratch` on device d, null until looked up
+std::mutex g_scratch_mutex;
+thread_local char g_noalloc_err[256];
+
+// Publishes the slot descriptor and the descriptor counts of this call.
+__global__ void k_noalloc_bind(NoAllocScratch* __restrict__ sc, FrameSlot slot, int nq, int nt) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    sc->slot = slot;
+    sc->counts[0] = nq;
+    sc->counts[1] = nt;
+}
+
+int noalloc_fail(int code, const char* msg) {
+    snprintf(g_noalloc_err, sizeof(g_noalloc_err), "%s", msg);
+    return code;
+}
+
+}  // namespace
+
+extern "C" const char* rtvm_noalloc_last_error(void) { return g_noalloc_err; }
+
+extern "C" int rtvm_match_hamming_xcheck_noalloc(const uint8_t* q_dev, int nq, const uint8_t* t_dev, int nt,
+                                                 int32_t* qidx_dev, int32_t* tidx_dev, int32_t* dist_dev,
+                                                 int32_t* m_out_dev, int sorted, void* hip_stream) {
+    g_noalloc_err[0] = 0;
+    if (nq < 0 || nt < 0 || !m_out_dev || (nq > 0 && (!q_dev || !qidx_dev || !tidx_dev || !dist_dev)) || (nt > 0 && !t_dev))
+        return noalloc_fail(RTVM_E_ARG, "match_hamming_xcheck_noalloc: bad argument");
+    if (nq > RTVM_NOALLOC_MAX_DESCRIPTORS || nt > RTVM_NOALLOC_MAX_DESCRIPTORS) {
+        snprintf(g_noalloc_err, sizeof(g_noalloc_err),
+                 "match_hamming_xcheck_noalloc: %d x %d descriptors, the fixed scratch holds at most %d per side", nq, nt,
+                 RTVM_NOALLOC_MAX_DESCRIPTORS);
+        return RTVM_E_ARG;
+    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+        return noalloc_fail(RTVM_E_HIP, "match_hamming_xcheck_noalloc: no current HIP device");
+    NoAllocScratch* sc;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {
+            void* p = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !p) {
+                snprintf(g_noalloc_err, sizeof(g_noalloc_err), "hipGetSymbolAddress(scratch) on device %d failed: %s", dev,
+                         hipGetErrorString(e));
+                return RTVM_E_HIP;
+            }
+            g_scratch_ptr[dev] = p;
+        }
+        sc = static_cast<NoAllocScratch*>(g_scratch_ptr[dev]);
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    FrameSlot slot;
+    memset(&slot, 0, sizeof(slot));
+    slot.feat.desc = const_cast<uint8_t*>(q_dev);
+    slot.prev.desc = const_cast<uint8_t*>(t_dev);
+    slot.feat.count = &sc->counts[0];
+    slot.prev.count = &sc->counts[1];
+    slot.qkey = sc->qkey;
+    slot.tkey = sc->tkey;
+    slot.m_qidx = qidx_dev;
+    slot.m_tidx = tidx_dev;
+    slot.m_dist = dist_dev;
+    slot.m_count = m_out_dev;
+    const FrameSlot* slots = &sc->slot;
+    hipLaunchKernelGGL(k_noalloc_bind, dim3(1), dim3(64), 0, stream, sc, slot, nq, nt);
+    const int nfill = nq > nt ? nq : nt;
+    if (nfill > 0) {
+        // the keys keep the previous call's values: both directions start at "no neighbour" again
+        hipLaunchKernelGGL(k_match_init, dim3((nfill + 255) / 256, 1), dim3(256), 0, stream, slots, 0, nq, nt);
+        const int tiles = (nfill + 63) / 64;
+        hipLaunchKernelGGL(k_hamming_argmin, dim3(tiles, tiles, 2), dim3(64), 0, stream, slots, 0);
+    }
+    hipLaunchKernelGGL(k_xcheck_compact, dim3(1), dim3(1024), 0, stream, slots, 0, sorted ? 1 : 0);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_noalloc_err, sizeof(g_noalloc_err), "match_hamming_xcheck_noalloc: launch failed: %s", hipGetErrorString(e));
+        return RTVM_E_HIP;
+    }
     return RTVM_OK;
 }
