@@ -15,8 +15,9 @@
  *   - every array argument is caller-owned, C-contiguous, and sized as the
  *     comment states.  Pointers are host pointers unless the entry point says
  *     "device".  Nothing returned has to be freed by the caller.
- *   - a context is single-threaded (one video stream, one HIP stream, one
- *     device).  Distinct contexts may be used from distinct threads/processes.
+ *   - a context is single-threaded (one video stream on one device; it owns four
+ *     HIP streams, or one with RTVM_FLAG_SINGLE_STREAM or without a frame size).
+ *     Distinct contexts may be used from distinct threads/processes.
  *   - this library contains no CPU fallback: with no usable HIP device
  *     rtvm_create() fails with RTVM_E_HIP.
  */
@@ -253,6 +254,42 @@ int rtvm_batch_retry(rtvm_ctx* ctx, long ticket, int first, int count);
  * detected behind it were matched against the wrong frame: release them and detect again. */
 int rtvm_batch_detect(rtvm_ctx* ctx, const uint8_t* const* bgr_dev, int n);
 int rtvm_batch_release(rtvm_ctx* ctx, long ticket);
+/* ---- detected batches for hosts that keep validate / smooth / chain (main.py:733-746) on their
+ * side: the asynchronous form of rtvm_frame_register / rtvm_frame_commit.  The Python VideMosaic
+ * runs its headless mode on these: process_frame (main.py:710-759) only enqueues the frame; the
+ * numpy statements of the reference decide per frame from the batch's results; the warps and
+ * blends follow in pieces.  No counterpart in the reference beyond process_frame itself. ---- */
+
+/* Per-frame outcome of detection, matching and RANSAC (main.py:716-731) of the batch `ticket`
+ * queued with rtvm_batch_detect and not yet released: match count, found (0 = fewer than 4
+ * matches or no model: the reference skips the frame), keypoint count, H_rel (cap x 9 doubles,
+ * frame -> previous frame).  Arrays of cap entries, any may be NULL.  Waits for that batch's
+ * RANSAC only.  rtvm_batch_results_ready: 1 when that wait would not block, else 0. */
+int rtvm_batch_results(rtvm_ctx* ctx, long ticket, int* n_matches, int* found, int* n_keypoints,
+                       double* H_rel, int cap);
+int rtvm_batch_results_ready(rtvm_ctx* ctx, long ticket);
+/* main.py:748, 756-759 for frames first .. first+count-1 of the detected batch `ticket` with the
+ * absolute homographies the host computed (H_abs: count x 9 doubles, copied before the call
+ * returns): warp + blend in frame order, then kp_prev/des_prev = features of the last of them.
+ * Only frames the host decided to stitch are committed (a skipped frame is never passed).  The
+ * piece is a batch of its own (rtvm_batch_ticket, rtvm_batch_status_of): frames behind a blend
+ * that cleared a canvas pixel come back RTVM_FRAME_PENDING with reason RTVM_PENDING_MASK and are
+ * committed again with the same homographies; pieces queued behind such a piece come back
+ * RTVM_PENDING_VOID.  Asynchronous. */
+int rtvm_batch_commit(rtvm_ctx* ctx, long ticket, int first, int count, const double* H_abs);
+/* 1 when the status of the piece / batch `ticket` (one of the last 16) can be read without
+ * waiting, else 0. */
+int rtvm_batch_done(rtvm_ctx* ctx, long ticket);
+/* After the host skipped a frame (main.py:722-731): what is detected next is matched against the
+ * last committed frame (kp_prev/des_prev), not against the frame detected last. */
+int rtvm_batch_rebase(rtvm_ctx* ctx);
+/* kp_cur/des_cur and self.matches (main.py:718-720) of frame `index` of the held batch `ticket`;
+ * outputs as rtvm_get_features / rtvm_get_matches. */
+int rtvm_batch_get_features(rtvm_ctx* ctx, long ticket, int index, int* n_out, float* xy, float* size,
+                            float* angle_deg, float* response, int32_t* octave, uint8_t* desc);
+int rtvm_batch_get_matches(rtvm_ctx* ctx, long ticket, int index, int* m_out, int32_t* qidx, int32_t* tidx,
+                           int32_t* dist);
+
 /* Status bits, match count and the absolute homography of the most recent
  * rtvm_process_frame (any may be NULL).  Syncs the stream. */
 int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_matches, double H_abs[9]);

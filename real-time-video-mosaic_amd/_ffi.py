@@ -75,6 +75,13 @@ SIGNATURES = {
     "rtvm_batch_retry": (C.c_int, [_vp, C.c_long, C.c_int, C.c_int]),
     "rtvm_batch_detect": (C.c_int, [_vp, _vp, C.c_int]),
     "rtvm_batch_release": (C.c_int, [_vp, C.c_long]),
+    "rtvm_batch_results": (C.c_int, [_vp, C.c_long, _vp, _vp, _vp, _vp, C.c_int]),
+    "rtvm_batch_results_ready": (C.c_int, [_vp, C.c_long]),
+    "rtvm_batch_commit": (C.c_int, [_vp, C.c_long, C.c_int, C.c_int, _vp]),
+    "rtvm_batch_done": (C.c_int, [_vp, C.c_long]),
+    "rtvm_batch_rebase": (C.c_int, [_vp]),
+    "rtvm_batch_get_features": (C.c_int, [_vp, C.c_long, C.c_int, _intp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rtvm_batch_get_matches": (C.c_int, [_vp, C.c_long, C.c_int, _intp, _vp, _vp, _vp]),
     "rtvm_first_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_frame_register": (C.c_int, [_vp, _vp, _intp, _intp, _vp]),
     "rtvm_frame_commit": (C.c_int, [_vp, _vp]),
@@ -579,6 +586,62 @@ class Context:
 
     def batch_release(self, ticket):
         self._check(lib().rtvm_batch_release(self._h, ticket))
+
+    # ---- detected batches with the glue on the host ---------------------------------
+    def _flag(self, rc):
+        if rc < 0:
+            self._check(rc)
+        return bool(rc)
+
+    def batch_results_ready(self, ticket):
+        return self._flag(lib().rtvm_batch_results_ready(self._h, ticket))
+
+    def batch_results(self, ticket, n):
+        """(matches[n], found[n], keypoints[n], H_rel[n, 3, 3]) of the detected batch `ticket`."""
+        nm = np.zeros(n, np.int32)
+        fd = np.zeros(n, np.int32)
+        nk = np.zeros(n, np.int32)
+        H = np.zeros((n, 3, 3), np.float64)
+        self._check(lib().rtvm_batch_results(self._h, ticket, ptr(nm), ptr(fd), ptr(nk), ptr(H), n))
+        return nm, fd, nk, H
+
+    def batch_commit(self, ticket, first, H_abs):
+        """Queues warp + blend of frames first .. first+len(H_abs)-1 of the detected batch `ticket` with the
+        host's absolute homographies; returns the ticket of the piece."""
+        H = np.ascontiguousarray(H_abs, dtype=np.float64).reshape(-1, 9)
+        self._check(lib().rtvm_batch_commit(self._h, ticket, int(first), len(H), ptr(H)))
+        return self.batch_ticket()
+
+    def batch_done(self, ticket):
+        return self._flag(lib().rtvm_batch_done(self._h, ticket))
+
+    def batch_rebase(self):
+        self._check(lib().rtvm_batch_rebase(self._h))
+
+    def batch_get_features(self, ticket, index):
+        cap = max(self.max_keypoints(), 1)
+        n = C.c_int(0)
+        xy = np.empty((cap, 2), np.float32)
+        size = np.empty(cap, np.float32)
+        angle = np.empty(cap, np.float32)
+        resp = np.empty(cap, np.float32)
+        octave = np.empty(cap, np.int32)
+        desc = np.empty((cap, 32), np.uint8)
+        self._check(lib().rtvm_batch_get_features(self._h, ticket, int(index), C.byref(n), ptr(xy), ptr(size), ptr(angle),
+                                                  ptr(resp), ptr(octave), ptr(desc)))
+        k = n.value
+        return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=angle[:k].copy(),
+                    response=resp[:k].copy(), octave=octave[:k].copy(), desc=desc[:k].copy())
+
+    def batch_get_matches(self, ticket, index):
+        cap = max(self.max_keypoints(), 1)
+        m = C.c_int(0)
+        qi = np.empty(cap, np.int32)
+        ti = np.empty(cap, np.int32)
+        di = np.empty(cap, np.int32)
+        self._check(lib().rtvm_batch_get_matches(self._h, ticket, int(index), C.byref(m), ptr(qi), ptr(ti), ptr(di)))
+        k = m.value
+        return qi[:k].copy(), ti[:k].copy(), di[:k].copy()
 
     def _stitch_rest(self, ticket, start, k, first, status, stats, trace=None):
         """Frames first .. k-1 of the detected batch `ticket` (video frames start+first ..) came back

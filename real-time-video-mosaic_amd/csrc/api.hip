@@ -209,10 +209,19 @@ namespace {
 int alloc_all(rtvm_ctx* c) {
     const int mk = RTVM_MAX_MATCH;
     int r;
-    HIP_TRY(c, hipHostMalloc(&c->h_pinned, 1 << 16, hipHostMallocDefault));
-    memset(c->h_pinned, 0, 1 << 16);
+    // one pinned block: scratch for read-backs (16 KiB), batch reports, batch results, commit homographies
+    const size_t rep_bytes = (sizeof(BatchReport) * RTVM_REPORTS + 255) & ~(size_t)255;
+    const size_t res_bytes = (sizeof(BatchResults) * RTVM_NSETS + 255) & ~(size_t)255;
+    const size_t ch_bytes = sizeof(double) * RTVM_REPORTS * RTVM_MAX_BATCH * 9;
+    const size_t pinned_bytes = 16384 + rep_bytes + res_bytes + ch_bytes;
+    HIP_TRY(c, hipHostMalloc(&c->h_pinned, pinned_bytes, hipHostMallocDefault));
+    memset(c->h_pinned, 0, pinned_bytes);
     c->h_rep = (BatchReport*)((char*)c->h_pinned + 16384);
+    c->h_res = (BatchResults*)((char*)c->h_rep + rep_bytes);
+    c->h_commit_H = (double*)((char*)c->h_res + res_bytes);
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_rep, c->h_rep, 0));
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_res, c->h_res, 0));
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_commit_H, c->h_commit_H, 0));
     for (int k = 0; k < RTVM_NSETS; k++) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_feat[k], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_search[k], hipEventDisableTiming));

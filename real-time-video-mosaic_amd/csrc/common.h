@@ -212,6 +212,16 @@ struct BatchRecord {
 };
 #define RTVM_REPORTS 16
 
+// Detection, matching and RANSAC results of a detected batch, for hosts that keep the validate /
+// smooth / chain arithmetic on their side (rtvm_batch_results); written by the device into
+// pinned host memory, one per slot set.
+struct BatchResults {
+    int matches[RTVM_MAX_BATCH];
+    int found[RTVM_MAX_BATCH];
+    int kp[RTVM_MAX_BATCH];
+    double H[RTVM_MAX_BATCH][9];
+};
+
 // frame pointers of a batch, passed to the binding kernel by value
 struct BatchPtrs {
     const uint8_t* p[RTVM_MAX_BATCH];
@@ -255,6 +265,10 @@ struct rtvm_ctx {
     long set_owner[RTVM_NSETS]; // ticket of the batch whose detection results the slot set holds
     int set_live[RTVM_NSETS];   // the set holds a batch queued with rtvm_batch_detect and not yet released
     BatchReport* d_rep;        // device view of h_rep
+    BatchResults* h_res;       // [RTVM_NSETS] pinned: what rtvm_batch_results hands out
+    BatchResults* d_res;       // device view of h_res
+    double* h_commit_H;        // [RTVM_REPORTS][RTVM_MAX_BATCH * 9] pinned: homographies of rtvm_batch_commit
+    double* d_commit_H;        // device view of h_commit_H
     int fh, fw, ch, cw;
     int detector, nfeatures, flags;
     char err[512];

@@ -223,13 +223,57 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
     }
 }
 
+// The glue of a canvas half whose absolute homographies come from the host (rtvm_batch_commit):
+// the host has applied the skip rules, validate, smooth and chain (main.py:722-746) itself and
+// hands over only frames that are to be stitched.  What is left of k_batch_glue is the
+// bookkeeping: behind a canvas half that left frames pending (st->abort) the whole piece is
+// void; otherwise every frame is stitched with the homography it came with.
+__global__ __launch_bounds__(64) void k_batch_host_glue(StreamState* __restrict__ st, const double* __restrict__ H_in,
+                                                        int n, double* __restrict__ H_out, int* __restrict__ skip) {
+    const int lane = threadIdx.x;
+    const int abort = st->abort;
+    if (lane < n) {
+        skip[lane] = abort ? 1 : 0;
+        st->b_status[lane] = abort ? RTVM_FRAME_PENDING : 0;
+        st->b_matches[lane] = 0;
+        st->b_kp[lane] = 0;
+        if (!abort)
+            for (int i = 0; i < 9; i++) H_out[9 * lane + i] = H_in[9 * lane + i];
+    }
+    if (lane == 0) {
+        st->n_done = abort ? 0 : n;
+        st->last_good = abort ? -1 : n - 1;
+        if (!abort) {
+            st->tail_ok = 1;
+            st->frame_index += n;
+            for (int i = 0; i < 9; i++) st->H_old[i] = st->H_abs[i] = H_in[9 * (n - 1) + i];
+        }
+    }
+}
+
+// Per-frame outcome of detection, matching and RANSAC of a batch, gathered into pinned host
+// memory for rtvm_batch_results.  Lane j = frame j.
+__global__ __launch_bounds__(64) void k_batch_collect(const FrameSlot* __restrict__ slots, int sb, int n,
+                                                      BatchResults* __restrict__ out) {
+    const int j = threadIdx.x;
+    if (j >= n) return;
+    const FrameSlot& F = slots[sb + j];
+    const int m = *F.m_count;
+    out->matches[j] = m;
+    out->found[j] = m >= 4 ? *F.rs_found : 0;
+    out->kp[j] = *F.feat.count;
+    for (int i = 0; i < 9; i++) out->H[j][i] = F.rs_H[i];
+}
+
 // End of a batch.  The canvas masks of frames 1..n-1 were predicted (a blend of two
 // non-zero pixels stays non-zero); when the blend of frame `bad` broke that, the later
 // frames were left untouched: the state goes back to what it was after frame `bad` and
 // they are reported pending, like the rest of a batch after a skipped frame.  Then the
 // report the host reads.
+// host_glue: the homographies came from the host, which keeps the stream state itself; there is
+// no device state to go back to.
 __global__ void k_batch_finish(StreamState* __restrict__ st, const StreamState* __restrict__ snap, int n,
-                               BatchReport* __restrict__ rep) {
+                               BatchReport* __restrict__ rep, int host_glue) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int bad = st->bad_frame;
     int reason = RTVM_PENDING_NONE;
@@ -237,7 +281,7 @@ __global__ void k_batch_finish(StreamState* __restrict__ st, const StreamState* 
     if (bad >= 0 && bad < n - 1)
         for (int j = bad + 1; j < n; j++) later |= st->b_status[j] != RTVM_FRAME_PENDING;
     if (later) {
-        *st = snap[bad];
+        if (!host_glue) *st = snap[bad];
         for (int j = bad + 1; j < n; j++) {
             st->b_status[j] = RTVM_FRAME_PENDING;
             st->b_matches[j] = 0;
@@ -383,7 +427,10 @@ int queue_first_frame(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_of
 }
 
 // glue + warp/blend of every frame + kp_prev/des_prev update, on the main stream
-int queue_back_half(rtvm_ctx* c, int set, int sb, const uint8_t* const* ptrs, int n, int ahead) {
+// host_H: device-visible address of n absolute homographies supplied by the host, or null for the
+// device-side glue.
+int queue_back_half(rtvm_ctx* c, int set, int sb, const uint8_t* const* ptrs, int n, int ahead,
+                    const double* host_H = nullptr) {
     int r;
     c->seq += 1;
     const int slot = (int)(c->seq % RTVM_REPORTS);
@@ -396,13 +443,16 @@ int queue_back_half(rtvm_ctx* c, int set, int sb, const uint8_t* const* ptrs, in
         rec.ahead = ahead;
         for (int j = 0; j < n; j++) rec.ptrs[j] = ptrs[j];
     }
-    RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
-                50.0, 0.3, ahead, c->d_snap);
+    if (host_H)
+        RTVM_LAUNCH(c, k_batch_host_glue, dim3(1), dim3(64), 0, c->d_state, host_H, n, c->d_H, c->d_skip);
+    else
+        RTVM_LAUNCH(c, k_batch_glue, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_state, c->d_wtab, c->d_H, c->d_skip,
+                    50.0, 0.3, ahead, c->d_snap);
     if ((r = rtvm_launch_warp_prep(c, c->d_H, c->d_skip, n))) return r;
     if ((r = rtvm_launch_sides(c, ptrs, n))) return r;
     if ((r = rtvm_launch_weights(c, n))) return r;
     if ((r = rtvm_launch_commit(c, n))) return r;
-    RTVM_LAUNCH(c, k_batch_finish, dim3(1), dim3(64), 0, c->d_state, c->d_snap, n, c->d_rep + slot);
+    RTVM_LAUNCH(c, k_batch_finish, dim3(1), dim3(64), 0, c->d_state, c->d_snap, n, c->d_rep + slot, host_H ? 1 : 0);
     RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, sb, c->d_state, -1,
                 c->feat_prev, c->orb.max_kp);
     HIP_TRY(c, hipGetLastError());
@@ -470,6 +520,7 @@ int queue_detect(rtvm_ctx* c, const uint8_t* const* ptrs, int n, int* set_out, i
     {
         StreamScope fs(c, c->stream_lm);
         if ((r = rtvm_launch_ransac_refine(c, sb, n, 2.0))) return r;
+        RTVM_LAUNCH(c, k_batch_collect, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_res + set);
         HIP_TRY(c, hipEventRecord(c->ev_front[set], c->stream_lm));
     }
     c->spec_tail = sb + n - 1;
@@ -679,6 +730,85 @@ extern "C" int rtvm_batch_detect(rtvm_ctx* c, const uint8_t* const* bgr_dev, int
     return RTVM_OK;
 }
 
+// the slot set that holds the detection results of batch `ticket`, or -1
+static int held_set(const rtvm_ctx* c, long ticket) {
+    for (int k = 0; k < RTVM_NSETS; k++)
+        if (ticket >= 1 && c->set_owner[k] == ticket && c->recs[k].ticket == ticket) return k;
+    return -1;
+}
+
+extern "C" int rtvm_batch_results_ready(rtvm_ctx* c, long ticket) {
+    if (!c) return RTVM_E_ARG;
+    const int set = held_set(c, ticket);
+    if (set < 0) RTVM_FAIL(c, RTVM_E_STATE, "batch_results: the detection results of batch %ld are not held (any more)", ticket);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const hipError_t e = hipEventQuery(c->ev_front[set]);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    HIP_TRY(c, e);
+    return 0;
+}
+
+extern "C" int rtvm_batch_results(rtvm_ctx* c, long ticket, int* n_matches, int* found, int* n_keypoints,
+                                  double* H_rel, int cap) {
+    if (!c) return RTVM_E_ARG;
+    const int set = held_set(c, ticket);
+    if (set < 0) RTVM_FAIL(c, RTVM_E_STATE, "batch_results: the detection results of batch %ld are not held (any more)", ticket);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev_front[set]));
+    const BatchResults* res = c->h_res + set;
+    const int n = c->recs[set].n;
+    for (int j = 0; j < cap && j < n; j++) {
+        if (n_matches) n_matches[j] = res->matches[j];
+        if (found) found[j] = res->found[j];
+        if (n_keypoints) n_keypoints[j] = res->kp[j];
+        if (H_rel) memcpy(H_rel + 9 * j, res->H[j], 9 * sizeof(double));
+    }
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_batch_commit(rtvm_ctx* c, long ticket, int first, int count, const double* H_abs) {
+    if (!c) return RTVM_E_ARG;
+    if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "batch_commit: no stream");
+    if (!H_abs) RTVM_FAIL(c, RTVM_E_ARG, "batch_commit: null homographies");
+    const int set = held_set(c, ticket);
+    if (set < 0) RTVM_FAIL(c, RTVM_E_STATE, "batch_commit: the detection results of batch %ld are not held (any more)", ticket);
+    const BatchRecord rec = c->recs[set];
+    if (first < 0 || count < 1 || first + count > rec.n)
+        RTVM_FAIL(c, RTVM_E_ARG, "batch_commit: frames %d..%d of a batch of %d", first, first + count - 1, rec.n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the homographies wait in pinned memory of the report slot this piece will get (queue_back_half
+    // counts the ticket up); the device reads them from there
+    const int slot = (int)((c->seq + 1) % RTVM_REPORTS);
+    double* hH = c->h_commit_H + (size_t)slot * RTVM_MAX_BATCH * 9;
+    memcpy(hH, H_abs, (size_t)count * 9 * sizeof(double));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_main, c->ev_front[rec.set], 0));  // the frames and their features
+    int r = queue_back_half(c, rec.set, rec.sb + first, rec.ptrs + first, count, 0,
+                            c->d_commit_H + (size_t)slot * RTVM_MAX_BATCH * 9);
+    if (r) return r;
+    HIP_TRY(c, hipEventRecord(c->ev_back[rec.set], c->stream_main));
+    c->back_rec[rec.set] = 1;
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_batch_done(rtvm_ctx* c, long ticket) {
+    if (!c) return RTVM_E_ARG;
+    if (ticket < 1 || ticket > c->seq || c->seq - ticket >= RTVM_REPORTS)
+        RTVM_FAIL(c, RTVM_E_STATE, "batch_done: ticket %ld is not one of the last %d (%ld queued)", ticket, RTVM_REPORTS, c->seq);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const hipError_t e = hipEventQuery(c->ev_done[ticket % RTVM_REPORTS]);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    HIP_TRY(c, e);
+    return 0;
+}
+
+extern "C" int rtvm_batch_rebase(rtvm_ctx* c) {
+    if (!c) return RTVM_E_ARG;
+    c->spec_tail = -1;
+    return RTVM_OK;
+}
+
 extern "C" int rtvm_batch_release(rtvm_ctx* c, long ticket) {
     if (!c) return RTVM_E_ARG;
     for (int k = 0; k < RTVM_NSETS; k++)
@@ -797,6 +927,18 @@ extern "C" int rtvm_get_features(rtvm_ctx* c, int slot, int* n_out, float* xy, f
                      desc);
 }
 
+extern "C" int rtvm_batch_get_features(rtvm_ctx* c, long ticket, int index, int* n_out, float* xy, float* size,
+                                       float* angle_deg, float* response, int32_t* octave, uint8_t* desc) {
+    if (!c) return RTVM_E_ARG;
+    if (!n_out) RTVM_FAIL(c, RTVM_E_ARG, "batch_get_features: null argument");
+    const int set = held_set(c, ticket);
+    if (set < 0 || index < 0 || index >= c->recs[set].n)
+        RTVM_FAIL(c, RTVM_E_STATE, "batch_get_features: frame %d of batch %ld is not held", index, ticket);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev_front[set]));
+    return read_feat(c, c->h_slots[c->recs[set].sb + index].feat, n_out, xy, size, angle_deg, response, octave, desc);
+}
+
 // cv2.ORB detectAndCompute of a host frame (stage entry point): slot 0's features.
 int rtvm_orb_host(rtvm_ctx* c, const uint8_t* bgr, int* n_out, float* xy, float* size, float* angle_deg,
                   float* response, int32_t* octave, uint8_t* desc, uint8_t* gray) {
@@ -816,13 +958,30 @@ int rtvm_orb_host(rtvm_ctx* c, const uint8_t* bgr, int* n_out, float* xy, float*
     return read_feat(c, c->h_slots[0].feat, n_out, xy, size, angle_deg, response, octave, desc);
 }
 
+static int read_matches(rtvm_ctx* c, const FrameSlot& S, int* m_out, int32_t* qidx, int32_t* tidx, int32_t* dist);
+
 // Matches of the most recent frame against its predecessor, sorted by distance.
 extern "C" int rtvm_get_matches(rtvm_ctx* c, int* m_out, int32_t* qidx, int32_t* tidx, int32_t* dist) {
     if (!c) return RTVM_E_ARG;
     if (!m_out) RTVM_FAIL(c, RTVM_E_ARG, "get_matches: null argument");
     if (c->fh <= 0) RTVM_FAIL(c, RTVM_E_STATE, "get_matches: context has no frame size");
     HIP_TRY(c, hipSetDevice(c->device));
-    const FrameSlot& S = c->h_slots[0];
+    return read_matches(c, c->h_slots[0], m_out, qidx, tidx, dist);
+}
+
+extern "C" int rtvm_batch_get_matches(rtvm_ctx* c, long ticket, int index, int* m_out, int32_t* qidx, int32_t* tidx,
+                                      int32_t* dist) {
+    if (!c) return RTVM_E_ARG;
+    if (!m_out) RTVM_FAIL(c, RTVM_E_ARG, "batch_get_matches: null argument");
+    const int set = held_set(c, ticket);
+    if (set < 0 || index < 0 || index >= c->recs[set].n)
+        RTVM_FAIL(c, RTVM_E_STATE, "batch_get_matches: frame %d of batch %ld is not held", index, ticket);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev_front[set]));
+    return read_matches(c, c->h_slots[c->recs[set].sb + index], m_out, qidx, tidx, dist);
+}
+
+static int read_matches(rtvm_ctx* c, const FrameSlot& S, int* m_out, int32_t* qidx, int32_t* tidx, int32_t* dist) {
     int* hc = (int*)c->h_pinned;
     HIP_TRY(c, hipMemcpyAsync(hc, S.m_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

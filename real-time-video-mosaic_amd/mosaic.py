@@ -2,12 +2,25 @@
 
 Constructor and method signatures, attribute names, skip rules and printed
 warnings follow the reference; the arithmetic runs in librtvm.so on the GPU
-(there is no CPU fallback).  Per frame the class makes two library calls:
-``frame_register`` (upload, ORB, match, RANSAC) and ``frame_commit`` (warp, blend,
-state advance); the validate / smooth / chain arithmetic between them is the
-reference's numpy, kept on the host so that the public thresholds, the history
-list and H_old behave exactly like the reference's attributes.
+(there is no CPU fallback).  The validate / smooth / chain arithmetic of
+main.py:733-746 is the reference's numpy, kept on the host so that the public
+thresholds, the history list and H_old behave exactly like the reference's
+attributes.
+
+With a display flag set (``visualize`` or ``show_intermediate``, the reference's
+defaults: a window per frame) every ``process_frame`` call completes before it
+returns: ``frame_register`` (upload, ORB, match, RANSAC) and ``frame_commit``
+(warp, blend, state advance).  Headless (both flags off, what ``main.py --hide``
+passes at main.py:1603) and with the ORB detector, ``process_frame`` only takes
+the frame: frames are detected, matched and fitted in batches on the device
+while the caller fetches the next ones, the host applies the reference's rules
+to each batch's results in frame order, and the warps and blends follow in
+pieces.  Reading any result (``H``, ``H_old``, ``output_img``, ``matches``,
+``kp_*``, ``homography_history``, ...) first brings the object to the state the
+reference would have after the last ``process_frame`` call; warnings are printed
+in frame order, at the latest then.
 """
+import collections
 import threading
 
 import numpy as np
@@ -29,10 +42,226 @@ def _stage_ctx(device=0):
     return ctxs[device]
 
 
+class _Batch:
+    """A detected batch of the headless pipeline."""
+    __slots__ = ("ticket", "idx0", "frames", "n", "res", "glued", "H", "queued", "done")
+
+    def __init__(self, ticket, idx0, frames):
+        self.ticket, self.idx0, self.frames, self.n = ticket, idx0, frames, len(frames)
+        self.res = None      # (matches, found, keypoints, H_rel) once read
+        self.glued = 0       # frames the host rules have been applied to
+        self.H = []          # absolute homographies of the frames to stitch: frames 0 .. len(H)-1
+        self.queued = 0      # of those, queued in commit pieces
+        self.done = 0        # of those, confirmed stitched
+
+
+class _OrbPipeline:
+    """process_frame without waiting (ORB, headless).  Frames go through a ring of pinned host slots
+    to the device; detection, matching and RANSAC run in batches of `batch` frames, up to three
+    batches ahead (rtvm_batch_detect); when a batch's results arrive the host applies main.py:722-746
+    to its frames in order (skip rules, validate, smooth, chain: the owner's own methods and
+    attributes); the frames to stitch are committed in pieces of up to `piece` frames
+    (rtvm_batch_commit), three in flight.
+
+    The homographies do not depend on the canvas, so a piece that comes back with frames pending
+    (a blend cleared a canvas pixel: the canvas masks predicted for the frames behind it are
+    wrong) is simply committed again from the first pending frame, one frame at first and twice as
+    many each time.  A frame the reference skips (main.py:722-731) invalidates the matching of
+    everything detected behind it: those frames are detected again, matched against the last
+    stitched frame."""
+
+    def __init__(self, vm, batch=32, piece=16):
+        self.vm, self.ctx = vm, vm._ctx
+        self.B, self.P = int(batch), max(1, min(int(piece), int(batch)))
+        self.ctx.reserve_batch(self.B)
+        self.R = 6 * self.B                      # four batches alive, one being filled, one spare
+        self.ctx.ingest_reserve(self.R)
+        self.views = [self.ctx.ingest_host_slot(i) for i in range(self.R)]
+        self.n_in = 0                            # frames taken so far
+        self.retired = 0                         # frames whose ring slot may be written again
+        self.pend = collections.deque()          # (index, frame) in the ring, not yet detected
+        self.batches = collections.deque()       # detected batches, oldest first
+        self.inflight = collections.deque()      # commit pieces, oldest first: (ticket, batch, first, count)
+        self.m = self.P                          # frames of the next piece
+        self.need_rebase = False
+        self.flushing = False
+        self.held = None                         # the batch of the last frame, kept for kp_cur / matches
+        self.last = None                         # (batch, index) of the last frame the rules were applied to
+        self.stats = {"frames": 0, "batches": 0, "pieces": 0, "pieces_with_pending_frames": 0,
+                      "pieces_void": 0, "frames_detected_again": 0}
+
+    # ------------------------------------------------------------------ the caller's side
+    def put(self, frame):
+        idx = self.n_in
+        while idx - self.retired >= self.R:      # the slot still holds a frame that may be needed again
+            self._pump(block=True)
+        view = self.views[idx % self.R]
+        if frame.shape != view.shape:
+            raise ValueError("process_frame: frame of shape %s, the mosaic was created for %s" % (frame.shape, view.shape))
+        np.copyto(view, frame)
+        self.pend.append((idx, frame))
+        self.n_in += 1
+        self.stats["frames"] += 1
+        self._pump(block=False)
+
+    def busy(self):
+        return bool(self.pend or self.batches)
+
+    def flush(self):
+        self.flushing = True
+        try:
+            while self.pend or self.batches:
+                self._pump(block=True)
+        finally:
+            self.flushing = False
+
+    def close(self):
+        self.pend.clear()
+        self.batches.clear()
+        self.inflight.clear()
+        self.held = None
+
+    # ------------------------------------------------------------------ the state machine
+    def _live_sets(self):
+        return len(self.batches) + (1 if self.held is not None else 0)
+
+    def _pump(self, block):
+        progressed = self._detect()
+        progressed |= self._results(block and not self.inflight)
+        progressed |= self._commit()
+        progressed |= self._confirm(block)
+        progressed |= self._retire()
+        if block and not progressed:
+            # nothing was there to wait for: detection must be possible now
+            if not self._detect(force=True) and (self.pend or self.batches):
+                raise RuntimeError("VideMosaic pipeline stalled (%d frames waiting, %d batches)"
+                                   % (len(self.pend), len(self.batches)))
+
+    def _detect(self, force=False):
+        progressed = False
+        while self.pend and (len(self.pend) >= self.B or self.flushing or force):
+            if self.need_rebase:
+                # what is detected next is matched against the last stitched frame: its commit
+                # (which makes its features the previous ones) has to be confirmed first
+                if self.inflight or any(b.done < len(b.H) or b.glued < b.n for b in self.batches):
+                    break
+                self.ctx.batch_rebase()
+                self.need_rebase = False
+            if self.held is not None:            # the lazy reads of the last flush are over
+                self.ctx.batch_release(self.held.ticket)
+                self.held = None
+            if self._live_sets() >= 4:
+                break
+            k = min(self.B, len(self.pend))
+            items = [self.pend.popleft() for _ in range(k)]
+            idx0 = items[0][0]
+            s0 = idx0 % self.R
+            if s0 + k <= self.R:
+                ptrs = self.ctx.ingest_submit_range(s0, k)
+            else:
+                ptrs = [self.ctx.ingest_submit((idx0 + j) % self.R) for j in range(k)]
+            ticket = self.ctx.batch_detect(ptrs)
+            self.batches.append(_Batch(ticket, idx0, [f for _, f in items]))
+            self.stats["batches"] += 1
+            progressed = True
+            force = False
+        return progressed
+
+    def _results(self, block):
+        b = next((x for x in self.batches if x.res is None), None)
+        if b is None or not (block or self.ctx.batch_results_ready(b.ticket)):
+            return False
+        b.res = self.ctx.batch_results(b.ticket, b.n)
+        nm, fd, _, Hrel = b.res
+        vm = self.vm
+        for j in range(b.n):
+            H = vm._glue(b.frames[j], int(nm[j]), bool(fd[j]), Hrel[j])
+            b.glued = j + 1
+            self.last = (b, j)
+            if H is not None:
+                b.H.append(H)
+                continue
+            # the frame is skipped and the state did not advance: everything detected behind it was
+            # matched against the wrong frame
+            redo = [(b.idx0 + i, b.frames[i]) for i in range(j + 1, b.n)]
+            b.frames, b.n = b.frames[:j + 1], j + 1
+            while self.batches[-1] is not b:
+                later = self.batches.pop()
+                self.ctx.batch_release(later.ticket)
+                redo_later = [(later.idx0 + i, f) for i, f in enumerate(later.frames)]
+                self.pend.extendleft(reversed(redo_later))
+            self.pend.extendleft(reversed(redo))
+            self.stats["frames_detected_again"] += len(self.pend)
+            self.need_rebase = True
+            break
+        return True
+
+    def _commit(self):
+        progressed = False
+        while len(self.inflight) < 3:
+            b = next((x for x in self.batches if x.queued < len(x.H)), None)
+            if b is None:
+                break
+            if any(x.res is None or x.queued < len(x.H) for x in self._before(b)):
+                break                            # frame order across batches
+            cnt = min(self.m, len(b.H) - b.queued)
+            t = self.ctx.batch_commit(b.ticket, b.queued, b.H[b.queued:b.queued + cnt])
+            self.inflight.append((t, b, b.queued, cnt))
+            b.queued += cnt
+            self.m = min(2 * self.m, self.P)
+            self.stats["pieces"] += 1
+            progressed = True
+        return progressed
+
+    def _before(self, b):
+        for x in self.batches:
+            if x is b:
+                return
+            yield x
+
+    def _confirm(self, block):
+        if not self.inflight:
+            return False
+        t, b, first, cnt = self.inflight[0]
+        if not (block or self.ctx.batch_done(t)):
+            return False
+        self.inflight.popleft()
+        done = self.ctx.batch_status_of(t, cnt)[0]
+        b.done = first + done
+        if done < cnt:
+            # a blend cleared a canvas pixel: the frames behind it are committed again (their
+            # homographies stand); the pieces queued behind did nothing
+            self.stats["pieces_with_pending_frames"] += 1
+            for t2, _, _, c2 in self.inflight:
+                self.ctx.batch_status_of(t2, c2)
+                self.stats["pieces_void"] += 1
+            self.inflight.clear()
+            for x in self.batches:
+                x.queued = x.done
+            self.m = 1
+        return True
+
+    def _retire(self):
+        progressed = False
+        while self.batches:
+            b = self.batches[0]
+            if b.res is None or b.glued < b.n or b.done < len(b.H):
+                break
+            self.batches.popleft()
+            self.retired = b.idx0 + b.n
+            b.frames = None
+            if not self.batches and not self.pend:
+                self.held = b                    # the batch of the newest frame: kp_cur / matches read from it
+            else:
+                self.ctx.batch_release(b.ticket)
+            progressed = True
+        return progressed
+
+
 class VideMosaic:
     def __init__(self, first_image, output_height_times=2, output_width_times=1.2, detector_type="sift",
                  show_intermediate=True, output_dir=None, visualize=True, *, nfeatures=700, canvas_size=None,
-                 device=0, warp_mode="float"):
+                 device=0, warp_mode="float", pipeline_batch=32):
         # main.py:29-39
         self.detector_type = detector_type
         self.show_intermediate = show_intermediate
@@ -58,15 +287,21 @@ class VideMosaic:
         self._nfeatures = nfeatures
         self._cache = {}
         self._canvas_cache = None
+        # headless + ORB: process_frame only enqueues (see the module docstring); pipeline_batch = 0 turns it off
+        self._deferred = (detector_type == "orb" and not visualize and not show_intermediate and pipeline_batch > 0)
+        self._pipeline_batch = int(pipeline_batch)
+        self._pipe = None
+        self._pumping = False
 
         # main.py:86-87 (w_offset is the ROW offset, h_offset the COLUMN offset)
         self.w_offset = int(self._ch / 1 - fh / 1)
         self.h_offset = int(self._cw / 2 - fw / 2)
         self.process_first_frame(first_image)
 
-        self.H_old = np.eye(3)          # main.py:92-94
-        self.H_old[0, 2] = self.h_offset
-        self.H_old[1, 2] = self.w_offset
+        H0 = np.eye(3)                  # main.py:92-94
+        H0[0, 2] = self.h_offset
+        H0[1, 2] = self.w_offset
+        self.H_old = H0
         self.H = None
         # main.py:97-102
         self.stabilization_enabled = True
@@ -79,6 +314,7 @@ class VideMosaic:
     # ------------------------------------------------------------------ frames
     def process_first_frame(self, first_image):
         """main.py:104-112 plus the canvas set-up of main.py:80-90."""
+        self._sync()
         self.frame_prev = first_image
         self.frame_cur = first_image
         if self.detector_type == "sift":
@@ -94,6 +330,19 @@ class VideMosaic:
 
     def process_frame(self, frame_cur, frame_count):
         """main.py:710-759."""
+        if self._deferred:
+            if self._pipe is None:
+                self._pipe = _OrbPipeline(self, self._pipeline_batch, max(1, self._pipeline_batch // 2))
+            frame_cur = np.ascontiguousarray(frame_cur, dtype=np.uint8)
+            self._frame_cur = frame_cur
+            self._cache.clear()
+            self._canvas_cache = None
+            self._pumping = True
+            try:
+                self._pipe.put(frame_cur)
+            finally:
+                self._pumping = False
+            return
         self.frame_cur = frame_cur
         if self.detector_type == "sift":
             # main.py:716-731 with the SIFT branch of match(): detect, knn-2 + ratio, RANSAC
@@ -124,33 +373,85 @@ class VideMosaic:
         self._cache.clear()
         self._finish_frame(frame_cur, len(self._sift_matches[0]), H_relative is not None, H_relative)
 
-    def _finish_frame(self, frame_cur, n_matches, found, H_relative, staged=False):
-        """main.py:722-759 after matching and RANSAC: skip rules, validate, smooth, chain, warp.
-        staged: an ORB frame that was registered through the stage entry points, not frame_register."""
+    def _glue(self, frame_cur, n_matches, found, H_relative):
+        """main.py:722-746 and 756, 759 after matching and RANSAC: skip rules, validate, smooth, chain.
+        Returns the absolute homography the frame is to be warped with, or None when the reference
+        skips the frame (state not advanced)."""
+        self._frame_cur = frame_cur
         if n_matches < 4:
             print(f"Предупреждение: Недостаточно совпадений ({n_matches}), пропуск кадра")
-            return
+            return None
         if not found:
             print("Предупреждение: Не удалось вычислить гомографию, пропуск кадра")
-            return
+            return None
         if not self.validate_homography(H_relative):
             print("Предупреждение: Невалидная гомография (тряска/размытие), использую последнюю валидную")
             H_relative = np.eye(3)
         else:
-            self.last_valid_H = H_relative.copy()
+            self._last_valid_H = H_relative.copy()
         H_relative_smoothed = self.smooth_homography(H_relative)
-        self.H = np.matmul(self.H_old, H_relative_smoothed)
+        self._H = np.matmul(self._H_old, H_relative_smoothed)
+        self._H_old = self._H
+        self._frame_prev = frame_cur
+        return self._H
+
+    def _finish_frame(self, frame_cur, n_matches, found, H_relative, staged=False):
+        """main.py:722-759 after matching and RANSAC, frame by frame: the rules above, then warp + blend.
+        staged: an ORB frame that was registered through the stage entry points, not frame_register."""
+        H = self._glue(frame_cur, n_matches, found, H_relative)
+        if H is None:
+            return
         if self.detector_type == "sift":
-            self._ctx.warp_blend(frame_cur, self.H)   # main.py:748
+            self._ctx.warp_blend(frame_cur, H)        # main.py:748
             self._sift_prev = self._sift_cur          # main.py:757-758
         elif staged:
-            self._ctx.warp_blend(frame_cur, self.H)
+            self._ctx.warp_blend(frame_cur, H)
         else:
-            self._ctx.frame_commit(self.H)
+            self._ctx.frame_commit(H)
         self._canvas_cache = None
-        self.H_old = self.H
-        self.frame_prev = self.frame_cur
         self._cache["advanced"] = True
+
+    # ------------------------------------------------------------------ deferred work
+    def _sync(self):
+        """Brings the object to the state the reference has after the last process_frame call."""
+        p = self._pipe
+        if p is None or self._pumping or not p.busy():
+            return
+        self._pumping = True
+        try:
+            p.flush()
+        finally:
+            self._pumping = False
+        self._cache.clear()
+        self._canvas_cache = None
+
+    def flush(self):
+        """Waits until every frame handed to process_frame has been dealt with (headless mode; a no-op
+        otherwise).  Reading a result does the same."""
+        self._sync()
+
+    def _synced(name):   # noqa: N805 - attribute whose value depends on the frames still in flight
+        def get(self):
+            self._sync()
+            return getattr(self, name)
+
+        def put(self, value):
+            self._sync()
+            setattr(self, name, value)
+        return property(get, put)
+
+    H = _synced("_H")
+    H_old = _synced("_H_old")
+    last_valid_H = _synced("_last_valid_H")
+    homography_history = _synced("_homography_history")
+    frame_prev = _synced("_frame_prev")
+    frame_cur = _synced("_frame_cur")
+    # the knobs of main.py:97-101: setting one applies to the frames handed in afterwards, as in the reference
+    stabilization_enabled = _synced("_stabilization_enabled")
+    history_size = _synced("_history_size")
+    translation_threshold = _synced("_translation_threshold")
+    scale_threshold = _synced("_scale_threshold")
+    del _synced
 
     def process_frames(self, frames, first_frame_count=1, workers=4):
         """process_frame(frames[0], first_frame_count), process_frame(frames[1], ...), ... with the
@@ -165,6 +466,10 @@ class VideMosaic:
         been set to those of the last stitched frame, so that the object is left exactly as by
         per-frame calls.  (Frames already on the GPU: Context.process_video is the faster path.)"""
         frames = list(frames)
+        if self._deferred:   # process_frame itself does not wait
+            for i, frame in enumerate(frames):
+                self.process_frame(frame, first_frame_count + i)
+            return
         sift = self.detector_type == "sift"
         n = len(frames) if sift else len(frames) - 1   # ORB: the last frame takes the ordinary path
         if workers < 2 or n < 2:
@@ -219,9 +524,9 @@ class VideMosaic:
             # frame_register / frame_commit, the previous features kept here instead of on the device
             (qi, ti, di), H_relative = registered
             self._cache.clear()
-            before = self.H_old
+            before = self._H_old
             self._finish_frame(frame, len(qi), H_relative is not None, H_relative, staged=True)
-            if self.H_old is not before:   # the frame was stitched: it is the previous frame now
+            if self._H_old is not before:   # the frame was stitched: it is the previous frame now
                 state["prev"], state["prev_frame"] = cur, frame
 
         ahead = 4 * workers
@@ -264,17 +569,22 @@ class VideMosaic:
         return matches, H_relative
 
     # ------------------------------------------------------------------ lazily fetched state
+    def _held_frame(self):
+        """(ticket, index) of the newest frame when it went through the headless pipeline, else None."""
+        p = self._pipe
+        if p is None or p.held is None or p.last is None or p.last[0] is not p.held:
+            return None
+        return p.held.ticket, p.last[1]
+
     def _features(self, slot):
         if self.detector_type == "sift":
             return self._sift_cur if slot == 0 else self._sift_prev
+        self._sync()
         key = "feat%d" % slot
         if key not in self._cache:
-            self._cache[key] = self._ctx.get_features(slot)
+            held = self._held_frame() if slot == 0 else None
+            self._cache[key] = self._ctx.batch_get_features(*held) if held else self._ctx.get_features(slot)
         return self._cache[key]
-
-    def _cur_slot(self):
-        # after a committed frame the current features have become the previous ones
-        return 0
 
     @property
     def kp_cur(self):
@@ -298,18 +608,23 @@ class VideMosaic:
             if "matches" not in self._cache:
                 self._cache["matches"] = matches_from_arrays(*self._sift_matches)
             return self._cache["matches"]
+        self._sync()
         if "matches" not in self._cache:
-            self._cache["matches"] = matches_from_arrays(*self._ctx.get_matches())
+            held = self._held_frame()
+            arrays = self._ctx.batch_get_matches(*held) if held else self._ctx.get_matches()
+            self._cache["matches"] = matches_from_arrays(*arrays)
         return self._cache["matches"]
 
     @property
     def output_img(self):
         """The mosaic as the reference keeps it: (Hc, Wc, 3) float64 holding integers 0..255."""
+        self._sync()
         if self._canvas_cache is None:
             self._canvas_cache = self._ctx.canvas_read().astype(np.float64)
         return self._canvas_cache
 
     def output_img_u8(self):
+        self._sync()
         return self._ctx.canvas_read()
 
     def preview(self, width=400, height=300):
@@ -317,6 +632,7 @@ class VideMosaic:
         INTER_LINEAR), u8 BGR: what a progress display needs per frame (the reference's
         update_callback gets a copy of the full float64 canvas, main.py:1630-1632, which its GUI
         shrinks to 400 x 300, gui.py:143-155).  Only the small image crosses PCIe."""
+        self._sync()
         ch, cw = self._ctx.canvas_h, self._ctx.canvas_w
         return self._ctx.canvas_read_scaled(0, 0, cw, ch, int(width), int(height))
 
@@ -376,21 +692,23 @@ class VideMosaic:
         """main.py:803-834: recency-weighted mean of the last history_size relative homographies."""
         if not self.stabilization_enabled:
             return H
-        self.homography_history.append(H.copy())
-        if len(self.homography_history) > self.history_size:
-            self.homography_history.pop(0)
-        n = len(self.homography_history)
+        history = self.homography_history
+        history.append(H.copy())
+        if len(history) > self.history_size:
+            history.pop(0)
+        n = len(history)
         if n < 2:
             return H
         w = np.linspace(0.5, 1.0, n)
         w = w / np.sum(w)
         acc = np.zeros_like(H)
-        for wi, hi in zip(w, self.homography_history):
+        for wi, hi in zip(w, history):
             acc += wi * hi
         return acc
 
     def warp(self, frame_cur, H):
         """main.py:861-936: stitch frame_cur into the mosaic with homography H."""
+        self._sync()
         self._ctx.warp_blend(frame_cur, H)
         self._canvas_cache = None
         return self.output_img
@@ -424,6 +742,9 @@ class VideMosaic:
         return []
 
     def close(self):
+        if self._pipe is not None:
+            self._pipe.close()
+            self._pipe = None
         for c in getattr(self, "_worker_ctxs", None) or []:
             c.close()
         self._worker_ctxs = None

@@ -1,0 +1,138 @@
+"""VideMosaic in headless mode (visualize=False, show_intermediate=False, ORB): process_frame only takes
+the frame, the work follows in batches, and reading any result brings the object to the state the
+reference has after the last call.  Checked against the oracle and against the frame-synchronous class."""
+import numpy as np
+import pytest
+
+import reject_cases as rc
+import rtvm
+from rtvm import synth
+from oracle_mosaic import OracleMosaic
+
+FH, FW = 240, 320
+HEADLESS = dict(detector_type="orb", visualize=False, show_intermediate=False)
+
+
+def state_of(vm):
+    return dict(H=vm.H, H_old=vm.H_old, last_valid_H=vm.last_valid_H, history=list(vm.homography_history),
+                des_prev=vm.des_prev, des_cur=vm.des_cur, kp_cur=[(k.pt, k.angle, k.octave) for k in vm.kp_cur],
+                kp_prev=[(k.pt, k.response) for k in vm.kp_prev],
+                matches=[(m.queryIdx, m.trainIdx, m.distance) for m in vm.matches], canvas=vm.output_img_u8())
+
+
+def assert_same_state(a, b):
+    assert sorted(a) == sorted(b)
+    for k in a:
+        if k == "history":
+            assert len(a[k]) == len(b[k]) and all(np.array_equal(x, y) for x, y in zip(a[k], b[k]))
+        elif isinstance(a[k], list):
+            assert a[k] == b[k], k
+        elif a[k] is None:
+            assert b[k] is None
+        else:
+            assert np.array_equal(a[k], b[k]), k
+
+
+def tricky_video():
+    """Rejected homographies (every rule), frames without features in the middle of a batch, at its end and two
+    in a row, and patches of value 1 whose blends clear canvas pixels (mispredicted masks)."""
+    frames, _ = rc.sequence()
+    frames = [f.copy() for f in frames]
+    for f in frames:
+        f[90:150, 200:280] = 1
+    flat = np.full_like(frames[0], 90)
+    black = np.zeros_like(frames[0])
+    for pos, f in ((4, flat), (8, black), (13, flat), (14, black), (20, flat)):
+        frames.insert(pos, f)
+    return frames
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 4, 8, 32])
+def test_headless_pipeline_equals_frame_by_frame_and_oracle(batch, capsys):
+    frames = tricky_video()
+    sync = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=False, show_intermediate=True, nfeatures=500)
+    assert not sync._deferred
+    om = OracleMosaic(frames[0], nfeatures=500, glue="numpy")
+    for t, f in enumerate(frames[1:], 1):
+        sync.process_frame(f, t)
+        om.process_frame(f)
+    out_sync = capsys.readouterr().out
+    assert out_sync.count("пропуск кадра") == 5 and out_sync.count("Невалидная гомография") >= 5
+    assert np.array_equal(sync.H, om.H) and np.array_equal(sync.output_img_u8(), om.canvas)
+    want = state_of(sync)
+
+    vm = rtvm.VideMosaic(frames[0], nfeatures=500, pipeline_batch=batch, **HEADLESS)
+    assert vm._deferred
+    for t, f in enumerate(frames[1:], 1):
+        assert vm.process_frame(f, t) is None
+    assert vm.frame_cur is frames[-1]
+    got = state_of(vm)
+    out = capsys.readouterr().out
+    assert out == out_sync                      # the same warnings in the same order
+    assert_same_state(got, want)
+    stats = vm._pipe.stats
+    assert stats["frames"] == len(frames) - 1 and stats["frames_detected_again"] > 0
+    if batch >= 4:
+        assert stats["pieces_with_pending_frames"] > 0
+    # the object goes on from there, and reads in the middle of a video change nothing
+    more = [synth.render_frame(rc.world(), rc.view(dx=5 + 2 * i, dy=-4 - i), FH, FW) for i in range(1, 6)]
+    for i, f in enumerate(more):
+        sync.process_frame(f, 100 + i)
+        vm.process_frame(f, 100 + i)
+        if i == 2:
+            assert np.array_equal(vm.H, sync.H) and len(vm.matches) == len(sync.matches)
+    assert_same_state(state_of(vm), state_of(sync))
+    sync.close()
+    vm.close()
+
+
+@pytest.mark.gpu
+def test_headless_attributes_are_live(capsys):
+    """The public knobs of the reference (thresholds, history size, stabilisation switch, H_old) are read when a
+    frame's rules are applied; setting one first settles the frames handed in before."""
+    frames, _ = synth.make_video(FH, FW, 12, world_size=(520, 620), seed=3)
+    a = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=True, nfeatures=400)
+    b = rtvm.VideMosaic(frames[0], nfeatures=400, pipeline_batch=4, **HEADLESS)
+    for vm in (a, b):
+        for t in range(1, 5):
+            vm.process_frame(frames[t], t)
+        vm.translation_threshold = 1.0          # every later frame is "shaky"
+        vm.history_size = 3
+        for t in range(5, 9):
+            vm.process_frame(frames[t], t)
+        vm.stabilization_enabled = False
+        vm.translation_threshold = 50
+        shifted = vm.H_old.copy()
+        shifted[0, 2] += 7.0
+        vm.H_old = shifted
+        for t in range(9, 12):
+            vm.process_frame(frames[t], t)
+    out = capsys.readouterr().out
+    assert out.count("большое смещение") == 8          # frames 5..8, for both objects
+    assert len(a.homography_history) == len(b.homography_history) == 4   # one pop per append (main.py:819-820)
+    assert_same_state(state_of(b), state_of(a))
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+def test_headless_at_720p_matches_oracle_through_a_mask_retry_episode():
+    import torch
+    from test_headline import bench_video
+    fh, fw, ch, cw, nf, n = 720, 1280, 1440, 1536, 1000, 96
+    _, host = bench_video(n, fh, fw, torch.device("cuda", 0))
+    vm = rtvm.VideMosaic(host[0], nfeatures=nf, canvas_size=(ch, cw), **HEADLESS)
+    for t in range(1, n + 1):
+        vm.process_frame(host[t], t)
+    H, canvas, matches = vm.H, vm.output_img_u8(), [(m.queryIdx, m.trainIdx) for m in vm.matches]
+    stats = dict(vm._pipe.stats)
+    vm.close()
+    assert stats["pieces_with_pending_frames"] > 0 and stats["batches"] == 3
+    om = OracleMosaic(host[0], nfeatures=nf, canvas_size=(ch, cw), glue="numpy")
+    for f in host[1:]:
+        om.process_frame(f)
+        assert om.status == 0
+    assert np.array_equal(H, om.H)
+    assert matches == list(zip(om.matches[0].tolist(), om.matches[1].tolist()))
+    assert np.array_equal(canvas, om.canvas)

@@ -393,8 +393,9 @@ def test_dropin_with_the_default_sift_detector_matches_oracle(capsys):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("detector,workers", [("sift", 3), ("sift", 1), ("orb", 4)])
-def test_process_frames_equals_frame_by_frame(capsys, detector, workers):
+@pytest.mark.parametrize("detector,workers,display", [("sift", 3, False), ("sift", 1, False), ("orb", 4, True),
+                                                      ("orb", 4, False)])
+def test_process_frames_equals_frame_by_frame(capsys, detector, workers, display):
     """process_frames (SIFT: detection, matching and RANSAC of several frames on worker threads ahead of the
     sequential part) leaves the same mosaic, homographies, features, matches and printed warnings as one
     process_frame call per frame, also across skipped frames (a black one, a repeated one that follows it)."""
@@ -403,7 +404,9 @@ def test_process_frames_equals_frame_by_frame(capsys, detector, workers):
     frames.insert(4, np.zeros_like(frames[0]))        # no features: skipped, the next frame matches frame 3
     frames.insert(7, np.zeros_like(frames[0]))
     frames.insert(8, np.zeros_like(frames[0]))        # two skipped frames in a row
-    kw = dict(detector_type=detector, visualize=False, show_intermediate=False, nfeatures=300)
+    # display on: every call completes before it returns, process_frames runs detection on worker threads;
+    # off (ORB): process_frame itself only enqueues and process_frames is a loop over it
+    kw = dict(detector_type=detector, visualize=False, show_intermediate=display, nfeatures=300)
     a = rtvm.VideMosaic(frames[0], **kw)
     Hs = []
     for t, f in enumerate(frames[1:], 1):
@@ -414,6 +417,7 @@ def test_process_frames_equals_frame_by_frame(capsys, detector, workers):
     b.process_frames(frames[1:5], 1, workers=workers)
     assert np.array_equal(b.H, Hs[3])
     b.process_frames(frames[5:], 5, workers=workers)
+    b.flush()                                         # headless: the warnings of frames still in flight
     out_b = capsys.readouterr().out
     assert out_a == out_b and out_a.count("пропуск кадра") == 3
     assert np.array_equal(a.H, b.H) and np.array_equal(a.H_old, b.H_old)
@@ -435,7 +439,7 @@ def test_process_frames_at_720p_equals_frame_by_frame(detector, nf):
     Gs, wh, ww = rtvm.synth.bounded_path(25, fh, fw, seed=2)
     world = rtvm.synth.make_world(wh, ww, seed=0)
     frames = list(rtvm.synth.render_video_torch(world, Gs, fh, fw, torch.device("cuda", 0)).cpu().numpy())
-    kw = dict(detector_type=detector, visualize=False, show_intermediate=False, nfeatures=nf)
+    kw = dict(detector_type=detector, visualize=False, show_intermediate=True, nfeatures=nf)
     a = rtvm.VideMosaic(frames[0], **kw)
     for t, f in enumerate(frames[1:], 1):
         a.process_frame(f, t)
