@@ -321,7 +321,7 @@ void free_all(rtvm_ctx* c) {
     c->ingest_slots = 0;
     void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas,
                     c->d_mask_old, c->d_bold, c->d_snap_canvas, c->d_snap_mask, c->d_side, c->d_snap, c->d_gk, c->d_H,
-                    c->d_wp, c->d_cbox, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
+                    c->d_wp, c->d_cbox, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_work, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
                     c->d_skip};
     free_feat(&c->feat_prev);
     for (void* p : ptrs)
@@ -485,28 +485,35 @@ extern "C" int rtvm_match_l2_knn2(rtvm_ctx* c, const float* q, int nq, const flo
     if (nq == 0) return RTVM_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t need_q = (size_t)nq * dim, need_t = (size_t)nt * dim;
-    if (need_q > c->l_cap_q || need_t > c->l_cap_t) {  // grow the staging buffers
+    const size_t need_w = rtvm_l2_work_bytes(nq, nt, dim);
+    if (need_q > c->l_cap_q || need_t > c->l_cap_t || need_w > c->l_cap_work) {  // grow the staging buffers
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        void* old[] = {c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag};
+        void* old[] = {c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_work};
         for (void* p : old)
             if (p) (void)hipFree(p);
-        c->d_lq = c->d_lt = c->d_l_dist = c->d_l_norms = nullptr;
+        c->d_lq = c->d_lt = c->d_l_dist = nullptr;
         c->d_l_idx = nullptr;
-        c->d_l_flag = nullptr;
-        c->l_cap_q = c->l_cap_t = 0;
+        c->d_l_work = nullptr;
         const size_t cq = need_q > c->l_cap_q ? need_q : c->l_cap_q, ct = need_t > c->l_cap_t ? need_t : c->l_cap_t;
+        const size_t cw = need_w > c->l_cap_work ? need_w : c->l_cap_work;
+        c->l_cap_q = c->l_cap_t = c->l_cap_work = 0;
         ALLOC(c, d_lq, cq);
         ALLOC(c, d_lt, ct);
         ALLOC(c, d_l_idx, (size_t)2 * (cq / dim + 1));
         ALLOC(c, d_l_dist, (size_t)2 * (cq / dim + 1));
-        ALLOC(c, d_l_norms, cq / dim + ct / dim + 2);
-        ALLOC(c, d_l_flag, 4);
+        {
+            char* w = nullptr;
+            int r_ = dev_alloc(c, &w, cw);
+            if (r_ != RTVM_OK) return r_;
+            c->d_l_work = w;
+        }
         c->l_cap_q = cq;
         c->l_cap_t = ct;
+        c->l_cap_work = cw;
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_lq, q, need_q * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_lt, t, need_t * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    int r = rtvm_launch_l2_knn2(c, c->d_lq, nq, c->d_lt, nt, dim, c->d_l_idx, c->d_l_dist, c->d_l_norms, c->d_l_flag);
+    int r = rtvm_launch_l2_knn2(c, c->d_lq, nq, c->d_lt, nt, dim, c->d_l_idx, c->d_l_dist, c->d_l_work);
     if (r) return r;
     HIP_TRY(c, hipMemcpyAsync(idx, c->d_l_idx, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(dist, c->d_l_dist, (size_t)nq * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -297,9 +297,8 @@ struct rtvm_ctx {
     float* d_lt;
     int32_t* d_l_idx;
     float* d_l_dist;
-    float* d_l_norms;
-    int* d_l_flag;
-    size_t l_cap_q, l_cap_t;   // capacities in floats / rows
+    void* d_l_work;            // flag, norms, bf16 operands, per-tile keys (rtvm_l2_work_bytes)
+    size_t l_cap_q, l_cap_t, l_cap_work;   // capacities in floats / bytes
 
     // --- RANSAC ---
     uint32_t* d_rs_raw;    // raw outputs of the fixed-seed RNG
@@ -394,8 +393,9 @@ void rtvm_ransac_raw_table(uint32_t* raw, int n);
 int rtvm_launch_ransac(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence);
 int rtvm_launch_ransac_search(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence);
 int rtvm_launch_ransac_refine(rtvm_ctx* c, int sb, int nb, double thresh);
+size_t rtvm_l2_work_bytes(int nq, int nt, int dim);
 int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim, int32_t* d_idx,
-                        float* d_dist, float* d_norms, int* d_flag);
+                        float* d_dist, void* work);
 
 // ---- optional per-kernel timing with HIP events on the context's stream (prof.hip) ----
 int rtvm_prof_begin(rtvm_ctx* c, const char* name);

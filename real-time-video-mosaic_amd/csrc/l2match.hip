@@ -35,96 +35,210 @@ __device__ __forceinline__ void top2_insert(Top2& t, float d, int j) {
     }
 }
 
-// flag[0] = 1 iff every value is an integer in [0, 255]
-__global__ __launch_bounds__(256) void k_l2_check(const float* __restrict__ a, size_t na, const float* __restrict__ b,
-                                                  size_t nb, int* __restrict__ flag) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    bool bad = false;
-    if (i < na) {
-        const float v = a[i];
-        bad |= !(v >= 0.f && v <= 255.f && v == floorf(v));
+// ---- matrix-core path -------------------------------------------------------------------------
+//
+// k_l2_prep   converts both descriptor sets to bf16 once, in the order the matrix-core operands
+//             are consumed: for every block of 32 rows and every k-step of 16 columns, the 64
+//             operand registers of a wave (lane = 32 * half + row, 8 consecutive columns each)
+//             are 1 KiB of consecutive memory.  Also the squared norms and the "all values are
+//             integers 0..255" flag.
+// k_l2_tile   one workgroup per 128 queries x 128 train rows: the train tile goes through LDS
+//             (coalesced 16-byte copies in, conflict-free 16-byte operand reads out), every wave
+//             keeps its 32 queries' operands in registers and runs 4 x KS MFMAs.  C = T * Q^T,
+//             so the accumulator column of a lane is its query and its registers are train
+//             rows: the running top-2 of a query is two packed keys per lane,
+//             (d2 << 7 | row in tile), updated with three integer min/max per element.
+// k_l2_merge  top-2 of every query over the column tiles, sqrt, output.
+//
+// Order of the results: OpenCV compares the float32 distances sqrt(d2), earlier train row first
+// on ties.  Two different integers d2 can round to the same float sqrt only from 2^22 up (below,
+// neighbouring integers' roots are at least 2 ulp apart), so keys in d2 give the same order
+// whenever the second-best d2 of a query is below 2^22: always for real SIFT descriptors
+// (norm 512, d2 <= 2^20).  Queries beyond that go to k_l2_far, which orders by the rounded roots.
+
+constexpr int L2_TILE = 128;
+constexpr uint32_t L2_NOKEY = 0xFFFFFFFFu;
+constexpr uint32_t L2_FAR = 1u << 22;
+
+// grid.y = 0: queries, 1: train rows.  One thread per (row, group of 8 columns); KS = dim / 16.
+template <int KS>
+__global__ __launch_bounds__(256) void k_l2_prep(const float* __restrict__ q, int nq, const float* __restrict__ t, int nt,
+                                                 uint4* __restrict__ qb, uint4* __restrict__ tb,
+                                                 float* __restrict__ qn, float* __restrict__ tn, int* __restrict__ flag) {
+    constexpr int G = 2 * KS;  // groups of 8 columns per row
+    const bool train = blockIdx.y != 0;
+    const float* __restrict__ src = train ? t : q;
+    const int n = train ? nt : nq;
+    const int n_pad = (n + L2_TILE - 1) / L2_TILE * L2_TILE;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int row = id / G, g = id % G;
+    if (row >= n_pad) return;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < n) {
+        const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)row * (16 * KS) + 8 * g);
+        const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)row * (16 * KS) + 8 * g + 4);
+        v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w, v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
     }
-    if (i < nb) {
-        const float v = b[i];
-        bad |= !(v >= 0.f && v <= 255.f && v == floorf(v));
+    bool bad = false;
+    float ss = 0.f;
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        bad |= !(v[i] >= 0.f && v[i] <= 255.f && v[i] == floorf(v[i]));
+        ss += v[i] * v[i];   // exact for 8-bit integers in any order (below 2^24)
+        const uint32_t h = __float_as_uint(v[i]) >> 16;
+        if (i & 1)
+            w[i >> 1] |= h << 16;
+        else
+            w[i >> 1] = h;
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
-}
-
-__global__ __launch_bounds__(256) void k_l2_norms(const float* __restrict__ a, int n, int dim, float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < dim; k++) s += a[(size_t)i * dim + k] * a[(size_t)i * dim + k];
-    out[i] = s;
-}
-
-__device__ __forceinline__ bf16x8 load_bf16x8(const float* __restrict__ p) {
-    const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
-    bf16x8 r;
-    r[0] = (short)(__float_as_uint(lo.x) >> 16);
-    r[1] = (short)(__float_as_uint(lo.y) >> 16);
-    r[2] = (short)(__float_as_uint(lo.z) >> 16);
-    r[3] = (short)(__float_as_uint(lo.w) >> 16);
-    r[4] = (short)(__float_as_uint(hi.x) >> 16);
-    r[5] = (short)(__float_as_uint(hi.y) >> 16);
-    r[6] = (short)(__float_as_uint(hi.z) >> 16);
-    r[7] = (short)(__float_as_uint(hi.w) >> 16);
-    return r;
-}
-
-// One wave per 32 queries.  C = T_tile (32 train x K) * Q^T (K x 32 queries): the
-// accumulator column of a lane is its query, its 16 registers are 16 train rows, so
-// the running top-2 of a query lives in two lanes (l, l+32) and is merged at the end.
-// DIMS = dim / 16 k-steps; the query fragments stay in registers.
-template <int DIMS>
-__global__ __launch_bounds__(64) void k_l2_knn2_mfma(const float* __restrict__ q, int nq, const float* __restrict__ t,
-                                                     int nt, const float* __restrict__ qn,
-                                                     const float* __restrict__ tn, const int* __restrict__ flag,
-                                                     int32_t* __restrict__ idx, float* __restrict__ dist) {
-    if (!*flag) return;  // data is not 8-bit integer valued: the direct kernel handles it
-    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-    const int dim = DIMS * 16;
-    const int qi = min(blockIdx.x * 32 + r, nq - 1);
-    bf16x8 bq[DIMS];
+    // the G threads of a row are consecutive lanes of one wave (G divides 64)
 #pragma unroll
-    for (int s = 0; s < DIMS; s++) bq[s] = load_bf16x8(q + (size_t)qi * dim + s * 16 + 8 * h);
-    const float nqv = qn[qi];
-    Top2 best = {INFINITY, INFINITY, -1, -1};
-    for (int t0 = 0; t0 < nt; t0 += 32) {
-        const int tj = min(t0 + r, nt - 1);
+    for (int d = 1; d < G; d <<= 1) ss += __shfl_xor(ss, d);
+    if (g == 0) (train ? tn : qn)[row] = ss;
+    const int s = g >> 1, h = g & 1;
+    (train ? tb : qb)[((size_t)(row >> 5) * KS + s) * 64 + h * 32 + (row & 31)] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ void key_top2(uint32_t& k0, uint32_t& k1, uint32_t key) {
+    const uint32_t lo = min(k0, key), hi = max(k0, key);
+    k0 = lo;
+    k1 = min(k1, hi);
+}
+
+// blockIdx.x = query tile, blockIdx.y = train tile.  part: [train tiles][padded queries][2] keys.
+template <int KS>
+__global__ __launch_bounds__(256) void k_l2_tile(const uint4* __restrict__ qb, const uint4* __restrict__ tb,
+                                                 const float* __restrict__ qn, const float* __restrict__ tn, int nt,
+                                                 int nq_pad, const int* __restrict__ flag, uint32_t* __restrict__ part) {
+    if (!*flag) return;  // not 8-bit integer data: k_l2_knn2_direct computes the result
+    __shared__ uint4 s_t[4 * KS * 64];
+    __shared__ __align__(16) float s_tn[L2_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int t0 = blockIdx.y * L2_TILE;
+    {
+        const uint4* __restrict__ src = tb + (size_t)blockIdx.y * (4 * KS * 64);
+#pragma unroll
+        for (int i = 0; i < KS; i++) s_t[tid + 256 * i] = src[tid + 256 * i];
+        if (tid < L2_TILE) s_tn[tid] = tn[t0 + tid];
+    }
+    // the wave's 32 queries: operand registers for all k-steps
+    const int qblock = blockIdx.x * 4 + wave;
+    bf16x8 bq[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        const uint4 u = qb[((size_t)qblock * KS + s) * 64 + lane];
+        bq[s] = __builtin_bit_cast(bf16x8, u);
+    }
+    const float nqv = qn[qblock * 32 + (lane & 31)];
+    __syncthreads();
+    uint32_t k0 = L2_NOKEY, k1 = L2_NOKEY;
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[e] = 0.f;
 #pragma unroll
-        for (int s = 0; s < DIMS; s++) {
-            const bf16x8 at = load_bf16x8(t + (size_t)tj * dim + s * 16 + 8 * h);
+        for (int s = 0; s < KS; s++) {
+            const bf16x8 at = __builtin_bit_cast(bf16x8, s_t[(rb * KS + s) * 64 + lane]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, bq[s], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const int j = t0 + row;
-            if (j < nt) {
-                const float d2 = (nqv + tn[j]) - 2.f * acc[e];
-                top2_insert(best, sqrtf(d2), j);
+        for (int g4 = 0; g4 < 4; g4++) {
+            // accumulator registers 4*g4 .. 4*g4+3 are train rows 8*g4 + 4*h + (0..3) of the row block
+            const int r0 = 32 * rb + 8 * g4 + 4 * h;
+            const float4 n4 = *reinterpret_cast<const float4*>(&s_tn[r0]);
+            const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float d2 = (nqv + nn[i]) - 2.f * acc[4 * g4 + i];   // exact: integers below 2^24
+                const uint32_t key = ((uint32_t)d2 << 7) | (uint32_t)(r0 + i);
+                key_top2(k0, k1, t0 + r0 + i < nt ? key : L2_NOKEY);
             }
         }
     }
-    // merge the two half-waves
-    Top2 o;
-    o.d0 = __shfl_xor(best.d0, 32);
-    o.d1 = __shfl_xor(best.d1, 32);
-    o.i0 = __shfl_xor(best.i0, 32);
-    o.i1 = __shfl_xor(best.i1, 32);
-    if (o.i0 >= 0) top2_insert(best, o.d0, o.i0);
-    if (o.i1 >= 0) top2_insert(best, o.d1, o.i1);
-    const int qo = blockIdx.x * 32 + r;
-    if (h == 0 && qo < nq) {
-        idx[2 * qo] = best.i0;
-        idx[2 * qo + 1] = best.i1;
-        dist[2 * qo] = best.d0;
-        dist[2 * qo + 1] = best.d1;
+    // the two lanes of a query
+    const uint32_t o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
+    key_top2(k0, k1, o0);
+    key_top2(k0, k1, o1);
+    if (h == 0) {
+        const size_t o = ((size_t)blockIdx.y * nq_pad + qblock * 32 + lane) * 2;
+        part[o] = k0;
+        part[o + 1] = k1;
+    }
+}
+
+// One thread per query: top-2 over the train tiles (tiles ascend with the row index, keys inside
+// a tile order by d2 then row), sqrt, output; queries whose second-best d2 reaches 2^22 are listed
+// for k_l2_far.
+__global__ __launch_bounds__(256) void k_l2_merge(const uint32_t* __restrict__ part, int n_tiles, int nq, int nq_pad,
+                                                  const int* __restrict__ flag, int32_t* __restrict__ idx,
+                                                  float* __restrict__ dist, int* __restrict__ far_count,
+                                                  int* __restrict__ far_list) {
+    if (!*flag) return;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    unsigned long long b0 = ~0ull, b1 = ~0ull;
+    for (int tI = 0; tI < n_tiles; tI++) {
+        const uint2 k = *reinterpret_cast<const uint2*>(part + ((size_t)tI * nq_pad + qi) * 2);
+        const uint32_t ks[2] = {k.x, k.y};
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (ks[u] == L2_NOKEY) continue;
+            const unsigned long long key = ((unsigned long long)(ks[u] >> 7) << 32) | (uint32_t)(tI * L2_TILE + (ks[u] & 127));
+            const unsigned long long lo = key < b0 ? key : b0, hi = key < b0 ? b0 : key;
+            b0 = lo;
+            b1 = hi < b1 ? hi : b1;
+        }
+    }
+    const uint32_t d2a = (uint32_t)(b0 >> 32), d2b = (uint32_t)(b1 >> 32);
+    if (d2b >= L2_FAR) {  // the order of the rounded roots may differ from the order of d2
+        far_list[atomicAdd(far_count, 1)] = qi;
+        return;
+    }
+    idx[2 * qi] = (int)(uint32_t)b0;
+    idx[2 * qi + 1] = (int)(uint32_t)b1;
+    dist[2 * qi] = sqrtf((float)d2a);
+    dist[2 * qi + 1] = sqrtf((float)d2b);
+}
+
+// The listed queries, one wave each (grid-stride over the list): every train row's sqrt(d2) in
+// float32 as the sequential loop computes it, top-2 under "smaller distance, then earlier row".
+template <int KS>
+__global__ __launch_bounds__(64) void k_l2_far(const float* __restrict__ q, const float* __restrict__ t, int nt,
+                                               const int* __restrict__ flag, const int* __restrict__ far_count,
+                                               const int* __restrict__ far_list, int32_t* __restrict__ idx,
+                                               float* __restrict__ dist) {
+    if (!*flag) return;
+    const int lane = threadIdx.x, dim = 16 * KS;
+    const int n_far = *far_count;
+    for (int e = blockIdx.x; e < n_far; e += gridDim.x) {
+        const int qi = far_list[e];
+        Top2 best = {INFINITY, INFINITY, -1, -1};
+        for (int j = lane; j < nt; j += 64) {
+            float s = 0.f;
+            for (int k = 0; k < dim; k++) {
+                const float d = q[(size_t)qi * dim + k] - t[(size_t)j * dim + k];
+                s += d * d;
+            }
+            top2_insert(best, sqrtf(s), j);
+        }
+        for (int m = 1; m < 64; m <<= 1) {
+            Top2 o;
+            o.d0 = __shfl_xor(best.d0, m);
+            o.d1 = __shfl_xor(best.d1, m);
+            o.i0 = __shfl_xor(best.i0, m);
+            o.i1 = __shfl_xor(best.i1, m);
+            if (o.i0 >= 0) top2_insert(best, o.d0, o.i0);
+            if (o.i1 >= 0) top2_insert(best, o.d1, o.i1);
+        }
+        if (lane == 0) {
+            idx[2 * qi] = best.i0;
+            idx[2 * qi + 1] = best.i1;
+            dist[2 * qi] = best.d0;
+            dist[2 * qi + 1] = best.d1;
+        }
     }
 }
 
@@ -187,32 +301,66 @@ __global__ __launch_bounds__(256) void k_l2_knn2_direct(const float* __restrict_
 
 }  // namespace
 
-// dq: nq x dim, dt: nt x dim (device); d_idx / d_dist: nq x 2; d_norms: nq + nt floats; d_flag: 1 int
+size_t rtvm_l2_work_bytes(int nq, int nt, int dim) {
+    const size_t nq_pad = (size_t)(nq + L2_TILE - 1) / L2_TILE * L2_TILE, nt_pad = (size_t)(nt + L2_TILE - 1) / L2_TILE * L2_TILE;
+    size_t b = 256;                                   // flag, far_count
+    b += (nq_pad + nt_pad) * sizeof(float) + 512;     // norms
+    b += (nq_pad + nt_pad) * dim * 2 + 512;           // bf16 operands
+    b += (nt_pad / L2_TILE) * nq_pad * 2 * sizeof(uint32_t) + 256;  // per-tile top-2 keys
+    b += nq_pad * sizeof(int) + 256;                  // far list
+    return b;
+}
+
+// dq: nq x dim, dt: nt x dim (device); d_idx / d_dist: nq x 2; work: rtvm_l2_work_bytes(nq, nt, dim) bytes.
 int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, int nt, int dim, int32_t* d_idx,
-                        float* d_dist, float* d_norms, int* d_flag) {
+                        float* d_dist, void* work) {
     if (nq <= 0) return RTVM_OK;
     // two 64-row tiles; the same memory then holds the 256 partial results of the final merge
     size_t lds_bytes = (size_t)2 * 64 * (dim + 1) * sizeof(float);
     if (lds_bytes < 256 * sizeof(Top2)) lds_bytes = 256 * sizeof(Top2);
     if (lds_bytes > 160 * 1024) RTVM_FAIL(c, RTVM_E_ARG, "match_l2_knn2: descriptor dimension %d is too large", dim);
     const bool mfma = dim == 128 || dim == 64;
+    int* d_flag = (int*)work;
     if (mfma) {
-        HIP_TRY(c, hipMemsetAsync(d_flag, 1, sizeof(int), c->stream));  // non-zero = "all values are 8-bit integers"
-
-        const size_t na = (size_t)nq * dim, nb = (size_t)nt * dim;
-        const size_t nmax = na > nb ? na : nb;
-        RTVM_LAUNCH(c, k_l2_check, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, dq, na, dt, nb, d_flag);
-        RTVM_LAUNCH(c, k_l2_norms, dim3((nq + 255) / 256), dim3(256), 0, dq, nq, dim, d_norms);
-        RTVM_LAUNCH(c, k_l2_norms, dim3((nt + 255) / 256), dim3(256), 0, dt, nt, dim, d_norms + nq);
+        const int nq_pad = (nq + L2_TILE - 1) / L2_TILE * L2_TILE, nt_pad = (nt + L2_TILE - 1) / L2_TILE * L2_TILE;
+        const int n_tiles = nt_pad / L2_TILE;
+        char* w = (char*)work + 256;
+        int* d_far_count = d_flag + 1;
+        float* qn = (float*)w;
+        float* tn = qn + nq_pad;
+        w += ((size_t)(nq_pad + nt_pad) * sizeof(float) + 255) / 256 * 256;
+        uint4* qb = (uint4*)w;
+        uint4* tb = qb + (size_t)nq_pad * dim / 8;
+        w += ((size_t)(nq_pad + nt_pad) * dim * 2 + 255) / 256 * 256;
+        uint32_t* part = (uint32_t*)w;
+        w += ((size_t)n_tiles * nq_pad * 2 * sizeof(uint32_t) + 255) / 256 * 256;
+        int* far_list = (int*)w;
+        // flag = 1 ("all values are 8-bit integers" until a value says otherwise), far_count = 0
+        HIP_TRY(c, hipMemsetAsync(d_flag, 0, 2 * sizeof(int), c->stream));
+        HIP_TRY(c, hipMemsetAsync(d_flag, 1, 1, c->stream));
+        const int n_max = nq_pad > nt_pad ? nq_pad : nt_pad;
+        const dim3 gp((unsigned)(((size_t)n_max * (dim / 8) + 255) / 256), 2), gt(nq_pad / L2_TILE, n_tiles);
+        if (dim == 128) {
+            RTVM_LAUNCH(c, k_l2_prep<8>, gp, dim3(256), 0, dq, nq, dt, nt, qb, tb, qn, tn, d_flag);
+            RTVM_LAUNCH(c, k_l2_tile<8>, gt, dim3(256), 0, (const uint4*)qb, (const uint4*)tb, (const float*)qn,
+                        (const float*)tn, nt, nq_pad, (const int*)d_flag, part);
+        } else {
+            RTVM_LAUNCH(c, k_l2_prep<4>, gp, dim3(256), 0, dq, nq, dt, nt, qb, tb, qn, tn, d_flag);
+            RTVM_LAUNCH(c, k_l2_tile<4>, gt, dim3(256), 0, (const uint4*)qb, (const uint4*)tb, (const float*)qn,
+                        (const float*)tn, nt, nq_pad, (const int*)d_flag, part);
+        }
+        RTVM_LAUNCH(c, k_l2_merge, dim3((nq + 255) / 256), dim3(256), 0, (const uint32_t*)part, n_tiles, nq, nq_pad,
+                    (const int*)d_flag, d_idx, d_dist, d_far_count, far_list);
+        const int far_grid = nq < 1024 ? nq : 1024;
         if (dim == 128)
-            RTVM_LAUNCH(c, k_l2_knn2_mfma<8>, dim3((nq + 31) / 32), dim3(64), 0, dq, nq, dt, nt, d_norms, d_norms + nq,
-                        d_flag, d_idx, d_dist);
+            RTVM_LAUNCH(c, k_l2_far<8>, dim3(far_grid), dim3(64), 0, dq, dt, nt, (const int*)d_flag,
+                        (const int*)d_far_count, (const int*)far_list, d_idx, d_dist);
         else
-            RTVM_LAUNCH(c, k_l2_knn2_mfma<4>, dim3((nq + 31) / 32), dim3(64), 0, dq, nq, dt, nt, d_norms, d_norms + nq,
-                        d_flag, d_idx, d_dist);
+            RTVM_LAUNCH(c, k_l2_far<4>, dim3(far_grid), dim3(64), 0, dq, dt, nt, (const int*)d_flag,
+                        (const int*)d_far_count, (const int*)far_list, d_idx, d_dist);
     }
     (void)hipFuncSetAttribute((const void*)k_l2_knn2_direct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    RTVM_LAUNCH(c, k_l2_knn2_direct, dim3((nq + 63) / 64), dim3(256), lds_bytes, dq, nq, dt, nt, dim, d_flag,
+    RTVM_LAUNCH(c, k_l2_knn2_direct, dim3((nq + 63) / 64), dim3(256), lds_bytes, dq, nq, dt, nt, dim, (const int*)d_flag,
                 mfma ? 1 : 0, d_idx, d_dist);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;

@@ -135,11 +135,39 @@ def sift_like(seed, nq, nt, dim=128, planted=0.7):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nq,nt,dim", [(1, 2, 128), (33, 31, 128), (500, 700, 128), (2000, 2000, 128),
-                                       (300, 257, 64), (100, 90, 32)])
+                                       (300, 257, 64), (100, 90, 32), (128, 128, 128), (129, 257, 128),
+                                       (4100, 3000, 128)])
 def test_hip_l2_knn2_integer_valued_exact(ctx_small, nq, nt, dim):
     q, t = sift_like(nq + nt, nq, nt, dim)
     gi, gd = ctx_small.match_l2_knn2(q, t)
     ri, rd = orc.match_l2_knn2(q, t)
+    assert np.array_equal(gi, ri)
+    assert np.array_equal(gd, rd)
+
+
+@pytest.mark.gpu
+def test_hip_l2_knn2_far_descriptors_order_by_the_rounded_distance(ctx_small):
+    """From d2 = 2^22 up neighbouring integers can round to the same float32 root; OpenCV compares the roots, so
+    the earlier train row wins a tie of roots although its d2 is larger.  Mixed with queries whose neighbours are
+    near (the common case, ordered by d2 on the matrix cores)."""
+    rng = np.random.default_rng(17)
+    nt, nq = 300, 140
+    t = np.zeros((nt, 128), np.float32)
+    t[:, :100] = 255                                   # 100 * 255^2 = 6 502 500 > 2^22 from an all-zero query
+    t[:, 100:] = rng.integers(0, 2, (nt, 28))          # plus 0..28: roots 0.8 ulp apart
+    t[:, 100:108] = 1                                  # at least 8 everywhere ...
+    t[5, 100:] = 0
+    t[5, 100:103] = 1                                  # ... except row 5: d2 = 6 502 503 ...
+    t[9, 100:] = 0
+    t[9, 100:102] = 1                                  # ... and row 9: 6 502 502, the same float32 root
+    q = np.zeros((nq, 128), np.float32)
+    q[40:, :100] = 255                                 # near queries: d2 = 0..28 + noise
+    q[40:, 100:] = rng.integers(0, 3, (nq - 40, 28))
+    q[20:40, :64] = 255                                # in between: 36 * 255^2 = 2 340 900 < 2^22
+    ri, rd = orc.match_l2_knn2(q, t)
+    d2 = ((q[0][None] - t) ** 2).sum(1)
+    assert int(np.argmin(d2)) == 9 and ri[0].tolist() == [5, 9] and rd[0, 0] == rd[0, 1]   # the earlier row wins
+    gi, gd = ctx_small.match_l2_knn2(q, t)
     assert np.array_equal(gi, ri)
     assert np.array_equal(gd, rd)
 
