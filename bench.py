@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
 """Headline benchmark: stitched frames/s of the VideMosaic hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): synthetic 720p panned video, ORB-1000 +
-BF-Hamming cross-check + RANSAC findHomography + warpPerspective/blend into a
-1440x1536 canvas.  A step = VideMosaic.process_frame on one frame
-(rtvm_process_frame, frames already resident in HBM).  With --gpus N every rank
-stitches its own, independently seeded stream on its own GPU (no data-path
-collective; RCCL only carries the barrier and the max-over-ranks time).
+Workload (BASELINE.json configs[1]): synthetic 720p panned video, ORB-1000 + BF-Hamming
+cross-check + RANSAC findHomography + warpPerspective / blend into a 1440x1536 canvas.  A step
+is VideMosaic.process_frame (reference main.py:710-759) on one frame; the frames are resident in
+HBM and go through Context.process_video (rtvm_batch_detect / rtvm_batch_retry: detection,
+matching and RANSAC in batches ahead of the warp + blend, which follows in pieces).  With
+--gpus N every rank stitches its own, independently seeded stream on its own GPU (no data-path
+collective; RCCL carries only the barrier and the max-over-ranks time).  --procs N starts N such
+processes on ONE GPU (gloo): what N Python orchestrators cost each other on one host.
+
+Other workloads (--config): 1080p and 4K / 16k-canvas ORB streams through the same pipeline, and
+1080p_sift2000_l2: the reference's default detector at 2000 features, whose L2 knn-2 matcher is
+the one dense contraction of the path (matrix-core roofline).
 
 Prints ONE JSON line on rank 0.
 """
@@ -14,6 +20,7 @@ import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,7 +37,12 @@ CONFIGS = {
     "1080p_orb1000": (1080, 1920, 2160, 2304, 1000),
     "4k_orb4000_canvas16k": (2160, 3840, 4096, 16384, 4000),
     "360p_orb700": (360, 640, 720, 768, 700),
+    "1080p_sift2000_l2": (1080, 1920, 2160, 2304, 2000),
 }
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E
+HBM_COPY_GBS = 6290.0        # measured float4 copy rate
+MFMA_BF16_TFLOPS = 2500.0    # dense bf16 matrix-core peak
+PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
 
 
 def pyramid_pixels(fh, fw):
@@ -48,8 +60,8 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
     serves all frames of the batch.
 
     The distance transform runs two jobs per frame: the new mask on the frame's region of the
-    canvas (roi_px pixels) and the (predicted) old mask on the whole canvas, whose distances are
-    only needed on the blend window (the region plus the 15-pixel blur margin)."""
+    canvas (roi_px pixels) and the (predicted) old mask on the canvas content's bounding box, whose
+    distances are only needed on the blend window (the region plus the 15-pixel blur margin)."""
     P, C, S = fh * fw, ch * cw, pyramid_pixels(fh, fw)
     win_h, win_w = min(ch, fh + 38), min(cw, fw + 38)
     win = win_h * win_w
@@ -78,16 +90,34 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
     return table.get(name)
 
 
-def cpu_baseline(frames_np, cfg, n_frames):
-    """The CPU restatement (oracle/, single thread) on the first n_frames of the same video."""
+def warp_blend_stage_bytes(fh, fw, ch, cw, roi_px):
+    """The warp + blend stage by the reference's own data flow (main.py:871-927): frame read once, canvas
+    region read + written once, two full-canvas distance transforms (mask read + f32 distance written)
+    and two 31x31 blurs of f32 weights (read + write per separable pass)."""
+    return 3 * fh * fw + 6 * roi_px + 2 * 5 * ch * cw + 16 * roi_px
+
+
+def oracle_modules():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi
     from oracle_mosaic import OracleMosaic
+    return oracle_ffi, OracleMosaic
+
+
+def cpu_baseline(frames_np, cfg, n_frames, threads, detector="orb"):
+    """The CPU restatement (oracle/) on the first n_frames of the same video: frames/s and the mosaic."""
+    orc, OracleMosaic = oracle_modules()
     fh, fw, ch, cw, nf = cfg
-    om = OracleMosaic(frames_np[0], nfeatures=nf, canvas_size=(ch, cw), fixed=False, glue="explicit")
-    t0 = time.perf_counter()
-    for f in frames_np[1:n_frames + 1]:
-        om.process_frame(f)
-    dt = time.perf_counter() - t0
+    before = orc.set_threads(threads)
+    try:
+        om = OracleMosaic(frames_np[0], nfeatures=nf, canvas_size=(ch, cw), fixed=False,
+                          glue="explicit" if detector == "orb" else "numpy", detector=detector)
+        t0 = time.perf_counter()
+        for f in frames_np[1:n_frames + 1]:
+            om.process_frame(f)
+        dt = time.perf_counter() - t0
+    finally:
+        orc.set_threads(before)
     return n_frames / dt, om
 
 
@@ -112,6 +142,205 @@ def stream_seed(rank, world):
     return 0 if world == 1 else 10 + rank
 
 
+def per_rank_rates(frames, seconds, world, device=None):
+    """Every rank's own frames/s, gathered on all ranks."""
+    if world <= 1:
+        return [frames / seconds]
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([frames / seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def pmc_traffic(kernel, config):
+    """HBM bytes per frame of `kernel` from the committed rocprofv3 --pmc summary (separate FETCH_SIZE and
+    WRITE_SIZE passes over a known number of frames; the counters cannot be read from inside this process)."""
+    try:
+        with open(PMC_FILE) as fjs:
+            pmc = json.load(fjs)
+        if pmc.get("config") != config:
+            return None, None
+        ent = pmc["kernels"].get(kernel)
+        if not ent:
+            return None, None
+        return ent["hbm_bytes_per_frame"], pmc.get("_about")
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
+def run_procs(args):
+    """N independent single-GPU processes (own context, own seeded video) on ONE GPU, timed between common
+    barriers (gloo): the cost of N Python orchestrators and N pipelines sharing a host and a device."""
+    port = 29000 + os.getpid() % 3000
+    procs = []
+    for r in range(args.procs):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.procs), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RTVM_BENCH_SAME_GPU="1")
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup",
+               str(args.warmup), "--config", args.config, "--batch", str(args.batch), "--cpu-frames", "0",
+               "--dropin-frames", "0", "--host-frames", "0", "--sift-frames", "0"]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = [p.wait() for p in procs]
+    if any(rc):
+        raise SystemExit("a child process failed: %s" % rc)
+    sys.stdout.write(out.decode())
+
+
+def bench_sift_l2(args, cfg, dev, local_rank):
+    """cfg 3: 1080p, the reference's default detector with 2000 features.  value = stitched frames/s of
+    VideMosaic(detector_type='sift') (host frames, PCIe included: SIFT is not in the device-resident
+    pipeline); roofline = the L2 knn-2 matcher's matrix-core kernel on the descriptors of the video."""
+    fh, fw, ch, cw, nf = cfg
+    K, W = args.steps, args.warmup
+    T = 1 + W + K
+    Gs, wh, ww = synth.bounded_path(T, fh, fw, seed=2)
+    world_img = synth.make_world(wh, ww, seed=0)
+    host = list(synth.render_video_torch(world_img, Gs, fh, fw, dev).cpu().numpy())
+    vm = rtvm.VideMosaic(host[0], detector_type="sift", nfeatures=nf, canvas_size=(ch, cw), device=local_rank,
+                         show_intermediate=False, visualize=False)
+    vm.process_frames(host[1:1 + W], 1, workers=4)
+    vm.output_img_u8()
+    t0 = time.perf_counter()
+    vm.process_frames(host[1 + W:], 1 + W, workers=4)
+    vm.output_img_u8()
+    elapsed = time.perf_counter() - t0
+    q, t = vm.des_cur, vm.des_prev
+    n_matches = len(vm.matches)
+    vm.close()
+    # the matcher on the last two frames' descriptors, kernels timed with HIP events on their stream
+    ctx = rtvm.Context(device=local_rank)
+    for _ in range(3):
+        ctx.match_l2_knn2(q, t)
+    reps = 50
+    ctx.profile_start(None)
+    for _ in range(reps):
+        ctx.match_l2_knn2(q, t)
+    tab = ctx.profile_stop()
+    ctx.close()
+    name = "k_l2_tile<8>"
+    launches, total_ms, _ = tab[name]
+    avg_s = total_ms / launches * 1e-3
+    flop = 2.0 * len(q) * len(t) * 128
+    all_us = sum(v[1] for v in tab.values()) / reps * 1e3
+    roof = {"kernel": name, "bound": "mfma", "launches": launches, "avg_us": avg_s * 1e6,
+            "achieved": flop / avg_s / 1e12, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": flop / avg_s / 1e12 / MFMA_BF16_TFLOPS, "traffic": None,
+            "algorithmic_flop": flop, "descriptors": [len(q), len(t), 128],
+            "matcher_all_kernels_us": all_us,
+            "note": "2*Nq*Nt*128 flop of one 128x128-tile launch over the whole distance matrix; at this size the "
+                    "launch is one tile per workgroup and latency bound (16000 x 16000: 0.25 of the peak)"}
+    cpu = None
+    if args.cpu_frames > 0:
+        n_cpu = min(args.cpu_frames, 4)
+        fps1, _ = cpu_baseline(host, cfg, n_cpu, 1, "sift")
+        cpu = {"value": fps1, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "first %d frames of the same video through the oracle/ C++ restatement (SIFT), one thread" % n_cpu}
+    return {
+        "metric": "stitched frames/sec @1080p SIFT-2000 + L2 knn-2 (matrix cores) on 1xMI355X",
+        "value": K / elapsed, "unit": "frames/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.config, "frame": [fh, fw], "canvas": [ch, cw], "nfeatures": nf,
+                   "path": "VideMosaic.process_frames, 4 worker threads, host frames (PCIe included)",
+                   "last_frame_matches": n_matches},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+
+
+def leg_dropin(args, cfg, frames, local_rank, T):
+    """The drop-in class as the reference's main loop drives it (main.py:1596-1634): one host frame per
+    process_frame call, PCIe copies included.  Headless (both display flags off, what main.py --hide passes)
+    process_frame only takes the frame and the work follows in batches; the clock stops after flush() + a device
+    sync, i.e. with every frame stitched."""
+    fh, fw, ch, cw, nf = cfg
+    nd = min(args.dropin_frames, T - 1)
+    n_warm = min(32, nd // 4)
+    host_frames = frames[:nd + 1].cpu().numpy()
+    kw = dict(detector_type="orb", nfeatures=nf, canvas_size=(ch, cw), device=local_rank, warp_mode=args.warp_mode)
+    vm = rtvm.VideMosaic(host_frames[0], show_intermediate=False, visualize=False, **kw)
+    for t in range(1, n_warm + 1):
+        vm.process_frame(host_frames[t], t)
+    vm.flush()
+    vm._ctx.sync()
+    td0 = time.perf_counter()
+    for t in range(n_warm + 1, nd + 1):
+        vm.process_frame(host_frames[t], t)
+    vm.flush()
+    vm._ctx.sync()
+    td = time.perf_counter() - td0
+    dropin = {"value": (nd - n_warm) / td, "unit": "frames/s", "frames": nd - n_warm,
+              "pipeline": dict(vm._pipe.stats),
+              "note": "Python VideMosaic.process_frame, headless, one host frame per call: copy into the pinned "
+                      "ring, PCIe copy, batched detection, host-side validate/smooth/chain, batched warp + blend"}
+    vm.close()
+    # the same class with a display flag set: every call completes before it returns
+    ns = min(136, nd)
+    vm = rtvm.VideMosaic(host_frames[0], show_intermediate=True, visualize=False, **kw)
+    vm.process_frame(host_frames[1], 1)
+    td0 = time.perf_counter()
+    for t in range(2, ns + 1):
+        vm.process_frame(host_frames[t], t)
+    vm._ctx.sync()
+    dropin["process_frame_synchronous"] = {"value": (ns - 1) / (time.perf_counter() - td0), "frames": ns - 1}
+    vm.close()
+    if ns >= 16:
+        # ... and through process_frames: detection, matching and RANSAC on four worker threads
+        vm = rtvm.VideMosaic(host_frames[0], show_intermediate=True, visualize=False, **kw)
+        vm.process_frames(list(host_frames[1:9]), 1, workers=4)
+        td0 = time.perf_counter()
+        vm.process_frames(list(host_frames[9:ns + 1]), 9, workers=4)
+        vm.output_img_u8()
+        dropin["process_frames_4_workers"] = {"value": (ns - 8) / (time.perf_counter() - td0), "frames": ns - 8}
+        vm.close()
+    return dropin
+
+
+def leg_sift(args, cfg, frames, local_rank, T):
+    """The reference's default detector (main.py:1603 passes "sift"): the drop-in class frame by frame, and
+    process_frames with detection, matching and RANSAC on worker threads."""
+    fh, fw, ch, cw, nf = cfg
+    ns = min(args.sift_frames, T - 1)
+    host_frames = list(frames[:ns + 1].cpu().numpy())
+    vm = rtvm.VideMosaic(host_frames[0], detector_type="sift", nfeatures=700, canvas_size=(ch, cw),
+                         device=local_rank, warp_mode=args.warp_mode, show_intermediate=False, visualize=False)
+    n1 = min(16, ns)
+    ts0 = time.perf_counter()
+    for t, f in enumerate(host_frames[1:1 + n1], 1):
+        vm.process_frame(f, t)
+    ts1 = time.perf_counter()
+    vm.process_frames(host_frames[1 + n1:], 1 + n1, workers=4)
+    vm.output_img_u8()
+    ts2 = time.perf_counter()
+    leg = {"process_frame": {"value": n1 / (ts1 - ts0), "frames": n1},
+           "process_frames_4_workers": {"value": (ns - n1) / (ts2 - ts1), "frames": ns - n1} if ns > n1 else None,
+           "unit": "frames/s", "nfeatures": 700,
+           "note": "VideMosaic(detector_type='sift') with host frames, PCIe copies included"}
+    vm.close()
+    return leg
+
+
+def leg_host_ring(args, cfg, frames, local_rank, T, B):
+    """Frames in host memory through the ingest ring (pinned slots, copies on a stream of their own) into the same
+    batched pipeline: the PCIe-inclusive rate of the throughput path."""
+    fh, fw, ch, cw, nf = cfg
+    nh = min(args.host_frames, T - 1)
+    host_frames = frames[:nh + 1].cpu().numpy()
+    ctx2 = rtvm.Context(fh, fw, ch, cw, nfeatures=nf,
+                        flags=(rtvm._ffi.FLAG_WARP_FIXED if args.warp_mode == "fixed" else 0), device=local_rank)
+    ctx2.process_host_video(host_frames[0], host_frames[1:1 + min(64, nh)], ch - fh, int(cw / 2 - fw / 2), batch=B)
+    th0 = time.perf_counter()
+    sth = ctx2.process_host_video(host_frames[0], host_frames[1:], ch - fh, int(cw / 2 - fw / 2), batch=B)
+    th = time.perf_counter() - th0
+    leg = {"value": nh / th, "unit": "frames/s", "frames": nh, "frames_not_ok": int((sth != 0).sum()),
+           "note": "Context.process_host_video: host frames -> pinned ring -> device, batches of %d; "
+                   "one memcpy per frame into the pinned slot (4 threads) and the PCIe copy included" % B}
+    ctx2.close()
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +348,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--config", default="720p_orb1000", choices=sorted(CONFIGS))
     ap.add_argument("--warp-mode", default="float", choices=["float", "fixed"])
-    ap.add_argument("--batch", type=int, default=32, help="frames per rtvm_process_batch call (1..32)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per detection batch (1..32)")
     ap.add_argument("--single-stream", action="store_true", help="queue every batch on one HIP stream")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--path", default="bounded", choices=["bounded", "drift"],
@@ -131,28 +360,45 @@ def main():
                     help="frames of the video also run from host memory through the ingest ring (0 = skip)")
     ap.add_argument("--sift-frames", type=int, default=144,
                     help="frames of the PCIe-inclusive sample through VideMosaic with the SIFT detector (0 = skip)")
-    ap.add_argument("--dropin-frames", type=int, default=544,
+    ap.add_argument("--dropin-frames", type=int, default=1056,
                     help="frames of the PCIe-inclusive sample through the Python VideMosaic class (0 = skip)")
+    ap.add_argument("--procs", type=int, default=1,
+                    help="start this many independent processes (own context and video) on ONE GPU and report the aggregate")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel timing table to this JSON file")
     args = ap.parse_args()
+
+    if args.procs > 1:
+        return run_procs(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    same_gpu = os.environ.get("RTVM_BENCH_SAME_GPU") == "1"   # children of --procs
+    if world != args.gpus and not same_gpu:
         if rank == 0 and world > 1:
             print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if same_gpu:
+            dist.init_process_group(backend="gloo")
+            red_dev = None
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     cfg = CONFIGS[args.config]
     fh, fw, ch, cw, nf = cfg
+    if args.config == "1080p_sift2000_l2":
+        out = bench_sift_l2(args, cfg, dev, local_rank)
+        if rank == 0:
+            print(json.dumps(out))
+        return
     K, W = args.steps, args.warmup
-    T = 1 + W + K
+    # the host-frame legs may use more frames than the timed region
+    T = 1 + max(W + K, args.dropin_frames if world == 1 else 0, args.host_frames if world == 1 else 0)
     # --- synthetic video, seeded per rank (independent streams), resident in HBM
     # the camera path stays inside the canvas for any number of frames, so that every frame of the
     # timed region is warped and blended in full
@@ -184,34 +430,26 @@ def main():
                                canvas_batch=args.canvas_batch)
         return st, dict(ctx.video_stats)
 
-    ctx.stream_begin(base, row_off, col_off)
-    run(1, W)
-    ctx.sync()
-    # --- un-timed pass over a few frames with every kernel timed: finds the dominant kernel
-    probe = min(B, K)
-    ctx.profile_start(None)
-    run(1 + W, probe)
-    table = ctx.profile_stop()
-    # The canvas half (main stream) bounds the throughput; detection + matching and RANSAC of
-    # the following batches run beside it on streams of their own.  The roofline is that of
-    # the main stream's longest kernel; the longest kernel of all is reported next to it.
-    main_stream = {k: v for k, v in table.items() if v[2] == 0 or args.single_stream}
-    # Kernels within 5 % of the longest are a tie on a one-batch probe (k_dt_cols and k_warp differ
-    # by about 1 %): among those the one that moves the most bytes is taken, so that the choice
-    # does not flip from run to run and the HBM roofline is quoted for a kernel it can bound.
-    top_ms = max(v[1] for v in main_stream.values())
-    fh_, fw_, ch_, cw_, nf_ = cfg
-    roi_ = min(ch_ * cw_, (fh_ + 8) * (fw_ + 8))
-    tied = [k for k, v in main_stream.items() if v[1] >= 0.95 * top_ms]
-    dominant = max(tied, key=lambda k: (algorithmic_bytes(k, fh_, fw_, ch_, cw_, nf_, roi_, B) or 0, main_stream[k][1]))
-    tied_with = {k: {"us_per_frame": main_stream[k][1] * 1e3 / probe} for k in tied if k != dominant}
-    longest = max(table, key=lambda k: table[k][1])
-    # restart the stream so that the timed region is exactly frames 1+W .. W+K after W warm-up frames
-    ctx.stream_begin(base, row_off, col_off)
-    run(1, W)
-    ctx.sync()
+    def restart():
+        ctx.stream_begin(base, row_off, col_off)
+        run(1, W)
+        ctx.sync()
 
-    # --- timed region: K frames; only the dominant kernel carries HIP events
+    # --- pass 1, not timed for the headline: the same K frames with every kernel carrying HIP events.
+    # The canvas half (main stream) bounds the throughput; detection + matching and RANSAC of the following
+    # batches run beside it on streams of their own.  The roofline kernel is the main-stream kernel with the
+    # largest summed time over these K frames; the longest kernel of any stream is named next to it.
+    restart()
+    ctx.profile_start(None)
+    _, vstats1 = run(1 + W, K)
+    table = ctx.profile_stop()
+    main_stream = {k: v for k, v in table.items() if v[2] == 0 or args.single_stream}
+    dominant = max(main_stream, key=lambda k: main_stream[k][1])
+    longest = max(table, key=lambda k: table[k][1])
+
+    # --- pass 2, the timed region: exactly frames 1+W .. W+K after W warm-up frames; only the dominant kernel
+    # carries HIP events (on the stream it is launched on)
+    restart()
     ctx.profile_start(dominant)
     if world > 1:
         dist.barrier()
@@ -219,14 +457,15 @@ def main():
     ctx.sync()
     t0 = time.perf_counter()
     statuses, vstats = run(1 + W, K)
-    t_enq = time.perf_counter()
     ctx.sync()
     torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
     dom = ctx.profile_stop()[dominant]
-    elapsed = max_over_ranks(t1 - t0, world, dev)
+    elapsed = max_over_ranks(t1 - t0, world, red_dev)
+    rates = per_rank_rates(K, t_own, world, red_dev)
     st, nk, nm, H = ctx.frame_status()
     n_bad = int(np.count_nonzero(statuses & 11))
     if n_bad:
@@ -241,152 +480,95 @@ def main():
         # frames that went through the canvas-half kernels: those of the pieces that were not void,
         # plus the ones whose canvas half was queued again
         K_back = vstats["canvas_frames"] - vstats["frames_void"] + vstats["frames_retried"]
-        ab = ab_frame * K_back / launches if ab_frame else None   # mean per launch
-        # HBM traffic of the same kernel from the PMC counters of a separate rocprofv3 run (committed
-        # summary; the counters cannot be read from inside this process)
-        traffic, traffic_note = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fjs:
-                pmc = json.load(fjs)
-            ent = pmc["kernels"].get(dominant)
-            if ent and args.config == "720p_orb1000":
-                traffic = ent["hbm_bytes"] * (K_back / launches) / pmc["frames_per_launch"]
-                traffic_note = ("2*FETCH_SIZE + WRITE_SIZE of profiles/r1_pmc_traffic.json, scaled from %d to %.1f frames "
-                                "per launch" % (pmc["frames_per_launch"], K_back / launches))
-        except (OSError, KeyError, ValueError):
-            pass
+        fpl = K_back / launches
+        ab = ab_frame * fpl if ab_frame else None   # mean per launch
+        traffic_frame, traffic_note = pmc_traffic(dominant, args.config)
+        K1 = vstats1["canvas_frames"] - vstats1["frames_void"] + vstats1["frames_retried"]
+        by_time = sorted(main_stream, key=lambda k: -main_stream[k][1])
         roof = {"kernel": dominant, "bound": "hbm", "launches": launches, "avg_us": avg_s * 1e6,
-                "achieved": (ab / avg_s / 1e9) if ab else None, "peak": 8000.0, "unit": "GB/s",
-                "frac": (ab / avg_s / 1e9 / 8000.0) if ab else None,
-                "frac_of_measured_copy_peak": (ab / avg_s / 1e9 / 6290.0) if ab else None, "algorithmic_bytes": ab,
-                "algorithmic_bytes_per_frame": ab_frame, "frames_per_launch": K_back / launches, "traffic": traffic, "traffic_note": traffic_note,
-                "stream": "main (canvas half): the stream that bounds the frame rate",
-                "probe_us_per_frame": main_stream[dominant][1] * 1e3 / probe, "tied_within_5_percent": tied_with,
-                "longest_kernel_any_stream": {"kernel": longest, "us_per_frame": table[longest][1] * 1e3 / probe,
+                "achieved": (ab / avg_s / 1e9) if ab else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (ab / avg_s / 1e9 / HBM_PEAK_GBS) if ab else None,
+                "frac_of_measured_copy_peak": (ab / avg_s / 1e9 / HBM_COPY_GBS) if ab else None, "algorithmic_bytes": ab,
+                "algorithmic_bytes_per_frame": ab_frame, "frames_per_launch": fpl,
+                "traffic": traffic_frame * fpl if traffic_frame else None,
+                "traffic_bytes_per_frame": traffic_frame, "traffic_note": traffic_note,
+                "chosen_as": "main-stream (canvas half) kernel with the largest summed HIP-event time over the K frames "
+                             "of the instrumented pass; avg_us is from the timed pass",
+                "main_stream_us_per_frame": {k: main_stream[k][1] * 1e3 / K1 for k in by_time[:6]},
+                "longest_kernel_any_stream": {"kernel": longest, "us_per_frame": table[longest][1] * 1e3 / K,
                                               "stream": ["main", "detect+match", "ransac search", "ransac polish"][table[longest][2]]}}
-        # the warp + blend stage as a whole (everything on the main stream), from the un-timed probe batch:
-        # frame read once, canvas ROI read + written once, the reference's two full-canvas distance transforms
-        # (mask read + f32 distance written) and the two 31x31 blurs (f32 read + write per pass)
-        P_px, C_px = fh * fw, ch * cw
-        wb_bytes = 3 * P_px + 6 * roi_px + 2 * 5 * C_px + 16 * roi_px
-        wb_us = sum(v[1] for v in table.values() if v[2] == 0 or args.single_stream) * 1e3 / probe
+        # the warp + blend stage as a whole (everything on the main stream) over the K frames of the instrumented pass
+        wb_bytes = warp_blend_stage_bytes(fh, fw, ch, cw, roi_px)
+        wb_us = sum(v[1] for v in main_stream.values()) * 1e3 / K1
         warp_blend = {"algorithmic_bytes_per_frame": wb_bytes, "us_per_frame": wb_us,
-                      "achieved": wb_bytes / wb_us / 1e3, "unit": "GB/s", "frac": wb_bytes / wb_us / 1e3 / 8000.0,
-                      "note": "sum of the main-stream kernels of one full batch (HIP events, un-timed probe)"}
-        dropin = None
-        if args.dropin_frames > 0 and world == 1:
-            # The drop-in class as the reference's main loop drives it (main.py:1596-1634): one host frame per
-            # process_frame call, PCIe copies included.  Headless (both display flags off, what main.py --hide
-            # passes) process_frame only takes the frame and the work follows in batches; the clock stops after
-            # flush() + a device sync, i.e. with every frame stitched.
-            nd = min(args.dropin_frames, T - 1)
-            n_warm = min(32, nd // 4)
-            host_frames = frames[:nd + 1].cpu().numpy()
-            kw = dict(detector_type="orb", nfeatures=nf, canvas_size=(ch, cw), device=local_rank,
-                      warp_mode=args.warp_mode)
-            vm = rtvm.VideMosaic(host_frames[0], show_intermediate=False, visualize=False, **kw)
-            for t in range(1, n_warm + 1):
-                vm.process_frame(host_frames[t], t)
-            vm.flush()
-            vm._ctx.sync()
-            td0 = time.perf_counter()
-            for t in range(n_warm + 1, nd + 1):
-                vm.process_frame(host_frames[t], t)
-            vm.flush()
-            vm._ctx.sync()
-            td = time.perf_counter() - td0
-            dropin = {"value": (nd - n_warm) / td, "unit": "frames/s", "frames": nd - n_warm,
-                      "pipeline": dict(vm._pipe.stats),
-                      "note": "Python VideMosaic.process_frame, headless, one host frame per call: copy into the pinned "
-                              "ring, PCIe copy, batched detection, host-side validate/smooth/chain, batched warp + blend"}
-            vm.close()
-            # the same class with a display flag set: every call completes before it returns
-            ns = min(136, nd)
-            vm = rtvm.VideMosaic(host_frames[0], show_intermediate=True, visualize=False, **kw)
-            vm.process_frame(host_frames[1], 1)
-            td0 = time.perf_counter()
-            for t in range(2, ns + 1):
-                vm.process_frame(host_frames[t], t)
-            vm._ctx.sync()
-            dropin["process_frame_synchronous"] = {"value": (ns - 1) / (time.perf_counter() - td0), "frames": ns - 1}
-            vm.close()
-            if ns >= 16:
-                # ... and through process_frames: detection, matching and RANSAC on four worker threads
-                vm = rtvm.VideMosaic(host_frames[0], show_intermediate=True, visualize=False, **kw)
-                vm.process_frames(list(host_frames[1:9]), 1, workers=4)
-                td0 = time.perf_counter()
-                vm.process_frames(list(host_frames[9:ns + 1]), 9, workers=4)
-                vm.output_img_u8()
-                dropin["process_frames_4_workers"] = {"value": (ns - 8) / (time.perf_counter() - td0), "frames": ns - 8}
-                vm.close()
-        sift_leg = None
-        if args.sift_frames > 0 and world == 1:
-            # the reference's default detector (main.py:1603 passes "sift"): the drop-in class frame by frame,
-            # and process_frames with detection, matching and RANSAC on worker threads
-            ns = min(args.sift_frames, T - 1)
-            host_frames = list(frames[:ns + 1].cpu().numpy())
-            vm = rtvm.VideMosaic(host_frames[0], detector_type="sift", nfeatures=700, canvas_size=(ch, cw),
-                                 device=local_rank, warp_mode=args.warp_mode, show_intermediate=False, visualize=False)
-            n1 = min(16, ns)
-            ts0 = time.perf_counter()
-            for t, f in enumerate(host_frames[1:1 + n1], 1):
-                vm.process_frame(f, t)
-            ts1 = time.perf_counter()
-            vm.process_frames(host_frames[1 + n1:], 1 + n1, workers=4)
-            vm.output_img_u8()
-            ts2 = time.perf_counter()
-            sift_leg = {"process_frame": {"value": n1 / (ts1 - ts0), "frames": n1},
-                        "process_frames_4_workers": {"value": (ns - n1) / (ts2 - ts1), "frames": ns - n1} if ns > n1 else None,
-                        "unit": "frames/s", "nfeatures": 700,
-                        "note": "VideMosaic(detector_type='sift') with host frames, PCIe copies included"}
-            vm.close()
-        host_ingest = None
-        if args.host_frames > 0 and world == 1:
-            # frames in host memory through the ingest ring (pinned slots, copies on a stream of their own)
-            # into the same batched pipeline: the PCIe-inclusive rate of the throughput path
-            nh = min(args.host_frames, T - 1)
-            host_frames = frames[:nh + 1].cpu().numpy()
-            ctx2 = rtvm.Context(fh, fw, ch, cw, nfeatures=nf,
-                                flags=(rtvm._ffi.FLAG_WARP_FIXED if args.warp_mode == "fixed" else 0), device=local_rank)
-            ctx2.process_host_video(host_frames[0], host_frames[1:1 + min(64, nh)], ch - fh, int(cw / 2 - fw / 2), batch=B)
-            th0 = time.perf_counter()
-            sth = ctx2.process_host_video(host_frames[0], host_frames[1:], ch - fh, int(cw / 2 - fw / 2), batch=B)
-            th = time.perf_counter() - th0
-            host_ingest = {"value": nh / th, "unit": "frames/s", "frames": nh, "frames_not_ok": int((sth != 0).sum()),
-                           "note": "Context.process_host_video: host frames -> pinned ring -> device, batches of %d; "
-                                   "one memcpy per frame into the pinned slot (4 threads) and the PCIe copy included" % B}
-            ctx2.close()
-        cpu = None
-        if args.cpu_frames > 0 and world == 1:   # reported at N = 1 only
-            frames_np = frames[:args.cpu_frames + 1].cpu().numpy()
-            fps_cpu, _ = cpu_baseline(frames_np, cfg, args.cpu_frames)
+                      "achieved": wb_bytes / wb_us / 1e3, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                      "frac": wb_bytes / wb_us / 1e3 / HBM_PEAK_GBS,
+                      "note": "warp GB/s vs the HBM roofline: bytes of the reference's data flow (frame, canvas region, "
+                              "two canvas-sized distance transforms, two separable blurs) over the summed HIP-event "
+                              "time of all main-stream kernels, K frames of the instrumented pass"}
+        extras = {}
+        solo = world == 1
+        if args.dropin_frames > 0 and solo:
+            extras["dropin_pcie_inclusive"] = leg_dropin(args, cfg, frames, local_rank, T)
+        if args.sift_frames > 0 and solo:
+            extras["sift_dropin_pcie_inclusive"] = leg_sift(args, cfg, frames, local_rank, T)
+        if args.host_frames > 0 and solo:
+            extras["host_frames_pcie_inclusive"] = leg_host_ring(args, cfg, frames, local_rank, T, B)
+        cpu, cpu_all, parity = None, None, None
+        if args.cpu_frames > 0 and solo:   # reported at N = 1 only
+            orc, _ = oracle_modules()
+            n1 = args.cpu_frames
+            frames_np = frames[:2 * n1 + 1].cpu().numpy()
+            fps_cpu, om = cpu_baseline(frames_np, cfg, n1, 1)
             cpu = {"value": fps_cpu, "unit": "frames/s", "cores": 1, "kind": "port",
                    "sample": "first %d frames of the same synthetic video through the oracle/ C++ restatement, "
-                             "one thread" % args.cpu_frames}
+                             "one thread" % n1}
+            # the same frames through the GPU path: the mosaic must be the oracle's, pixel for pixel
+            ctx.stream_begin(base, row_off, col_off)
+            st_p, _ = run(1, n1)
+            _, _, _, H_p = ctx.frame_status()
+            canvas_p = ctx.canvas_read()
+            parity = {"frames": n1, "canvas_equal": bool(np.array_equal(canvas_p, om.canvas)),
+                      "homography_equal": bool(np.array_equal(H_p, om.H)),
+                      "statuses_equal": bool(st_p.tolist() == [0] * n1 and om.status == 0)}
+            threads = orc.default_threads()
+            n2 = min(2 * n1, len(frames_np) - 1)
+            fps_all, _ = cpu_baseline(frames_np, cfg, n2, threads)
+            cpu_all = {"value": fps_all, "unit": "frames/s", "cores": threads, "kind": "port",
+                       "host_cpus": os.cpu_count(),
+                       "sample": "first %d frames, the restatement's per-pixel / per-row / per-descriptor loops on "
+                                 "%d OpenMP threads (the box's CPU share; same results as one thread)" % (n2, threads)}
         out = {
             "metric": "stitched frames/sec @720p ORB-1000 on 1xMI355X; warp GB/s vs HBM roofline",
-            "value": world * K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": world * K / elapsed, "unit": "frames/s", "n_gpus": 1 if same_gpu else world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.config, "camera_path": args.path, "frame": [fh, fw], "canvas": [ch, cw], "nfeatures": nf,
                        "warp_mode": args.warp_mode, "batch": B, "hip_streams": 1 if args.single_stream else 4,
-                       "streams": world, "parallelism": "one stream per GPU",
+                       "streams": world, "parallelism": "one stream per GPU" if not same_gpu else "%d processes on one GPU" % world,
                        "last_frame": {"status": st, "keypoints": nk, "matches": nm},
                        "frames_queued": vstats["frames_queued"], "batches_queued": vstats["batches_queued"],
                        "batches_with_pending_frames": vstats["batches_with_pending_frames"],
                        "canvas_half_retries": vstats["retries"], "frames_retried": vstats["frames_retried"],
                        "frames_void": vstats["frames_void"], "canvas_pieces": vstats["canvas_pieces"],
                        "canvas_batch": args.canvas_batch or (B + 1) // 2},
-            "roofline": roof, "warp_blend_stage": warp_blend, "cpu_baseline": cpu, "dropin_pcie_inclusive": dropin,
-            "host_frames_pcie_inclusive": host_ingest, "sift_dropin_pcie_inclusive": sift_leg,
+            "roofline": roof, "warp_blend_stage": warp_blend, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
+            "parity_checked": bool(all(v for k, v in parity.items() if k != "frames")) if parity else None,
+            "parity": parity,
         }
+        if world > 1:
+            out["per_process_frames_per_s"] = rates
+        if same_gpu:
+            out["procs"] = world
+        out.update(extras)
         if args.kernel_table:
             rows = {k: {"launches": v[0], "total_ms": v[1], "avg_us": v[1] / v[0] * 1e3, "stream": v[2],
+                        "us_per_frame": v[1] * 1e3 / (K1 if v[2] == 0 else K),
                         "algorithmic_bytes_per_frame": algorithmic_bytes(k, fh, fw, ch, cw, nf, roi_px, B)}
                     for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])}
             os.makedirs(os.path.dirname(os.path.abspath(args.kernel_table)), exist_ok=True)
             with open(args.kernel_table, "w") as f:
-                json.dump({"frames": probe, "kernels": rows}, f, indent=1)
+                json.dump({"frames": K, "canvas_half_frames": K1, "kernels": rows}, f, indent=1)
         print(json.dumps(out))
     ctx.close()
     if world > 1:
