@@ -42,7 +42,14 @@ enum {
 };
 
 /* rtvm_create: detector */
-enum { RTVM_DET_ORB = 0, RTVM_DET_SIFT_MATCH_ONLY = 1 };
+enum {
+    RTVM_DET_ORB = 0,             /* ORB_create(n) + BFMatcher(NORM_HAMMING, crossCheck=True)  main.py:35-37 */
+    RTVM_DET_SIFT_MATCH_ONLY = 1, /* stage calls of the SIFT branch only (rtvm_sift, rtvm_match_l2_knn2, ...) */
+    RTVM_DET_SIFT = 2             /* SIFT_create(n) + BFMatcher() knn-2 + ratio 0.7  main.py:32-34, 688-692: the
+                                     stream path (rtvm_first_frame, rtvm_stream_begin, rtvm_process_*, rtvm_batch_*)
+                                     detects, matches and fits with the reference's default detector; features are
+                                     128 floats per keypoint and match distances are floats */
+};
 
 /* rtvm_create: flags */
 enum {
@@ -386,10 +393,11 @@ int rtvm_stream_set_prev(rtvm_ctx* ctx, const uint8_t* bgr);
  * other reading calls wait for it. */
 int rtvm_frame_commit(rtvm_ctx* ctx, const double H[9]);
 /* kp_cur/des_cur (slot 0) or kp_prev/des_prev (slot 1) of the stream; any output may
- * be NULL; capacity rtvm_max_keypoints(). */
+ * be NULL; capacity rtvm_max_keypoints().  desc: n*32 u8 (ORB) or n*128 f32 (RTVM_DET_SIFT). */
 int rtvm_get_features(rtvm_ctx* ctx, int slot, int* n_out, float* xy, float* size, float* angle_deg,
                       float* response, int32_t* octave, uint8_t* desc);
-/* self.matches of the most recent frame (sorted by distance); capacity rtvm_max_keypoints(). */
+/* self.matches of the most recent frame (sorted by distance); capacity rtvm_max_keypoints().
+ * dist: Hamming distances as i32 (ORB) or the bit patterns of the f32 L2 distances (RTVM_DET_SIFT). */
 int rtvm_get_matches(rtvm_ctx* ctx, int* m_out, int32_t* qidx, int32_t* tidx, int32_t* dist);
 
 /* ---- measurement aid (no counterpart in the reference) ----------------------- */

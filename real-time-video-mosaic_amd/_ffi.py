@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librtvm.so")
 
 OK = 0
 E_ARG, E_HIP, E_NOMEM, E_DEGENERATE, E_STATE = -1, -2, -3, -4, -5
-DET_ORB, DET_SIFT_MATCH_ONLY = 0, 1
+DET_ORB, DET_SIFT_MATCH_ONLY, DET_SIFT = 0, 1, 2
 FLAG_WARP_FIXED = 1
 FLAG_SINGLE_STREAM = 4
 FRAME_FEW_MATCHES, FRAME_NO_HOMOGRAPHY, FRAME_INVALID_H = 1, 2, 4
@@ -246,6 +246,7 @@ class Context:
         self.canvas_h, self.canvas_w = canvas_h, canvas_w
         self.nfeatures = nfeatures
         self.device = device
+        self.detector = detector
 
     def close(self):
         if getattr(self, "_h", None):
@@ -488,6 +489,15 @@ class Context:
         H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
         self._check(lib().rtvm_frame_commit(self._h, ptr(H)))
 
+    def _desc_buffer(self, cap):
+        """Descriptor array of the stream path: 32 bytes per keypoint (ORB) or 128 floats (DET_SIFT)."""
+        return np.empty((cap, 128), np.float32) if self.detector == DET_SIFT else np.empty((cap, 32), np.uint8)
+
+    def _distances(self, di):
+        """Match distances as the reference's DMatch carries them: Hamming counts, or float L2 distances (DET_SIFT:
+        the library hands over their bit patterns)."""
+        return di.view(np.float32) if self.detector == DET_SIFT else di
+
     def get_features(self, slot):
         cap = max(self.max_keypoints(), 1)
         n = C.c_int(0)
@@ -496,7 +506,7 @@ class Context:
         angle = np.empty(cap, np.float32)
         resp = np.empty(cap, np.float32)
         octave = np.empty(cap, np.int32)
-        desc = np.empty((cap, 32), np.uint8)
+        desc = self._desc_buffer(cap)
         self._check(lib().rtvm_get_features(self._h, int(slot), C.byref(n), ptr(xy), ptr(size), ptr(angle),
                                             ptr(resp), ptr(octave), ptr(desc)))
         k = n.value
@@ -511,7 +521,7 @@ class Context:
         di = np.empty(cap, np.int32)
         self._check(lib().rtvm_get_matches(self._h, C.byref(m), ptr(qi), ptr(ti), ptr(di)))
         k = m.value
-        return qi[:k].copy(), ti[:k].copy(), di[:k].copy()
+        return qi[:k].copy(), ti[:k].copy(), self._distances(di[:k].copy())
 
     # ---- per-kernel timing ----------------------------------------------------
     def profile_start(self, name_filter=None):
@@ -626,7 +636,7 @@ class Context:
         angle = np.empty(cap, np.float32)
         resp = np.empty(cap, np.float32)
         octave = np.empty(cap, np.int32)
-        desc = np.empty((cap, 32), np.uint8)
+        desc = self._desc_buffer(cap)
         self._check(lib().rtvm_batch_get_features(self._h, ticket, int(index), C.byref(n), ptr(xy), ptr(size), ptr(angle),
                                                   ptr(resp), ptr(octave), ptr(desc)))
         k = n.value
@@ -641,7 +651,7 @@ class Context:
         di = np.empty(cap, np.int32)
         self._check(lib().rtvm_batch_get_matches(self._h, ticket, int(index), C.byref(m), ptr(qi), ptr(ti), ptr(di)))
         k = m.value
-        return qi[:k].copy(), ti[:k].copy(), di[:k].copy()
+        return qi[:k].copy(), ti[:k].copy(), self._distances(di[:k].copy())
 
     def _stitch_rest(self, ticket, start, k, first, status, stats, trace=None):
         """Frames first .. k-1 of the detected batch `ticket` (video frames start+first ..) came back

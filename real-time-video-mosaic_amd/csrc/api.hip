@@ -23,7 +23,7 @@ int dev_alloc(rtvm_ctx* c, T** p, size_t n) {
         if (r_ != RTVM_OK) return r_;                         \
     } while (0)
 
-int alloc_feat(rtvm_ctx* c, FeatSet* f, int n) {
+int alloc_feat(rtvm_ctx* c, FeatSet* f, int n, int desc_bytes) {
     int r;
     if ((r = dev_alloc(c, &f->xy, (size_t)n * 2))) return r;
     if ((r = dev_alloc(c, &f->size, n))) return r;
@@ -31,7 +31,7 @@ int alloc_feat(rtvm_ctx* c, FeatSet* f, int n) {
     if ((r = dev_alloc(c, &f->response, n))) return r;
     if ((r = dev_alloc(c, &f->octave, n))) return r;
     if ((r = dev_alloc(c, &f->lxy, (size_t)n * 2))) return r;
-    if ((r = dev_alloc(c, &f->desc, (size_t)n * 32))) return r;
+    if ((r = dev_alloc(c, &f->desc, (size_t)n * desc_bytes))) return r;
     if ((r = dev_alloc(c, &f->count, 4))) return r;
     return RTVM_OK;
 }
@@ -55,8 +55,23 @@ struct Carver {
     }
 };
 
-void carve_slot(rtvm_ctx* c, Carver& k, FrameSlot& S, int cap, int with_orb) {
-    if (with_orb) {
+void carve_slot(rtvm_ctx* c, Carver& k, FrameSlot& S, int cap, int kind) {
+    if (kind == 2) {  // SIFT: features with 128-float descriptors, the L2 matcher's work area
+        S.feat.xy = k.take<float>((size_t)cap * 2);
+        S.feat.size = k.take<float>(cap);
+        S.feat.angle = k.take<float>(cap);
+        S.feat.response = k.take<float>(cap);
+        S.feat.octave = k.take<int32_t>(cap);
+        S.feat.desc = k.take<uint8_t>((size_t)cap * 512);
+        S.feat.count = k.take<int>(4);
+        const size_t pad = ((size_t)cap + 127) / 128 * 128;
+        S.l2_qb = k.take<uint4>(pad * 16);
+        S.l2_tb = k.take<uint4>(pad * 16);
+        S.l2_qn = k.take<float>(pad);
+        S.l2_tn = k.take<float>(pad);
+        S.l2_part = k.take<uint32_t>((pad / 128) * pad * 2);
+    }
+    if (kind == 1) {
         S.pyr = k.take<uint8_t>(c->orb_pyr_bytes);
         S.pyr_blur = k.take<uint8_t>(c->orb_pyr_bytes);
         S.score = k.take<uint8_t>(c->orb_pyr_bytes);
@@ -98,11 +113,11 @@ void carve_slot(rtvm_ctx* c, Carver& k, FrameSlot& S, int cap, int with_orb) {
 
 // Allocates the buffers of one frame slot (one device allocation) and publishes the
 // slot to the device copy of the slot array.
-int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int with_orb) {
+int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int kind) {
     FrameSlot& S = c->h_slots[slot];
     memset(&S, 0, sizeof(S));
     Carver dry{nullptr, 0};
-    carve_slot(c, dry, S, cap_kp, with_orb);
+    carve_slot(c, dry, S, cap_kp, kind);
     const size_t bytes = dry.off + 256;
     void* arena = nullptr;
     hipError_t e = hipMalloc(&arena, bytes);
@@ -111,7 +126,7 @@ int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int with_orb) {
     HIP_TRY(c, hipMemset(arena, 0, bytes));
     Carver k{(char*)arena, 0};
     memset(&S, 0, sizeof(S));
-    carve_slot(c, k, S, cap_kp, with_orb);
+    carve_slot(c, k, S, cap_kp, kind);
     if (slot == RTVM_STAGE_SLOT) {  // host-buffer matcher: descriptors come from the staging buffers
         S.feat.desc = c->d_mq;
         S.feat.count = c->d_mcount;
@@ -283,13 +298,23 @@ int alloc_all(rtvm_ctx* c) {
     // stage slot (host-buffer matcher / RANSAC entry points)
     if ((r = rtvm_slots_alloc(c, RTVM_STAGE_SLOT, mk, 0))) return r;
     // ORB + stream
-    if (c->fh > 0 && c->fw > 0) {
+    c->desc_bytes = 32;
+    if (c->fh > 0 && c->fw > 0 && c->detector == RTVM_DET_SIFT) {
+        // the stream path with the reference's default detector
+        c->desc_bytes = 512;
+        c->orb.max_kp = rtvm_sift_max_keypoints(c->nfeatures);  // the bound every feature array is sized with
+        if ((r = rtvm_sift_pipe_create(c))) return r;
+        if ((r = alloc_feat(c, &c->feat_prev, c->orb.max_kp, 512))) return r;
+        if ((r = rtvm_slots_alloc(c, 0, c->orb.max_kp, 2))) return r;
+        c->n_batch = 1;
+        if ((r = rtvm_sift_pipe_reserve(c, 1))) return r;
+    } else if (c->fh > 0 && c->fw > 0) {
         if ((r = rtvm_orb_plan(c))) return r;
         ALLOC(c, d_xofs, c->orb_xtab_total + 1);
         ALLOC(c, d_xw, c->orb_xtab_total + 1);
         ALLOC(c, d_yofs, c->orb_ytab_total + 1);
         ALLOC(c, d_yw, c->orb_ytab_total + 1);
-        if ((r = alloc_feat(c, &c->feat_prev, c->orb.max_kp))) return r;
+        if ((r = alloc_feat(c, &c->feat_prev, c->orb.max_kp, 32))) return r;
         if ((r = rtvm_slots_alloc(c, 0, c->orb.max_kp, 1))) return r;
         c->n_batch = 1;
         if ((r = rtvm_orb_setup(c))) return r;
@@ -303,6 +328,7 @@ int alloc_all(rtvm_ctx* c) {
 }
 
 void free_all(rtvm_ctx* c) {
+    rtvm_sift_pipe_free(c);
     for (int i = 0; i < 8; i++) {
         if (c->sift_buf[i]) (void)hipFree(c->sift_buf[i]);
         c->sift_buf[i] = nullptr;
@@ -362,6 +388,8 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
     if (!out) return RTVM_E_ARG;
     *out = nullptr;
     if (frame_h < 0 || frame_w < 0 || canvas_h < 0 || canvas_w < 0 || nfeatures < 0) return RTVM_E_ARG;
+    if (detector != RTVM_DET_ORB && detector != RTVM_DET_SIFT_MATCH_ONLY && detector != RTVM_DET_SIFT) return RTVM_E_ARG;
+    if (detector == RTVM_DET_SIFT && frame_h > 0 && (nfeatures < 1 || nfeatures > RTVM_SIFT_STREAM_MAX_KP - 256)) return RTVM_E_ARG;
     // the warp reads the two taps of a row with one 8-byte load that must fit inside the frame
     if ((frame_h > 0 || frame_w > 0) && (frame_h < 2 || frame_w < 2)) return RTVM_E_ARG;
     int ndev = 0;
@@ -524,8 +552,10 @@ extern "C" int rtvm_match_l2_knn2(rtvm_ctx* c, const float* q, int nq, const flo
 // ---- gray / ORB ---------------------------------------------------------------
 extern "C" int rtvm_max_keypoints(const rtvm_ctx* c) { return c ? c->orb.max_kp : 0; }
 
-static int need_frame(rtvm_ctx* c, const char* who) {
+static int need_frame(rtvm_ctx* c, const char* who, bool orb_only = true) {
     if (c->fh <= 0 || c->fw <= 0) RTVM_FAIL(c, RTVM_E_STATE, "%s: context was created without a frame size", who);
+    if (orb_only && c->detector == RTVM_DET_SIFT)
+        RTVM_FAIL(c, RTVM_E_STATE, "%s: the context was created with the SIFT detector", who);
     return RTVM_OK;
 }
 
@@ -554,12 +584,14 @@ extern "C" int rtvm_gray(rtvm_ctx* c, const uint8_t* bgr, uint8_t* gray) {
 extern "C" int rtvm_reserve_batch(rtvm_ctx* c, int n) {
     if (!c) return RTVM_E_ARG;
     if (n < 1 || n > RTVM_MAX_BATCH) RTVM_FAIL(c, RTVM_E_ARG, "reserve_batch: batch size must be 1..%d", RTVM_MAX_BATCH);
-    int r = need_frame(c, "reserve_batch");
+    int r = need_frame(c, "reserve_batch", false);
     if (r) return r;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int kind = c->detector == RTVM_DET_SIFT ? 2 : 1;
+    if (kind == 2 && (r = rtvm_sift_pipe_reserve(c, n))) return r;
     for (int s = c->n_batch; s < n; s++) {
-        if ((r = rtvm_slots_alloc(c, s, c->orb.max_kp, 1))) return r;
+        if ((r = rtvm_slots_alloc(c, s, c->orb.max_kp, kind))) return r;
         c->n_batch = s + 1;
     }
     for (int s = c->n_side; s < n; s++) {
@@ -568,7 +600,7 @@ extern "C" int rtvm_reserve_batch(rtvm_ctx* c, int n) {
     }
     for (int s = c->n_set1; s < n; s++) {
         for (int k = 1; k < RTVM_NSETS; k++)
-            if ((r = rtvm_slots_alloc(c, k * RTVM_MAX_BATCH + s, c->orb.max_kp, 1))) return r;
+            if ((r = rtvm_slots_alloc(c, k * RTVM_MAX_BATCH + s, c->orb.max_kp, kind))) return r;
         c->n_set1 = s + 1;
     }
     return RTVM_OK;

@@ -10,6 +10,7 @@
 #define RTVM_NLEVELS 8
 #define RTVM_MAX_MATCH 16384   // keypoints per side the Hamming matcher (sorted form) accepts
 #define RTVM_RANSAC_MAX_ITERS 2000
+#define RTVM_SIFT_STREAM_MAX_KP 8192   // keypoints per frame the stream path holds with the SIFT detector
 
 // ---------------------------------------------------------------------------
 // ORB geometry and tables, passed to the kernels by value.
@@ -75,6 +76,13 @@ struct FrameSlot {
     double* rs_H;          // 9 doubles
     uint8_t* rs_mask;
     int* rs_found;
+    // L2 matcher work area (contexts with the SIFT detector): both descriptor sets as bf16 in
+    // matrix-core operand order, their squared norms, per-tile top-2 keys
+    uint4* l2_qb;
+    uint4* l2_tb;
+    float* l2_qn;
+    float* l2_tn;
+    uint32_t* l2_part;
 };
 
 #define RTVM_MAX_BATCH 32
@@ -271,6 +279,8 @@ struct rtvm_ctx {
     double* d_commit_H;        // device view of h_commit_H
     int fh, fw, ch, cw;
     int detector, nfeatures, flags;
+    int desc_bytes;            // bytes of one descriptor of the stream path: 32 (ORB) or 512 (SIFT)
+    void* sift_pipe;           // SIFT detection for the frames of a batch (sift.hip)
     char err[512];
 
     // --- ORB ---
@@ -384,9 +394,17 @@ int rtvm_launch_warp_blend(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H)
 int rtvm_orb_plan(rtvm_ctx* c);   // host-side geometry (before allocation)
 int rtvm_orb_setup(rtvm_ctx* c);  // uploads tables (after allocation)
 int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb);
+// sift.hip: the same for contexts with the SIFT detector (features into slot.feat; desc = 128 floats)
+int rtvm_sift_pipe_create(rtvm_ctx* c);          // geometry (before the slots are allocated)
+int rtvm_sift_pipe_reserve(rtvm_ctx* c, int n);  // pyramids and lists for batches of up to n frames
+void rtvm_sift_pipe_free(rtvm_ctx* c);
+int rtvm_launch_sift(rtvm_ctx* c, int sb, int nb);
+// l2match.hip: knn-2 + ratio test + sort by distance (main.py:688-698) of slot.feat against slot.prev
+int rtvm_launch_l2_slots(rtvm_ctx* c, int sb, int nb, int cap);
 // stream.hip
 int rtvm_stream_setup(rtvm_ctx* c);
-int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int with_orb);  // api.hip
+// api.hip; kind 0: matcher / RANSAC work areas only, 1: plus ORB detection planes and features, 2: plus SIFT features
+int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int kind);
 // ransac.hip
 size_t rtvm_ransac_state_bytes();
 void rtvm_ransac_raw_table(uint32_t* raw, int n);

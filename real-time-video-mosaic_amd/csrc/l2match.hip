@@ -62,14 +62,9 @@ constexpr uint32_t L2_FAR = 1u << 22;
 
 // grid.y = 0: queries, 1: train rows.  One thread per (row, group of 8 columns); KS = dim / 16.
 template <int KS>
-__global__ __launch_bounds__(256) void k_l2_prep(const float* __restrict__ q, int nq, const float* __restrict__ t, int nt,
-                                                 uint4* __restrict__ qb, uint4* __restrict__ tb,
-                                                 float* __restrict__ qn, float* __restrict__ tn, int* __restrict__ flag) {
+__device__ __forceinline__ void l2_prep_rows(const float* __restrict__ src, int n, int n_pad, uint4* __restrict__ dstb,
+                                             float* __restrict__ dstn, int* __restrict__ flag) {
     constexpr int G = 2 * KS;  // groups of 8 columns per row
-    const bool train = blockIdx.y != 0;
-    const float* __restrict__ src = train ? t : q;
-    const int n = train ? nt : nq;
-    const int n_pad = (n + L2_TILE - 1) / L2_TILE * L2_TILE;
     const int id = blockIdx.x * 256 + threadIdx.x;
     const int row = id / G, g = id % G;
     if (row >= n_pad) return;
@@ -92,13 +87,32 @@ __global__ __launch_bounds__(256) void k_l2_prep(const float* __restrict__ q, in
         else
             w[i >> 1] = h;
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+    if (flag && __any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
     // the G threads of a row are consecutive lanes of one wave (G divides 64)
 #pragma unroll
     for (int d = 1; d < G; d <<= 1) ss += __shfl_xor(ss, d);
-    if (g == 0) (train ? tn : qn)[row] = ss;
+    if (g == 0) dstn[row] = ss;
     const int s = g >> 1, h = g & 1;
-    (train ? tb : qb)[((size_t)(row >> 5) * KS + s) * 64 + h * 32 + (row & 31)] = make_uint4(w[0], w[1], w[2], w[3]);
+    dstb[((size_t)(row >> 5) * KS + s) * 64 + h * 32 + (row & 31)] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void k_l2_prep(const float* __restrict__ q, int nq, const float* __restrict__ t, int nt,
+                                                 uint4* __restrict__ qb, uint4* __restrict__ tb,
+                                                 float* __restrict__ qn, float* __restrict__ tn, int* __restrict__ flag) {
+    const bool train = blockIdx.y != 0;
+    const int n = train ? nt : nq;
+    l2_prep_rows<KS>(train ? t : q, n, (n + L2_TILE - 1) / L2_TILE * L2_TILE, train ? tb : qb, train ? tn : qn, flag);
+}
+
+// The same for the frames of a batch: blockIdx.z = frame, descriptors and counts from the slots
+// (SIFT descriptors are 8-bit integers by construction: no check).
+__global__ __launch_bounds__(256) void k_l2_prep_slots(const FrameSlot* __restrict__ slots, int sb, int cap_pad) {
+    const FrameSlot& S = slots[sb + blockIdx.z];
+    const bool train = blockIdx.y != 0;
+    const FeatSet& F = train ? S.prev : S.feat;
+    l2_prep_rows<8>(reinterpret_cast<const float*>(F.desc), min(*F.count, cap_pad), cap_pad, train ? S.l2_tb : S.l2_qb,
+                    train ? S.l2_tn : S.l2_qn, nullptr);
 }
 
 __device__ __forceinline__ void key_top2(uint32_t& k0, uint32_t& k1, uint32_t key) {
@@ -109,10 +123,9 @@ __device__ __forceinline__ void key_top2(uint32_t& k0, uint32_t& k1, uint32_t ke
 
 // blockIdx.x = query tile, blockIdx.y = train tile.  part: [train tiles][padded queries][2] keys.
 template <int KS>
-__global__ __launch_bounds__(256) void k_l2_tile(const uint4* __restrict__ qb, const uint4* __restrict__ tb,
-                                                 const float* __restrict__ qn, const float* __restrict__ tn, int nt,
-                                                 int nq_pad, const int* __restrict__ flag, uint32_t* __restrict__ part) {
-    if (!*flag) return;  // not 8-bit integer data: k_l2_knn2_direct computes the result
+__device__ __forceinline__ void l2_tile_body(const uint4* __restrict__ qb, const uint4* __restrict__ tb,
+                                             const float* __restrict__ qn, const float* __restrict__ tn, int nt, int nq_pad,
+                                             uint32_t* __restrict__ part) {
     __shared__ uint4 s_t[4 * KS * 64];
     __shared__ __align__(16) float s_tn[L2_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -167,6 +180,118 @@ __global__ __launch_bounds__(256) void k_l2_tile(const uint4* __restrict__ qb, c
         part[o] = k0;
         part[o + 1] = k1;
     }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void k_l2_tile(const uint4* __restrict__ qb, const uint4* __restrict__ tb,
+                                                 const float* __restrict__ qn, const float* __restrict__ tn, int nt,
+                                                 int nq_pad, const int* __restrict__ flag, uint32_t* __restrict__ part) {
+    if (!*flag) return;  // not 8-bit integer data: k_l2_knn2_direct computes the result
+    l2_tile_body<KS>(qb, tb, qn, tn, nt, nq_pad, part);
+}
+
+// blockIdx.z = frame of the batch; tiles beyond the frame's descriptor counts have nothing to do.
+__global__ __launch_bounds__(256) void k_l2_tile_slots(const FrameSlot* __restrict__ slots, int sb, int cap_pad) {
+    const FrameSlot& S = slots[sb + blockIdx.z];
+    const int nq = min(*S.feat.count, cap_pad), nt = min(*S.prev.count, cap_pad);
+    if ((int)blockIdx.x * L2_TILE >= nq || (int)blockIdx.y * L2_TILE >= nt) return;
+    l2_tile_body<8>(S.l2_qb, S.l2_tb, S.l2_qn, S.l2_tn, nt, cap_pad, S.l2_part);
+}
+
+// main.py:688-698 behind the tiles, one workgroup per frame: the two nearest train rows of every
+// query (merge over the column tiles, roots), Lowe's ratio test `d0 < 0.7 * d1` in double
+// precision as Python evaluates it, compaction in query order, stable sort by distance (keys:
+// bit pattern of the float distance, then the position before sorting).  SIFT descriptors have
+// norm 512 at most, so d2 stays below 2^22 and the order of d2 is the order of the roots.
+__global__ __launch_bounds__(1024) void k_l2_ratio_sort(const FrameSlot* __restrict__ slots, int sb, int cap_pad) {
+    const FrameSlot& S = slots[sb + blockIdx.x];
+    __shared__ unsigned long long s_key[RTVM_SIFT_STREAM_MAX_KP];
+    __shared__ uint16_t s_q[RTVM_SIFT_STREAM_MAX_KP], s_t[RTVM_SIFT_STREAM_MAX_KP];
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = min(*S.feat.count, cap_pad), nt = min(*S.prev.count, cap_pad);
+    const int n_tiles = (nt + L2_TILE - 1) / L2_TILE;
+    const uint32_t* __restrict__ part = S.l2_part;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nq; i0 += 1024) {
+        const int i = i0 + tid;
+        bool ok = false;
+        float d0 = 0.f;
+        int j0 = 0;
+        if (i < nq && nt >= 2) {  // with fewer than two train rows the reference has no pair to test
+            unsigned long long b0 = ~0ull, b1 = ~0ull;
+            for (int tI = 0; tI < n_tiles; tI++) {
+                const uint2 k = *reinterpret_cast<const uint2*>(part + ((size_t)tI * cap_pad + i) * 2);
+                const uint32_t ks[2] = {k.x, k.y};
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (ks[u] == L2_NOKEY) continue;
+                    const unsigned long long key =
+                        ((unsigned long long)(ks[u] >> 7) << 32) | (uint32_t)(tI * L2_TILE + (ks[u] & 127));
+                    const unsigned long long lo = key < b0 ? key : b0, hi = key < b0 ? b0 : key;
+                    b0 = lo;
+                    b1 = hi < b1 ? hi : b1;
+                }
+            }
+            d0 = sqrtf((float)(uint32_t)(b0 >> 32));
+            const float d1 = sqrtf((float)(uint32_t)(b1 >> 32));
+            j0 = (int)(uint32_t)b0;
+            ok = (double)d0 < 0.7 * (double)d1;
+        }
+        const unsigned long long bal = __ballot(ok);
+        const int wrank = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += s_wave[w];
+        const int base = s_base;
+        if (ok) {
+            const int pos = base + woff + wrank;
+            s_key[pos] = ((unsigned long long)__float_as_uint(d0) << 32) | (uint32_t)pos;
+            s_q[pos] = (uint16_t)i;
+            s_t[pos] = (uint16_t)j0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += s_wave[w];
+            s_base = base + tot;
+        }
+        __syncthreads();
+    }
+    const int m = s_base;
+    if (m > 1) {
+        int n2 = 1;
+        while (n2 < m) n2 <<= 1;
+        for (int i = m + tid; i < n2; i += 1024) s_key[i] = ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < n2; i += 1024) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long a = s_key[i], b = s_key[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) {
+                            s_key[i] = b;
+                            s_key[ixj] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    for (int p = tid; p < m; p += 1024) {
+        const unsigned long long key = s_key[p];
+        const int src = (int)(uint32_t)key;  // position before sorting
+        S.m_qidx[p] = s_q[src];
+        S.m_tidx[p] = s_t[src];
+        S.m_dist[p] = (int)(uint32_t)(key >> 32);  // bit pattern of the float distance
+    }
+    if (tid == 0) *S.m_count = m;
 }
 
 // One thread per query: top-2 over the train tiles (tiles ascend with the row index, keys inside
@@ -362,6 +487,20 @@ int rtvm_launch_l2_knn2(rtvm_ctx* c, const float* dq, int nq, const float* dt, i
     (void)hipFuncSetAttribute((const void*)k_l2_knn2_direct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     RTVM_LAUNCH(c, k_l2_knn2_direct, dim3((nq + 63) / 64), dim3(256), lds_bytes, dq, nq, dt, nt, dim, (const int*)d_flag,
                 mfma ? 1 : 0, d_idx, d_dist);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
+}
+
+// knn-2 + ratio + sort for slots sb .. sb+nb-1 (contexts with the SIFT detector): matches into
+// slot.m_qidx / m_tidx / m_dist (distances as float bit patterns) / m_count.
+int rtvm_launch_l2_slots(rtvm_ctx* c, int sb, int nb, int cap) {
+    if (cap > RTVM_SIFT_STREAM_MAX_KP) RTVM_FAIL(c, RTVM_E_ARG, "L2 matcher: at most %d descriptors per frame", RTVM_SIFT_STREAM_MAX_KP);
+    const int cap_pad = (cap + L2_TILE - 1) / L2_TILE * L2_TILE;
+    const int tiles = cap_pad / L2_TILE;
+    RTVM_LAUNCH(c, k_l2_prep_slots, dim3((cap_pad * 16 + 255) / 256, 2, nb), dim3(256), 0, (const FrameSlot*)c->d_slots, sb,
+                cap_pad);
+    RTVM_LAUNCH(c, k_l2_tile_slots, dim3(tiles, tiles, nb), dim3(256), 0, (const FrameSlot*)c->d_slots, sb, cap_pad);
+    RTVM_LAUNCH(c, k_l2_ratio_sort, dim3(nb), dim3(1024), 0, (const FrameSlot*)c->d_slots, sb, cap_pad);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }

@@ -1,7 +1,8 @@
 // cv2.SIFT_create(n).detectAndCompute(gray, None) for gfx950 (reference main.py:33, 111-112,
 // 717-718; OpenCV defaults nOctaveLayers = 3, contrastThreshold = 0.04, edgeThreshold = 10,
-// sigma = 1.6).  Stage entry point rtvm_sift: host frame in, keypoints and 128-float
-// descriptors out.
+// sigma = 1.6).  Every kernel carries the frame of a batch in its grid (blockIdx.z, or .y for
+// the per-keypoint kernels), so the stage entry point rtvm_sift (one host frame) and the
+// device-resident stream path (rtvm_launch_sift: the frames of a batch) share them.
 //
 //   k_sift_base      gray (15-bit fixed point) as float, doubled with the arithmetic of
 //                    cv::resize(INTER_LINEAR) on floats
@@ -12,18 +13,25 @@
 //   k_sift_decimate  next octave = every second pixel of layer 3
 //   k_sift_extrema   26-neighbour extrema above the contrast floor -> candidate keys (every
 //                    octave and layer in one launch)
-//   k_sift_refine    one wave per candidate (keys sorted on the host: octave, layer, row,
-//                    column): adjustLocalExtrema, orientation histogram, peaks
+//   k_sift_refine    one wave per candidate: adjustLocalExtrema, orientation histogram, peaks;
+//                    keypoints appended to a list in whatever order the waves finish
+//   k_sift_rank / k_sift_mark / k_sift_compact
+//                    KeyPointsFilter::removeDuplicatedSorted and retainBest(nfeatures) without a
+//                    sort: every keypoint counts the keypoints that precede it in the sorted
+//                    order (a total order: equal records are identical), the duplicates are
+//                    marked, every unique keypoint counts the unique ones with a larger
+//                    response (kept iff fewer than nfeatures), and the kept ones are compacted
+//                    in sorted order
 //   k_sift_describe  one wave per keypoint: calcSIFTDescriptor (samples in parallel, sums in order)
 // Sums that OpenCV accumulates sequentially (orientation and descriptor histograms) are
 // accumulated sequentially by one thread here as well; exp, atan2, cos, sin and pow are
-// evaluated in double precision and rounded to float.  Duplicate removal and
-// retainBest(nfeatures) run on the host between the last two kernels.
+// evaluated in double precision and rounded to float.
 #include "common.h"
 
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <new>
 #include <vector>
 
 namespace {
@@ -55,13 +63,44 @@ struct SPyr {
     SImg dog[MAX_OCT * (SL + 2)];
 };
 
+// Everything one frame of a batch needs, in device memory; the kernels index an array of these
+// with the frame's position in the batch.  All frames of a batch have the same geometry.
+struct SiftFrame {
+    SPyr pyr;                   // planes of the frame's Gaussian and difference pyramids
+    float* scratch;             // row-pass plane (size of the doubled image)
+    const uint8_t* bgr;         // frame pixels
+    unsigned long long* keys;   // scale-space extrema
+    int* counts;                // [0] extrema found, [1] keypoints listed, [2] keypoints kept, [3] overflow bits
+    SKp* list;                  // keypoints as the refinement appends them
+    SKp* sorted;                // the same in removeDuplicatedSorted order
+    int* gt;                    // per sorted keypoint: -1 = duplicate, else unique keypoints with a larger response
+    SKp* kept;                  // the filtered keypoints, coordinates of the doubled image
+    float* xy;                  // outputs: n x 2, level-0 pixel coordinates
+    float* size;
+    float* angle;
+    float* response;
+    int32_t* octave;
+    float* desc;                // n x 128
+    int* n_out;
+};
+
+// plane ids: Gaussian layer g, 256 + difference layer d, or the row-pass plane
+constexpr int PLANE_DOG = 256, PLANE_SCRATCH = 1024;
+__device__ __forceinline__ float* plane(const SiftFrame& f, int id) {
+    return id == PLANE_SCRATCH ? f.scratch : id >= PLANE_DOG ? f.pyr.dog[id - PLANE_DOG].px : f.pyr.gp[id].px;
+}
+
 __device__ __forceinline__ int reflect101s(int p, int n) {
     if (n == 1) return 0;
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_sift_base(const uint8_t* __restrict__ bgr, int h, int w, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_sift_base(const SiftFrame* __restrict__ F, int h, int w, int dst_id) {
+    const SiftFrame& f = F[blockIdx.z];
+    const uint8_t* __restrict__ bgr = f.bgr;
+    float* __restrict__ out = plane(f, dst_id);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) f.counts[threadIdx.x] = 0;  // nothing found yet
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= 2 * w || y >= 2 * h) return;
     float fx = (float)(((double)x + 0.5) * 0.5 - 0.5), fy = (float)(((double)y + 0.5) * 0.5 - 0.5);
@@ -131,8 +170,11 @@ __device__ __forceinline__ float col_taps_border(const Taps& t, const float* col
     return a;
 }
 
-__global__ __launch_bounds__(256) void k_sift_blur_rows(const float* __restrict__ src, float* __restrict__ dst, int h, int w,
+__global__ __launch_bounds__(256) void k_sift_blur_rows(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w,
                                                         Taps t) {
+    const SiftFrame& f = F[blockIdx.z];
+    const float* __restrict__ src = plane(f, src_id);
+    float* __restrict__ dst = plane(f, dst_id);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const int half = t.n / 2;
@@ -148,8 +190,13 @@ __global__ __launch_bounds__(256) void k_sift_blur_rows(const float* __restrict_
 
 // Column pass; with `below` (the Gaussian layer under the one being made) it also writes the
 // difference of the two layers, dog = this - below, the value a separate subtraction would give.
-__global__ __launch_bounds__(256) void k_sift_blur_cols(const float* __restrict__ src, float* __restrict__ dst, int h, int w,
-                                                        Taps t, const float* __restrict__ below, float* __restrict__ dog) {
+__global__ __launch_bounds__(256) void k_sift_blur_cols(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w,
+                                                        Taps t, int below_id, int dog_id) {
+    const SiftFrame& f = F[blockIdx.z];
+    const float* __restrict__ src = plane(f, src_id);
+    float* __restrict__ dst = plane(f, dst_id);
+    const float* __restrict__ below = below_id >= 0 ? plane(f, below_id) : nullptr;
+    float* __restrict__ dog = below_id >= 0 ? plane(f, dog_id) : nullptr;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const int half = t.n / 2;
@@ -164,8 +211,11 @@ __global__ __launch_bounds__(256) void k_sift_blur_cols(const float* __restrict_
     if (below) dog[(size_t)y * w + x] = a - below[(size_t)y * w + x];
 }
 
-__global__ __launch_bounds__(256) void k_sift_decimate(const float* __restrict__ src, int sw, float* __restrict__ dst, int h,
+__global__ __launch_bounds__(256) void k_sift_decimate(const SiftFrame* __restrict__ F, int src_id, int sw, int dst_id, int h,
                                                        int w) {
+    const SiftFrame& f = F[blockIdx.z];
+    const float* __restrict__ src = plane(f, src_id);
+    float* __restrict__ dst = plane(f, dst_id);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     dst[(size_t)y * w + x] = src[(size_t)(2 * y) * sw + 2 * x];
@@ -202,7 +252,8 @@ __device__ __forceinline__ void small_layer(const SPyr* P, int o, int i, const T
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_sift_small_octaves(const SPyr* P, int o0, int o1, TapsAll T, int lds_px) {
+__global__ __launch_bounds__(1024) void k_sift_small_octaves(const SiftFrame* F, int o0, int o1, TapsAll T, int lds_px) {
+    const SPyr* P = &F[blockIdx.z].pyr;
     extern __shared__ float s_small[];
     float* cur = s_small;            // the layer below the one being made
     float* rowp = s_small + lds_px;  // its row pass
@@ -238,8 +289,11 @@ struct ExtremaTiles {
     int tiles_x[MAX_OCT];
 };
 
-__global__ __launch_bounds__(256) void k_sift_extrema(const SPyr* __restrict__ P, ExtremaTiles T, float threshold,
-                                                      unsigned long long* __restrict__ keys, int* __restrict__ count, int cap) {
+__global__ __launch_bounds__(256) void k_sift_extrema(const SiftFrame* __restrict__ F, ExtremaTiles T, float threshold, int cap) {
+    const SiftFrame& f = F[blockIdx.z];
+    const SPyr* __restrict__ P = &f.pyr;
+    unsigned long long* __restrict__ keys = f.keys;
+    int* __restrict__ count = f.counts;
     int octave = 0;
     while (octave + 1 < T.n_oct && (int)blockIdx.x >= T.tile_start[octave + 1]) octave++;
     const int tile = blockIdx.x - T.tile_start[octave], layer = blockIdx.y + 1;
@@ -406,9 +460,13 @@ __device__ float orientation_hist(const SImg img, int px, int py, int radius, fl
 // (the host does not know the count yet).  Keypoints go to `list` in whatever order the waves
 // finish: the host sorts them (KeyPointsFilter::removeDuplicatedSorted), so the order of the
 // candidates and of the list does not reach the result.
-__global__ __launch_bounds__(64) void k_sift_refine(const SPyr* __restrict__ P, const unsigned long long* __restrict__ keys,
-                                                    const int* __restrict__ count, int cap, SKp* __restrict__ list,
-                                                    int* __restrict__ list_count, int list_cap) {
+__global__ __launch_bounds__(64) void k_sift_refine(const SiftFrame* __restrict__ F, int cap, int list_cap) {
+    const SiftFrame& f = F[blockIdx.y];
+    const SPyr* __restrict__ P = &f.pyr;
+    const unsigned long long* __restrict__ keys = f.keys;
+    const int* __restrict__ count = f.counts;
+    SKp* __restrict__ list = f.list;
+    int* __restrict__ list_count = f.counts + 1;
     __shared__ float temphist[ORI_BINS], hist[ORI_BINS];
     __shared__ __align__(16) float s_val[64];
     __shared__ __align__(16) int s_bin[64];
@@ -447,10 +505,149 @@ __global__ __launch_bounds__(64) void k_sift_refine(const SPyr* __restrict__ P, 
 // time (gradient, exp, atan2, the eight trilinear shares and the bin index); lane 0 then adds
 // the shares to the histogram in LDS in scan order, which is the order of OpenCV's sequential
 // loop, so the float sums come out the same.
-__global__ __launch_bounds__(64) void k_sift_describe(const SPyr* __restrict__ P, const SKp* __restrict__ kps, int n,
-                                                      float* __restrict__ desc) {
+// Sorted order of KeyPointsFilter::removeDuplicatedSorted (x, y, size descending, angle, response
+// descending, octave descending).
+__device__ __forceinline__ bool kp_before(const SKp& a, const SKp& b) {
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.size != b.size) return a.size > b.size;
+    if (a.angle != b.angle) return a.angle < b.angle;
+    if (a.response != b.response) return a.response > b.response;
+    return a.octave > b.octave;
+}
+
+// Position of every listed keypoint in the sorted order = number of keypoints that precede it
+// (records that compare equal are equal in every field; the list index breaks those ties, so
+// the positions are a permutation).  grid = (list blocks, frames).
+__global__ __launch_bounds__(256) void k_sift_rank(const SiftFrame* __restrict__ F, int list_cap) {
+    const SiftFrame& f = F[blockIdx.y];
+    const int n = min(f.counts[1], list_cap);
+    if ((int)blockIdx.x * 256 >= n) return;
+    __shared__ SKp s[256];
+    __shared__ unsigned long long s_key[256];
+    const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    const SKp me = f.list[min(i, n - 1)];
+    // x and y are positive, so their bit patterns order like the values: one 64-bit compare decides
+    // all pairs except those at the same position
+    const unsigned long long my_key = ((unsigned long long)__float_as_uint(me.x) << 32) | __float_as_uint(me.y);
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+        if (j0 + tid < n) {
+            const SKp o = f.list[j0 + tid];
+            s[tid] = o;
+            s_key[tid] = ((unsigned long long)__float_as_uint(o.x) << 32) | __float_as_uint(o.y);
+        }
+        __syncthreads();
+        const int m = min(256, n - j0);
+        for (int u = 0; u < m; u++) {
+            const unsigned long long ko = s_key[u];
+            if (ko == my_key) {
+                // same position: the remaining fields decide, then the place in the list (records that
+                // compare equal are equal in every field)
+                const SKp o = s[u];
+                const bool lt = kp_before(o, me), gtb = kp_before(me, o);
+                rank += (lt || (!gtb && j0 + u < i)) ? 1 : 0;
+            } else {
+                rank += ko < my_key ? 1 : 0;
+            }
+        }
+    }
+    if (i < n) f.sorted[rank] = me;
+}
+
+// removeDuplicatedSorted keeps a keypoint iff it differs from its predecessor in x, y, size or
+// angle; retainBest(nfeatures) then keeps a keypoint iff its response is at least the
+// nfeatures-th largest, i.e. iff fewer than nfeatures unique keypoints have a larger response.
+__global__ __launch_bounds__(256) void k_sift_mark(const SiftFrame* __restrict__ F, int list_cap) {
+    const SiftFrame& f = F[blockIdx.y];
+    const int n = min(f.counts[1], list_cap);
+    if ((int)blockIdx.x * 256 >= n) return;
+    __shared__ float s_r[256];
+    __shared__ int s_u[256];
+    const int tid = threadIdx.x, p = blockIdx.x * 256 + tid;
+    const SKp* __restrict__ sorted = f.sorted;
+    const float my_r = sorted[min(p, n - 1)].response;
+    int gt = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+        const int q = j0 + tid;
+        if (q < n) {
+            const SKp a = sorted[q];
+            bool uniq = true;
+            if (q > 0) {
+                const SKp b = sorted[q - 1];
+                uniq = a.x != b.x || a.y != b.y || a.size != b.size || a.angle != b.angle;
+            }
+            s_r[tid] = a.response;
+            s_u[tid] = uniq ? 1 : 0;
+        }
+        __syncthreads();
+        const int m = min(256, n - j0);
+        for (int u = 0; u < m; u++) gt += (s_u[u] && s_r[u] > my_r) ? 1 : 0;
+    }
+    if (p < n) {
+        bool uniq = true;
+        if (p > 0) {
+            const SKp a = sorted[p], b = sorted[p - 1];
+            uniq = a.x != b.x || a.y != b.y || a.size != b.size || a.angle != b.angle;
+        }
+        f.gt[p] = uniq ? gt : -1;
+    }
+}
+
+// The kept keypoints in sorted order, at most out_cap of them: the list the descriptor kernel
+// reads and the caller's arrays (coordinates and size back to the input image, octave field
+// re-based for firstOctave = -1).
+__global__ __launch_bounds__(256) void k_sift_compact(const SiftFrame* __restrict__ F, int list_cap, int nfeatures, int out_cap) {
+    const SiftFrame& f = F[blockIdx.y];
+    const int n = min(f.counts[1], list_cap);
+    if (n == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            f.counts[2] = 0;
+            *f.n_out = 0;
+        }
+        return;
+    }
+    if ((int)blockIdx.x * 256 >= n) return;
+    __shared__ int s_k[256];
+    const int tid = threadIdx.x, p = blockIdx.x * 256 + tid;
+    const int* __restrict__ gt = f.gt;
+    int before = 0;  // kept keypoints in front of p
+    for (int j0 = 0; j0 < (int)blockIdx.x * 256 + 256 && j0 < n; j0 += 256) {
+        __syncthreads();
+        const int q = j0 + tid;
+        s_k[tid] = (q < n && gt[q] >= 0 && gt[q] < nfeatures) ? 1 : 0;
+        __syncthreads();
+        const int m = min(256, p - j0);
+        for (int u = 0; u < m; u++) before += s_k[u];
+    }
+    if (p >= n) return;
+    const bool keep = gt[p] >= 0 && gt[p] < nfeatures;
+    if (p == n - 1) {
+        const int total = min(before + (keep ? 1 : 0), out_cap);
+        f.counts[2] = total;
+        *f.n_out = total;
+    }
+    if (!keep || before >= out_cap) return;
+    const SKp kp = f.sorted[p];
+    f.kept[before] = kp;
+    f.xy[2 * before] = kp.x * 0.5f;
+    f.xy[2 * before + 1] = kp.y * 0.5f;
+    f.size[before] = kp.size * 0.5f;
+    f.angle[before] = kp.angle;
+    f.response[before] = kp.response;
+    f.octave[before] = (kp.octave & ~255) | ((kp.octave - 1) & 255);
+}
+
+// grid = (out_cap, frames): wave q of frame y describes kept keypoint q, if there is one.
+__global__ __launch_bounds__(64) void k_sift_describe(const SiftFrame* __restrict__ F) {
+    const SiftFrame& f = F[blockIdx.y];
     const int q = blockIdx.x, lane = threadIdx.x;
-    const SKp kp = kps[q];
+    if (q >= f.counts[2]) return;
+    const SPyr* __restrict__ P = &f.pyr;
+    float* __restrict__ desc = f.desc;
+    const SKp kp = f.kept[q];
     const int oct = kp.octave & 255, layer = (kp.octave >> 8) & 255;
     const float scale_oct = 1.f / (float)(1 << oct);
     float ori = 360.f - kp.angle;
@@ -579,13 +776,155 @@ Taps gauss_taps(double sigma) {
     return t;
 }
 
-bool kp_less(const SKp& a, const SKp& b) {
-    if (a.x != b.x) return a.x < b.x;
-    if (a.y != b.y) return a.y < b.y;
-    if (a.size != b.size) return a.size > b.size;
-    if (a.angle != b.angle) return a.angle < b.angle;
-    if (a.response != b.response) return a.response > b.response;
-    return a.octave > b.octave;
+dim3 grid3(int w, int h, int nb) { return dim3((w + 63) / 64, (h + 3) / 4, nb); }
+
+// What depends on the frame size alone: octaves, plane offsets inside a frame's arena (in
+// floats), filter taps, the tiling of the extrema kernel.
+struct SiftGeom {
+    int h = 0, w = 0, bh, bw, n_oct, o_small, lds_px;
+    int oh[MAX_OCT], ow[MAX_OCT];
+    size_t off_gp[MAX_OCT * (SL + 3)], off_dog[MAX_OCT * (SL + 2)], scratch_off, total;
+    Taps base, taps[SL + 3];
+    TapsAll small;
+    ExtremaTiles tiles;
+    float threshold;
+};
+
+int sift_geometry(rtvm_ctx* c, int h, int w, SiftGeom& g) {
+    if (h < 16 || w < 16 || h > 8192 || w > 8192) RTVM_FAIL(c, RTVM_E_ARG, "sift: frame %dx%d (16..8192 pixels a side)", h, w);
+    g.h = h, g.w = w, g.bh = 2 * h, g.bw = 2 * w;
+    g.n_oct = cv_round_d(std::log((double)std::min(g.bw, g.bh)) / std::log(2.) - 2) + 1;
+    if (g.n_oct < 1 || g.n_oct > MAX_OCT) RTVM_FAIL(c, RTVM_E_ARG, "sift: %d octaves", g.n_oct);
+    double sig[SL + 3];
+    sig[0] = SSIGMA;
+    const double kf = std::pow(2., 1. / SL);
+    for (int i = 1; i < SL + 3; i++) {
+        const double sp = std::pow(kf, (double)(i - 1)) * SSIGMA, st = sp * kf;
+        sig[i] = std::sqrt(st * st - sp * sp);
+    }
+    size_t total = 0;
+    int oh = g.bh, ow = g.bw;
+    for (int o = 0; o < g.n_oct; o++) {
+        g.oh[o] = oh, g.ow[o] = ow;
+        for (int i = 0; i < SL + 3; i++) {
+            g.off_gp[o * (SL + 3) + i] = total;
+            total += (size_t)oh * ow;
+        }
+        for (int i = 0; i < SL + 2; i++) {
+            g.off_dog[o * (SL + 2) + i] = total;
+            total += (size_t)oh * ow;
+        }
+        oh /= 2, ow /= 2;
+        if (oh < 1 || ow < 1) RTVM_FAIL(c, RTVM_E_ARG, "sift: frame too small for %d octaves", g.n_oct);
+    }
+    g.scratch_off = total;
+    total += (size_t)g.bh * g.bw;
+    g.total = total;
+    const float sig_diff = std::sqrt(std::max(SSIGMA * SSIGMA - 1.f, 0.01f));
+    g.base = gauss_taps((double)sig_diff);
+    memset(&g.small, 0, sizeof(g.small));
+    for (int i = 1; i < SL + 3; i++) {
+        g.taps[i] = gauss_taps(sig[i]);
+        g.small.t[i] = g.taps[i];
+    }
+    g.threshold = (float)(int)std::floor(0.5 * SCONTRAST / SL * 255);
+    // octaves from o_small on are built by one workgroup in one launch
+    g.o_small = g.n_oct;
+    for (int o = g.n_oct - 1; o >= 1 && g.oh[o] * g.ow[o] <= SMALL_OCTAVE_PX; o--) g.o_small = o;
+    g.lds_px = g.o_small < g.n_oct ? g.oh[g.o_small] * g.ow[g.o_small] : 0;
+    memset(&g.tiles, 0, sizeof(g.tiles));
+    for (int o = 0; o < g.n_oct; o++) {
+        if (!(g.oh[o] > 2 * SBORDER && g.ow[o] > 2 * SBORDER)) break;  // the octaves only get smaller
+        const int tx = (g.ow[o] - 2 * SBORDER + 63) / 64, ty = (g.oh[o] - 2 * SBORDER + 3) / 4;
+        g.tiles.tiles_x[o] = tx;
+        g.tiles.tile_start[o + 1] = g.tiles.tile_start[o] + tx * ty;
+        g.tiles.n_oct = o + 1;
+    }
+    return RTVM_OK;
+}
+
+// Sizes of the per-frame work areas.
+constexpr int SIFT_CAND_CAP = 1 << 18, SIFT_LIST_CAP = 1 << 16;
+
+size_t sift_work_bytes(int out_cap) {
+    size_t b = 0;
+    b += (size_t)SIFT_CAND_CAP * 8;                // keys
+    b += 256;                                      // counts
+    b += 3 * ((size_t)SIFT_LIST_CAP * sizeof(SKp) + 256);  // list, sorted, kept
+    b += (size_t)SIFT_LIST_CAP * sizeof(int) + 256;        // gt
+    (void)out_cap;
+    return b + 1024;
+}
+
+// The host copy of one frame's descriptor: planes inside `arena` (g.total floats), lists inside
+// `work` (sift_work_bytes); frame pixels and outputs are filled in by the caller.
+void sift_frame_init(SiftFrame& f, const SiftGeom& g, float* arena, char* work) {
+    memset(&f, 0, sizeof(f));
+    for (int o = 0; o < g.n_oct; o++) {
+        for (int i = 0; i < SL + 3; i++) f.pyr.gp[o * (SL + 3) + i] = SImg{arena + g.off_gp[o * (SL + 3) + i], g.oh[o], g.ow[o]};
+        for (int i = 0; i < SL + 2; i++) f.pyr.dog[o * (SL + 2) + i] = SImg{arena + g.off_dog[o * (SL + 2) + i], g.oh[o], g.ow[o]};
+    }
+    f.scratch = arena + g.scratch_off;
+    auto take = [&](size_t bytes) {
+        char* p = work;
+        work += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    f.keys = (unsigned long long*)take((size_t)SIFT_CAND_CAP * 8);
+    f.counts = (int*)take(256);
+    f.list = (SKp*)take((size_t)SIFT_LIST_CAP * sizeof(SKp));
+    f.sorted = (SKp*)take((size_t)SIFT_LIST_CAP * sizeof(SKp));
+    f.kept = (SKp*)take((size_t)SIFT_LIST_CAP * sizeof(SKp));
+    f.gt = (int*)take((size_t)SIFT_LIST_CAP * sizeof(int));
+}
+
+// Detection and description of nb frames (descriptors d_frames[0 .. nb-1], all of geometry g) on
+// the context's current stream.
+int sift_launch(rtvm_ctx* c, const SiftGeom& g, const SiftFrame* d_frames, int nb, int nfeatures, int out_cap) {
+    const int bh = g.bh, bw = g.bw;
+    // base image: doubled, blurred by sqrt(sigma^2 - 1) (into gp[0] via the last DoG plane of octave 0 as a temporary)
+    {
+        const int dbl = PLANE_DOG + SL + 1;  // free until the DoG of octave 0 is formed
+        RTVM_LAUNCH(c, k_sift_base, grid3(bw, bh, nb), dim3(256), 0, d_frames, g.h, g.w, dbl);
+        RTVM_LAUNCH(c, k_sift_blur_rows, grid3(bw, bh, nb), dim3(256), 0, d_frames, dbl, PLANE_SCRATCH, bh, bw, g.base);
+        RTVM_LAUNCH(c, k_sift_blur_cols, grid3(bw, bh, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, 0, bh, bw, g.base, -1, -1);
+    }
+    for (int o = 0; o < g.o_small; o++) {
+        const int oh = g.oh[o], ow = g.ow[o];
+        for (int i = 0; i < SL + 3; i++) {
+            const int dst = o * (SL + 3) + i;
+            if (i == 0) {
+                if (o == 0) continue;
+                RTVM_LAUNCH(c, k_sift_decimate, grid3(ow, oh, nb), dim3(256), 0, d_frames, (o - 1) * (SL + 3) + SL, g.ow[o - 1],
+                            dst, oh, ow);
+            } else {
+                RTVM_LAUNCH(c, k_sift_blur_rows, grid3(ow, oh, nb), dim3(256), 0, d_frames, dst - 1, PLANE_SCRATCH, oh, ow,
+                            g.taps[i]);
+                RTVM_LAUNCH(c, k_sift_blur_cols, grid3(ow, oh, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, dst, oh, ow, g.taps[i],
+                            dst - 1, PLANE_DOG + o * (SL + 2) + i - 1);
+            }
+        }
+    }
+    if (g.o_small < g.n_oct) {
+        const size_t lds_bytes = (size_t)2 * g.lds_px * sizeof(float);
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sift_small_octaves),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        RTVM_LAUNCH(c, k_sift_small_octaves, dim3(1, 1, nb), dim3(1024), lds_bytes, d_frames, g.o_small, g.n_oct, g.small,
+                    g.lds_px);
+    }
+    if (g.tiles.n_oct > 0)
+        RTVM_LAUNCH(c, k_sift_extrema, dim3(g.tiles.tile_start[g.tiles.n_oct], SL, nb), dim3(256), 0, d_frames, g.tiles,
+                    g.threshold, SIFT_CAND_CAP);
+    // refinement of every candidate, queued behind the extrema without a host round trip; then
+    // removeDuplicatedSorted + retainBest on the device, then the descriptors of what is kept
+    RTVM_LAUNCH(c, k_sift_refine, dim3(nb > 1 ? 2048 : 4096, nb), dim3(64), 0, d_frames, SIFT_CAND_CAP, SIFT_LIST_CAP);
+    const dim3 gl(SIFT_LIST_CAP / 256, nb);
+    RTVM_LAUNCH(c, k_sift_rank, gl, dim3(256), 0, d_frames, SIFT_LIST_CAP);
+    RTVM_LAUNCH(c, k_sift_mark, gl, dim3(256), 0, d_frames, SIFT_LIST_CAP);
+    RTVM_LAUNCH(c, k_sift_compact, gl, dim3(256), 0, d_frames, SIFT_LIST_CAP, nfeatures, out_cap);
+    RTVM_LAUNCH(c, k_sift_describe, dim3(out_cap, nb), dim3(64), 0, d_frames);
+    HIP_TRY(c, hipGetLastError());
+    return RTVM_OK;
 }
 
 // Buffer `slot` of the context with room for `bytes`: kept between calls, replaced by a larger
@@ -603,18 +942,87 @@ int sift_buffer(rtvm_ctx* c, int slot, size_t bytes, void** out) {
     *out = c->sift_buf[slot];
     return RTVM_OK;
 }
-struct Dev {
-    void* p = nullptr;
-};
-#define SIFT_BUF(c, slot, dev, bytes)                                   \
-    do {                                                                \
-        int r_ = sift_buffer((c), (slot), (size_t)(bytes), &(dev).p);   \
-        if (r_ != RTVM_OK) return r_;                                   \
+#define SIFT_BUF(c, slot, ptr, bytes)                                 \
+    do {                                                              \
+        int r_ = sift_buffer((c), (slot), (size_t)(bytes), &(ptr));   \
+        if (r_ != RTVM_OK) return r_;                                 \
     } while (0)
 
-dim3 grid2(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
+// Frame pixels and output arrays of the frames of a batch: slot sb + j feeds work area j.
+__global__ void k_sift_bind(SiftFrame* __restrict__ F, const FrameSlot* __restrict__ slots, int sb, int nb) {
+    const int j = threadIdx.x;
+    if (j >= nb) return;
+    const FrameSlot& S = slots[sb + j];
+    F[j].bgr = S.bgr;
+    F[j].xy = S.feat.xy;
+    F[j].size = S.feat.size;
+    F[j].angle = S.feat.angle;
+    F[j].response = S.feat.response;
+    F[j].octave = S.feat.octave;
+    F[j].desc = reinterpret_cast<float*>(S.feat.desc);
+    F[j].n_out = S.feat.count;
+}
+
+// SIFT detection for the stream path: one work area (pyramids, lists) per frame of a batch.  The
+// areas serve every batch in turn: detection of consecutive batches is queued on one stream.
+struct SiftPipe {
+    SiftGeom g;
+    int n = 0;                      // work areas allocated
+    SiftFrame* d_frames = nullptr;  // [RTVM_MAX_BATCH]
+    void* arena[RTVM_MAX_BATCH] = {};
+    void* work[RTVM_MAX_BATCH] = {};
+};
 
 }  // namespace
+
+int rtvm_sift_pipe_create(rtvm_ctx* c) {
+    SiftPipe* p = new (std::nothrow) SiftPipe;
+    if (!p) RTVM_FAIL(c, RTVM_E_NOMEM, "host allocation failed");
+    c->sift_pipe = p;
+    int r = sift_geometry(c, c->fh, c->fw, p->g);
+    if (r) return r;
+    hipError_t e = hipMalloc((void**)&p->d_frames, sizeof(SiftFrame) * RTVM_MAX_BATCH);
+    if (e != hipSuccess) RTVM_FAIL(c, RTVM_E_NOMEM, "sift: hipMalloc failed: %s", hipGetErrorString(e));
+    return RTVM_OK;
+}
+
+int rtvm_sift_pipe_reserve(rtvm_ctx* c, int n) {
+    SiftPipe* p = (SiftPipe*)c->sift_pipe;
+    if (!p) RTVM_FAIL(c, RTVM_E_STATE, "sift: the context was not created with the SIFT detector");
+    for (int j = p->n; j < n && j < RTVM_MAX_BATCH; j++) {
+        const size_t ab = p->g.total * sizeof(float), wb = sift_work_bytes(c->orb.max_kp);
+        hipError_t e = hipMalloc(&p->arena[j], ab);
+        if (e == hipSuccess) e = hipMalloc(&p->work[j], wb);
+        if (e != hipSuccess)
+            RTVM_FAIL(c, RTVM_E_NOMEM, "sift: hipMalloc(%zu + %zu bytes) for the pyramids of batch frame %d failed: %s", ab, wb, j,
+                      hipGetErrorString(e));
+        SiftFrame f;
+        sift_frame_init(f, p->g, (float*)p->arena[j], (char*)p->work[j]);
+        HIP_TRY(c, hipMemcpy(p->d_frames + j, &f, sizeof(SiftFrame), hipMemcpyHostToDevice));
+        p->n = j + 1;
+    }
+    return RTVM_OK;
+}
+
+void rtvm_sift_pipe_free(rtvm_ctx* c) {
+    SiftPipe* p = (SiftPipe*)c->sift_pipe;
+    if (!p) return;
+    for (int j = 0; j < RTVM_MAX_BATCH; j++) {
+        if (p->arena[j]) (void)hipFree(p->arena[j]);
+        if (p->work[j]) (void)hipFree(p->work[j]);
+    }
+    if (p->d_frames) (void)hipFree(p->d_frames);
+    delete p;
+    c->sift_pipe = nullptr;
+}
+
+// cv2.SIFT_create(nfeatures).detectAndCompute for the frames bound to slots sb .. sb+nb-1: features into slot.feat
+int rtvm_launch_sift(rtvm_ctx* c, int sb, int nb) {
+    SiftPipe* p = (SiftPipe*)c->sift_pipe;
+    if (!p || nb < 1 || nb > p->n) RTVM_FAIL(c, RTVM_E_STATE, "sift: batch of %d frames, work areas for %d", nb, p ? p->n : 0);
+    RTVM_LAUNCH(c, k_sift_bind, dim3(1), dim3(64), 0, p->d_frames, (const FrameSlot*)c->d_slots, sb, nb);
+    return sift_launch(c, p->g, p->d_frames, nb, c->nfeatures, c->orb.max_kp);
+}
 
 extern "C" int rtvm_sift_max_keypoints(int nfeatures) { return nfeatures + 256; }
 
@@ -623,173 +1031,60 @@ extern "C" int rtvm_sift(rtvm_ctx* c, const uint8_t* bgr, int h, int w, int nfea
     if (!c) return RTVM_E_ARG;
     if (!bgr || !n_out || !xy || !size || !angle_deg_out || !response || !octave || !desc)
         RTVM_FAIL(c, RTVM_E_ARG, "sift: null argument");
-    if (h < 16 || w < 16 || h > 8192 || w > 8192 || nfeatures < 1) RTVM_FAIL(c, RTVM_E_ARG, "sift: frame %dx%d, %d features", h, w, nfeatures);
+    if (nfeatures < 1 || nfeatures > SIFT_LIST_CAP - 256) RTVM_FAIL(c, RTVM_E_ARG, "sift: %d features (1..%d)", nfeatures, SIFT_LIST_CAP - 256);
     HIP_TRY(c, hipSetDevice(c->device));
-    const int bh = 2 * h, bw = 2 * w;
-    const int n_oct = cv_round_d(std::log((double)std::min(bw, bh)) / std::log(2.) - 2) + 1;
-    if (n_oct < 1 || n_oct > MAX_OCT) RTVM_FAIL(c, RTVM_E_ARG, "sift: %d octaves", n_oct);
-    double sig[SL + 3];
-    sig[0] = SSIGMA;
-    const double kf = std::pow(2., 1. / SL);
-    for (int i = 1; i < SL + 3; i++) {
-        const double sp = std::pow(kf, (double)(i - 1)) * SSIGMA, st = sp * kf;
-        sig[i] = std::sqrt(st * st - sp * sp);
-    }
-    // one arena: frame, row-pass scratch, Gaussian and DoG pyramids
-    SPyr P;
-    memset(&P, 0, sizeof(P));
-    size_t total = 0;
-    std::vector<size_t> off_gp((size_t)n_oct * (SL + 3)), off_dog((size_t)n_oct * (SL + 2));
-    {
-        int oh = bh, ow = bw;
-        for (int o = 0; o < n_oct; o++) {
-            for (int i = 0; i < SL + 3; i++) {
-                off_gp[o * (SL + 3) + i] = total;
-                P.gp[o * (SL + 3) + i].h = oh, P.gp[o * (SL + 3) + i].w = ow;
-                total += (size_t)oh * ow;
-            }
-            for (int i = 0; i < SL + 2; i++) {
-                off_dog[o * (SL + 2) + i] = total;
-                P.dog[o * (SL + 2) + i].h = oh, P.dog[o * (SL + 2) + i].w = ow;
-                total += (size_t)oh * ow;
-            }
-            oh /= 2, ow /= 2;
-            if (oh < 1 || ow < 1) RTVM_FAIL(c, RTVM_E_ARG, "sift: frame too small for %d octaves", n_oct);
-        }
-    }
-    const size_t scratch_off = total;
-    total += (size_t)bh * bw;
-    const int cand_cap = 1 << 18;
-    Dev arena, frame, keys, count, pyr, cand_out, kp_dev, desc_dev;
-    SIFT_BUF(c, 0, arena, total * sizeof(float));
+    SiftGeom g;
+    int r = sift_geometry(c, h, w, g);
+    if (r) return r;
+    const int out_cap = rtvm_sift_max_keypoints(nfeatures);
+    // buffers: pyramids, frame pixels, lists, frame descriptor, outputs
+    void *arena, *frame, *work, *fdesc, *outs;
+    SIFT_BUF(c, 0, arena, g.total * sizeof(float));
     SIFT_BUF(c, 1, frame, (size_t)h * w * 3);
-    SIFT_BUF(c, 2, keys, (size_t)cand_cap * 8);
-    SIFT_BUF(c, 3, count, 2 * sizeof(int));  // extrema found, keypoints listed
-    SIFT_BUF(c, 4, pyr, sizeof(SPyr));
-    float* A = (float*)arena.p;
-    for (size_t i = 0; i < off_gp.size(); i++) P.gp[i].px = A + off_gp[i];
-    for (size_t i = 0; i < off_dog.size(); i++) P.dog[i].px = A + off_dog[i];
-    float* scratch = A + scratch_off;
-    HIP_TRY(c, hipMemcpyAsync(frame.p, bgr, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(pyr.p, &P, sizeof(SPyr), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(count.p, 0, 2 * sizeof(int), c->stream));
-    // base image: doubled, blurred by sqrt(sigma^2 - 1) (into gp[0] via the last DoG plane as a temporary)
+    SIFT_BUF(c, 2, work, sift_work_bytes(out_cap));
+    SIFT_BUF(c, 4, fdesc, sizeof(SiftFrame));
+    const size_t row = (2 + 1 + 1 + 1 + 1 + 128) * sizeof(float);
+    SIFT_BUF(c, 7, outs, (size_t)out_cap * row + 8 * 256);
+    SiftFrame f;
+    sift_frame_init(f, g, (float*)arena, (char*)work);
+    f.bgr = (const uint8_t*)frame;
     {
-        float* dbl = P.dog[SL + 1].px;  // free until the DoG of octave 0 is formed
-        RTVM_LAUNCH(c, k_sift_base, grid2(bw, bh), dim3(256), 0, (const uint8_t*)frame.p, h, w, dbl);
-        const float sig_diff = std::sqrt(std::max(SSIGMA * SSIGMA - 1.f, 0.01f));
-        const Taps t = gauss_taps((double)sig_diff);
-        RTVM_LAUNCH(c, k_sift_blur_rows, grid2(bw, bh), dim3(256), 0, (const float*)dbl, scratch, bh, bw, t);
-        RTVM_LAUNCH(c, k_sift_blur_cols, grid2(bw, bh), dim3(256), 0, (const float*)scratch, P.gp[0].px, bh, bw, t,
-                    (const float*)nullptr, (float*)nullptr);
+        char* o = (char*)outs;
+        auto take = [&](size_t bytes) {
+            char* p = o;
+            o += (bytes + 255) & ~(size_t)255;
+            return p;
+        };
+        f.xy = (float*)take((size_t)out_cap * 8);
+        f.size = (float*)take((size_t)out_cap * 4);
+        f.angle = (float*)take((size_t)out_cap * 4);
+        f.response = (float*)take((size_t)out_cap * 4);
+        f.octave = (int32_t*)take((size_t)out_cap * 4);
+        f.desc = (float*)take((size_t)out_cap * 512);
+        f.n_out = (int*)take(4);
     }
-    Taps taps[SL + 3];
-    for (int i = 1; i < SL + 3; i++) taps[i] = gauss_taps(sig[i]);
-    const float threshold = (float)(int)std::floor(0.5 * SCONTRAST / SL * 255);
-    // octaves from o_small on are built by one workgroup in one launch
-    int o_small = n_oct;
-    for (int o = n_oct - 1; o >= 1 && P.gp[o * (SL + 3)].h * P.gp[o * (SL + 3)].w <= SMALL_OCTAVE_PX; o--) o_small = o;
-    for (int o = 0; o < o_small; o++) {
-        const int oh = P.gp[o * (SL + 3)].h, ow = P.gp[o * (SL + 3)].w;
-        for (int i = 0; i < SL + 3; i++) {
-            SImg& dst = P.gp[o * (SL + 3) + i];
-            if (i == 0) {
-                if (o == 0) continue;
-                const SImg& src = P.gp[(o - 1) * (SL + 3) + SL];
-                RTVM_LAUNCH(c, k_sift_decimate, grid2(ow, oh), dim3(256), 0, (const float*)src.px, src.w, dst.px, oh, ow);
-            } else {
-                const SImg& src = P.gp[o * (SL + 3) + i - 1];
-                RTVM_LAUNCH(c, k_sift_blur_rows, grid2(ow, oh), dim3(256), 0, (const float*)src.px, scratch, oh, ow, taps[i]);
-                RTVM_LAUNCH(c, k_sift_blur_cols, grid2(ow, oh), dim3(256), 0, (const float*)scratch, dst.px, oh, ow, taps[i],
-                            (const float*)src.px, P.dog[o * (SL + 2) + i - 1].px);
-            }
-        }
-    }
-    if (o_small < n_oct) {
-        TapsAll ta;
-        memset(&ta, 0, sizeof(ta));
-        for (int i = 1; i < SL + 3; i++) ta.t[i] = taps[i];
-        const int lds_px = P.gp[o_small * (SL + 3)].h * P.gp[o_small * (SL + 3)].w;
-        const size_t lds_bytes = (size_t)2 * lds_px * sizeof(float);
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sift_small_octaves),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        RTVM_LAUNCH(c, k_sift_small_octaves, dim3(1), dim3(1024), lds_bytes, (const SPyr*)pyr.p, o_small, n_oct, ta, lds_px);
-    }
-    {
-        ExtremaTiles T;
-        memset(&T, 0, sizeof(T));
-        T.n_oct = 0;
-        for (int o = 0; o < n_oct; o++) {
-            const int oh = P.gp[o * (SL + 3)].h, ow = P.gp[o * (SL + 3)].w;
-            if (!(oh > 2 * SBORDER && ow > 2 * SBORDER)) break;  // the octaves only get smaller
-            const dim3 g = grid2(ow - 2 * SBORDER, oh - 2 * SBORDER);
-            T.tiles_x[o] = (int)g.x;
-            T.tile_start[o + 1] = T.tile_start[o] + (int)(g.x * g.y);
-            T.n_oct = o + 1;
-        }
-        if (T.n_oct > 0)
-            RTVM_LAUNCH(c, k_sift_extrema, dim3(T.tile_start[T.n_oct], SL), dim3(256), 0, (const SPyr*)pyr.p, T, threshold,
-                        (unsigned long long*)keys.p, (int*)count.p, cand_cap);
-    }
-    HIP_TRY(c, hipGetLastError());
-    // refinement of every candidate, queued behind the extrema without a host round trip
-    const int list_cap = 1 << 16, list_first = 1 << 13;
-    SIFT_BUF(c, 5, cand_out, (size_t)list_cap * sizeof(SKp));
-    int* d_list_count = (int*)count.p + 1;
-    RTVM_LAUNCH(c, k_sift_refine, dim3(4096), dim3(64), 0, (const SPyr*)pyr.p, (const unsigned long long*)keys.p,
-                (const int*)count.p, cand_cap, (SKp*)cand_out.p, d_list_count, list_cap);
-    HIP_TRY(c, hipGetLastError());
-    int counts[2] = {0, 0};
-    std::vector<SKp> all(list_first);
-    HIP_TRY(c, hipMemcpyAsync(counts, count.p, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(all.data(), cand_out.p, (size_t)list_first * sizeof(SKp), hipMemcpyDeviceToHost, c->stream));
+    // the descriptor goes through pinned memory: a pageable source would make the copy synchronous
+    SiftFrame* hf = (SiftFrame*)((char*)c->h_pinned + 8192);
+    static_assert(sizeof(SiftFrame) <= 8192, "frame descriptor staging");
+    *hf = f;
+    HIP_TRY(c, hipMemcpyAsync(frame, bgr, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(fdesc, hf, sizeof(SiftFrame), hipMemcpyHostToDevice, c->stream));
+    if ((r = sift_launch(c, g, (const SiftFrame*)fdesc, 1, nfeatures, out_cap))) return r;
+    int* counts = (int*)c->h_pinned;
+    HIP_TRY(c, hipMemcpyAsync(counts, f.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (counts[0] > cand_cap) RTVM_FAIL(c, RTVM_E_NOMEM, "sift: %d scale-space extrema, room for %d", counts[0], cand_cap);
-    if (counts[1] > list_cap) RTVM_FAIL(c, RTVM_E_NOMEM, "sift: %d keypoints before filtering, room for %d", counts[1], list_cap);
-    if (counts[1] > list_first) {
-        all.resize(counts[1]);
-        HIP_TRY(c, hipMemcpyAsync(all.data() + list_first, (const SKp*)cand_out.p + list_first,
-                                  (size_t)(counts[1] - list_first) * sizeof(SKp), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    all.resize(counts[1]);
-    // KeyPointsFilter::removeDuplicatedSorted, retainBest(nfeatures); keypoints that compare equal
-    // are equal in every field, so the order they arrived in does not matter
-    std::sort(all.begin(), all.end(), kp_less);
-    std::vector<SKp> uniq;
-    for (const SKp& q : all)
-        if (uniq.empty() || uniq.back().x != q.x || uniq.back().y != q.y || uniq.back().size != q.size ||
-            uniq.back().angle != q.angle)
-            uniq.push_back(q);
-    if ((int)uniq.size() > nfeatures) {
-        std::vector<float> resp;
-        for (const SKp& q : uniq) resp.push_back(q.response);
-        std::nth_element(resp.begin(), resp.begin() + (nfeatures - 1), resp.end(), std::greater<float>());
-        const float cut = resp[nfeatures - 1];
-        std::vector<SKp> kept;
-        for (const SKp& q : uniq)
-            if (q.response >= cut) kept.push_back(q);
-        uniq.swap(kept);
-    }
-    const int n = std::min((int)uniq.size(), rtvm_sift_max_keypoints(nfeatures));
+    if (counts[0] > SIFT_CAND_CAP) RTVM_FAIL(c, RTVM_E_NOMEM, "sift: %d scale-space extrema, room for %d", counts[0], SIFT_CAND_CAP);
+    if (counts[1] > SIFT_LIST_CAP) RTVM_FAIL(c, RTVM_E_NOMEM, "sift: %d keypoints before filtering, room for %d", counts[1], SIFT_LIST_CAP);
+    const int n = counts[2];
+    if (n < 0 || n > out_cap) RTVM_FAIL(c, RTVM_E_HIP, "sift: device returned keypoint count %d", n);
     *n_out = n;
     if (n == 0) return RTVM_OK;
-    SIFT_BUF(c, 7, kp_dev, (size_t)n * (sizeof(SKp) + 128 * sizeof(float)) + 256);
-    desc_dev.p = (char*)kp_dev.p + (((size_t)n * sizeof(SKp) + 255) & ~(size_t)255);
-    HIP_TRY(c, hipMemcpyAsync(kp_dev.p, uniq.data(), (size_t)n * sizeof(SKp), hipMemcpyHostToDevice, c->stream));
-    RTVM_LAUNCH(c, k_sift_describe, dim3(n), dim3(64), 0, (const SPyr*)pyr.p, (const SKp*)kp_dev.p, n,
-                (float*)desc_dev.p);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(desc, desc_dev.p, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(xy, f.xy, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(size, f.size, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(angle_deg_out, f.angle, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(response, f.response, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(octave, f.octave, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(desc, f.desc, (size_t)n * 512, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (int q = 0; q < n; q++) {
-        const SKp& kp = uniq[q];
-        xy[2 * q] = kp.x * 0.5f;
-        xy[2 * q + 1] = kp.y * 0.5f;
-        size[q] = kp.size * 0.5f;
-        angle_deg_out[q] = kp.angle;
-        response[q] = kp.response;
-        octave[q] = (kp.octave & ~255) | ((kp.octave - 1) & 255);
-    }
     return RTVM_OK;
 }

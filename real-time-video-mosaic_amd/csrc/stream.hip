@@ -315,21 +315,28 @@ __global__ void k_batch_bind(FrameSlot* __restrict__ slots, int sb, int n, Batch
     if (j == 0) slots[sb].prev = prev;
 }
 
-__device__ __forceinline__ void copy_feat(const FeatSet& cur, const FeatSet& prev, int i, int n) {
-    if (i == 0) *prev.count = n;
+// Thread t of the copy: keypoint t / parts, 16-byte words part, part + parts, ... of its descriptor
+// (parts = 1 for 32-byte descriptors: one thread per keypoint; 8 for the 512-byte ones).
+__device__ __forceinline__ void copy_feat(const FeatSet& cur, const FeatSet& prev, int t, int n, int desc_bytes) {
+    const int parts = desc_bytes > 64 ? 8 : 1;
+    const int i = t / parts, part = t - i * parts;
+    if (t == 0) *prev.count = n;
     if (i >= n) return;
-    prev.xy[2 * i] = cur.xy[2 * i];
-    prev.xy[2 * i + 1] = cur.xy[2 * i + 1];
-    prev.size[i] = cur.size[i];
-    prev.angle[i] = cur.angle[i];
-    prev.response[i] = cur.response[i];
-    prev.octave[i] = cur.octave[i];
-    prev.lxy[2 * i] = cur.lxy[2 * i];
-    prev.lxy[2 * i + 1] = cur.lxy[2 * i + 1];
-    const uint4* s = reinterpret_cast<const uint4*>(cur.desc + (size_t)i * 32);
-    uint4* d = reinterpret_cast<uint4*>(prev.desc + (size_t)i * 32);
-    d[0] = s[0];
-    d[1] = s[1];
+    if (part == 0) {
+        prev.xy[2 * i] = cur.xy[2 * i];
+        prev.xy[2 * i + 1] = cur.xy[2 * i + 1];
+        prev.size[i] = cur.size[i];
+        prev.angle[i] = cur.angle[i];
+        prev.response[i] = cur.response[i];
+        prev.octave[i] = cur.octave[i];
+        if (cur.lxy) {
+            prev.lxy[2 * i] = cur.lxy[2 * i];
+            prev.lxy[2 * i + 1] = cur.lxy[2 * i + 1];
+        }
+    }
+    const uint4* s = reinterpret_cast<const uint4*>(cur.desc + (size_t)i * desc_bytes);
+    uint4* d = reinterpret_cast<uint4*>(prev.desc + (size_t)i * desc_bytes);
+    for (int w = part; w < desc_bytes / 16; w += parts) d[w] = s[w];
 }
 
 // kp_prev, des_prev <- features of the last frame of the batch that advanced the state
@@ -337,12 +344,12 @@ __device__ __forceinline__ void copy_feat(const FeatSet& cur, const FeatSet& pre
 // the slot to copy.
 __global__ __launch_bounds__(256) void k_advance_feats(const FrameSlot* __restrict__ slots, int sb,
                                                        const StreamState* __restrict__ st, int which, FeatSet prev,
-                                                       int max_kp) {
+                                                       int max_kp, int desc_bytes) {
     const int j = which >= 0 ? which : st->last_good;
     if (j < 0) return;
     const FeatSet cur = slots[sb + j].feat;
     const int n = min(*cur.count, max_kp);
-    copy_feat(cur, prev, blockIdx.x * 256 + threadIdx.x, n);
+    copy_feat(cur, prev, blockIdx.x * 256 + threadIdx.x, n, desc_bytes);
 }
 
 __global__ void k_state_init(StreamState* st, int row_off, int col_off, int* skip) {
@@ -373,7 +380,8 @@ __global__ void k_state_init(StreamState* st, int row_off, int col_off, int* ski
 int need_stream_ctx(rtvm_ctx* c, const char* who) {
     if (c->fh <= 0 || c->fw <= 0 || c->ch <= 0 || c->cw <= 0)
         RTVM_FAIL(c, RTVM_E_STATE, "%s: context was created without frame/canvas size", who);
-    if (c->detector != RTVM_DET_ORB) RTVM_FAIL(c, RTVM_E_STATE, "%s: the stream path needs the ORB detector", who);
+    if (c->detector != RTVM_DET_ORB && c->detector != RTVM_DET_SIFT)
+        RTVM_FAIL(c, RTVM_E_STATE, "%s: the stream path needs a context created with RTVM_DET_ORB or RTVM_DET_SIFT", who);
     return RTVM_OK;
 }
 
@@ -393,12 +401,28 @@ int bind_batch(rtvm_ctx* c, int sb, const uint8_t* const* ptrs, int n, const Fea
     return RTVM_OK;
 }
 
+// cv2 detectAndCompute of the context's detector for slots sb..sb+n-1 (main.py:111-112, 717-718)
+int launch_detect(rtvm_ctx* c, int sb, int n) {
+    return c->detector == RTVM_DET_SIFT ? rtvm_launch_sift(c, sb, n) : rtvm_launch_orb(c, sb, n);
+}
+
+// kp_prev, des_prev <- features of slot sb + which (which = -1: of the last frame that advanced the state)
+void launch_advance_feats(rtvm_ctx* c, int sb, int which) {
+    const int threads = c->orb.max_kp * (c->desc_bytes > 64 ? 8 : 1);
+    RTVM_LAUNCH(c, k_advance_feats, dim3((threads + 255) / 256), dim3(256), 0, c->d_slots, sb, c->d_state, which,
+                c->feat_prev, c->orb.max_kp, c->desc_bytes);
+}
+
 // detect + match against the previous frame + gather points for slots sb..sb+n-1
 int queue_features(rtvm_ctx* c, int sb, int n) {
     int r;
-    if ((r = rtvm_launch_orb(c, sb, n))) return r;
+    if ((r = launch_detect(c, sb, n))) return r;
     const int cap = c->orb.max_kp;
-    if ((r = rtvm_launch_hamming(c, sb, n, cap, cap, 1))) return r;
+    if (c->detector == RTVM_DET_SIFT) {
+        if ((r = rtvm_launch_l2_slots(c, sb, n, cap))) return r;
+    } else if ((r = rtvm_launch_hamming(c, sb, n, cap, cap, 1))) {
+        return r;
+    }
     RTVM_LAUNCH(c, k_gather_pts, dim3((cap + 255) / 256, n), dim3(256), 0, c->d_slots, sb);
     return RTVM_OK;
 }
@@ -416,9 +440,8 @@ int queue_first_frame(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int col_of
     c->seq = 0;
     for (int k = 0; k < RTVM_NSETS; k++) c->set_live[k] = 0, c->set_owner[k] = 0;
     if ((r = bind_batch(c, 0, &d_bgr, 1, c->feat_prev))) return r;
-    if ((r = rtvm_launch_orb(c, 0, 1))) return r;
-    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
-                c->feat_prev, c->orb.max_kp);
+    if ((r = launch_detect(c, 0, 1))) return r;
+    launch_advance_feats(c, 0, 0);
     if ((r = rtvm_launch_canvas_init(c, d_bgr, row_off, col_off))) return r;
     RTVM_LAUNCH(c, k_state_init, dim3(1), dim3(64), 0, c->d_state, row_off, col_off, c->d_skip);
     HIP_TRY(c, hipGetLastError());
@@ -453,8 +476,7 @@ int queue_back_half(rtvm_ctx* c, int set, int sb, const uint8_t* const* ptrs, in
     if ((r = rtvm_launch_weights(c, n))) return r;
     if ((r = rtvm_launch_commit(c, n))) return r;
     RTVM_LAUNCH(c, k_batch_finish, dim3(1), dim3(64), 0, c->d_state, c->d_snap, n, c->d_rep + slot, host_H ? 1 : 0);
-    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, sb, c->d_state, -1,
-                c->feat_prev, c->orb.max_kp);
+    launch_advance_feats(c, sb, -1);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->stream_main));
     return RTVM_OK;
@@ -869,9 +891,8 @@ extern "C" int rtvm_stream_set_prev(rtvm_ctx* c, const uint8_t* bgr) {
     const uint8_t* p = c->d_bgr;
     c->spec_tail = -1;
     if ((r = bind_batch(c, 0, &p, 1, c->feat_prev))) return r;
-    if ((r = rtvm_launch_orb(c, 0, 1))) return r;
-    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
-                c->feat_prev, c->orb.max_kp);
+    if ((r = launch_detect(c, 0, 1))) return r;
+    launch_advance_feats(c, 0, 0);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RTVM_OK;
@@ -890,8 +911,7 @@ extern "C" int rtvm_frame_commit(rtvm_ctx* c, const double H[9]) {
     HIP_TRY(c, hipMemcpyAsync(c->d_H, hp, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int r;
     if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H))) return r;
-    RTVM_LAUNCH(c, k_advance_feats, dim3((c->orb.max_kp + 255) / 256), dim3(256), 0, c->d_slots, 0, c->d_state, 0,
-                c->feat_prev, c->orb.max_kp);
+    launch_advance_feats(c, 0, 0);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
@@ -909,7 +929,7 @@ static int read_feat(rtvm_ctx* c, const FeatSet& F, int* n_out, float* xy, float
         if (angle_deg) HIP_TRY(c, hipMemcpyAsync(angle_deg, F.angle, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         if (response) HIP_TRY(c, hipMemcpyAsync(response, F.response, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         if (octave) HIP_TRY(c, hipMemcpyAsync(octave, F.octave, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-        if (desc) HIP_TRY(c, hipMemcpyAsync(desc, F.desc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+        if (desc) HIP_TRY(c, hipMemcpyAsync(desc, F.desc, (size_t)n * c->desc_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     *n_out = n;

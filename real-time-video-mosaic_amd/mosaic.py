@@ -55,8 +55,8 @@ class _Batch:
         self.done = 0        # of those, confirmed stitched
 
 
-class _OrbPipeline:
-    """process_frame without waiting (ORB, headless).  Frames go through a ring of pinned host slots
+class _Pipeline:
+    """process_frame without waiting (headless; ORB or SIFT: the context's detector).  Frames go through a ring of pinned host slots
     to the device; detection, matching and RANSAC run in batches of `batch` frames, up to three
     batches ahead (rtvm_batch_detect); when a batch's results arrive the host applies main.py:722-746
     to its frames in order (skip rules, validate, smooth, chain: the owner's own methods and
@@ -282,13 +282,16 @@ class VideMosaic:
             canvas_size = (int(output_height_times * fh), int(output_width_times * fw))
         self._ch, self._cw = int(canvas_size[0]), int(canvas_size[1])
         flags = _ffi.FLAG_WARP_FIXED if warp_mode == "fixed" else 0
-        det = _ffi.DET_ORB if detector_type == "orb" else _ffi.DET_SIFT_MATCH_ONLY
+        # headless: process_frame only enqueues (see the module docstring); pipeline_batch = 0 turns it off
+        self._deferred = not visualize and not show_intermediate and pipeline_batch > 0 and nfeatures <= 7936
+        # SIFT with a display flag set runs stage by stage, the way the reference itself does
+        self._staged_sift = detector_type == "sift" and not self._deferred
+        det = _ffi.DET_ORB if detector_type == "orb" else \
+            (_ffi.DET_SIFT_MATCH_ONLY if self._staged_sift else _ffi.DET_SIFT)
         self._ctx = _ffi.Context(fh, fw, self._ch, self._cw, det, nfeatures, flags, device)
         self._nfeatures = nfeatures
         self._cache = {}
         self._canvas_cache = None
-        # headless + ORB: process_frame only enqueues (see the module docstring); pipeline_batch = 0 turns it off
-        self._deferred = (detector_type == "orb" and not visualize and not show_intermediate and pipeline_batch > 0)
         self._pipeline_batch = int(pipeline_batch)
         self._pipe = None
         self._pumping = False
@@ -317,7 +320,7 @@ class VideMosaic:
         self._sync()
         self.frame_prev = first_image
         self.frame_cur = first_image
-        if self.detector_type == "sift":
+        if self._staged_sift:
             # stage by stage, the way the reference itself runs: features, canvas
             self._sift_prev = self._ctx.sift(first_image, self._nfeatures)
             self._sift_cur = self._sift_prev
@@ -332,7 +335,7 @@ class VideMosaic:
         """main.py:710-759."""
         if self._deferred:
             if self._pipe is None:
-                self._pipe = _OrbPipeline(self, self._pipeline_batch, max(1, self._pipeline_batch // 2))
+                self._pipe = _Pipeline(self, self._pipeline_batch, max(1, self._pipeline_batch // 2))
             frame_cur = np.ascontiguousarray(frame_cur, dtype=np.uint8)
             self._frame_cur = frame_cur
             self._cache.clear()
@@ -344,7 +347,7 @@ class VideMosaic:
                 self._pumping = False
             return
         self.frame_cur = frame_cur
-        if self.detector_type == "sift":
+        if self._staged_sift:
             # main.py:716-731 with the SIFT branch of match(): detect, knn-2 + ratio, RANSAC
             cur = self._ctx.sift(frame_cur, self._nfeatures)
             registered = self._sift_register(self._ctx, cur, self._sift_prev)
@@ -401,7 +404,7 @@ class VideMosaic:
         H = self._glue(frame_cur, n_matches, found, H_relative)
         if H is None:
             return
-        if self.detector_type == "sift":
+        if self._staged_sift:
             self._ctx.warp_blend(frame_cur, H)        # main.py:748
             self._sift_prev = self._sift_cur          # main.py:757-758
         elif staged:
@@ -470,7 +473,7 @@ class VideMosaic:
             for i, frame in enumerate(frames):
                 self.process_frame(frame, first_frame_count + i)
             return
-        sift = self.detector_type == "sift"
+        sift = self._staged_sift
         n = len(frames) if sift else len(frames) - 1   # ORB: the last frame takes the ordinary path
         if workers < 2 or n < 2:
             for i, frame in enumerate(frames):
@@ -577,7 +580,7 @@ class VideMosaic:
         return p.held.ticket, p.last[1]
 
     def _features(self, slot):
-        if self.detector_type == "sift":
+        if self._staged_sift:
             return self._sift_cur if slot == 0 else self._sift_prev
         self._sync()
         key = "feat%d" % slot
@@ -604,7 +607,7 @@ class VideMosaic:
 
     @property
     def matches(self):
-        if self.detector_type == "sift":
+        if self._staged_sift:
             if "matches" not in self._cache:
                 self._cache["matches"] = matches_from_arrays(*self._sift_matches)
             return self._cache["matches"]

@@ -48,22 +48,24 @@ def tricky_video():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch", [1, 4, 8, 32])
-def test_headless_pipeline_equals_frame_by_frame_and_oracle(batch, capsys):
+@pytest.mark.parametrize("detector,batch", [("orb", 1), ("orb", 4), ("orb", 8), ("orb", 32), ("sift", 1), ("sift", 5),
+                                            ("sift", 16)])
+def test_headless_pipeline_equals_frame_by_frame_and_oracle(detector, batch, capsys):
     frames = tricky_video()
-    sync = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=False, show_intermediate=True, nfeatures=500)
+    sync = rtvm.VideMosaic(frames[0], detector_type=detector, visualize=False, show_intermediate=True, nfeatures=500)
     assert not sync._deferred
-    om = OracleMosaic(frames[0], nfeatures=500, glue="numpy")
+    om = OracleMosaic(frames[0], nfeatures=500, glue="numpy", detector=detector)
     for t, f in enumerate(frames[1:], 1):
         sync.process_frame(f, t)
         om.process_frame(f)
     out_sync = capsys.readouterr().out
-    assert out_sync.count("пропуск кадра") == 5 and out_sync.count("Невалидная гомография") >= 5
+    assert out_sync.count("пропуск кадра") == 5 and out_sync.count("Невалидная гомография") >= (5 if detector == "orb" else 1)
     assert np.array_equal(sync.H, om.H) and np.array_equal(sync.output_img_u8(), om.canvas)
     want = state_of(sync)
 
-    vm = rtvm.VideMosaic(frames[0], nfeatures=500, pipeline_batch=batch, **HEADLESS)
-    assert vm._deferred
+    kw = dict(HEADLESS, detector_type=detector)
+    vm = rtvm.VideMosaic(frames[0], nfeatures=500, pipeline_batch=batch, **kw)
+    assert vm._deferred and vm._ctx.detector == (rtvm._ffi.DET_SIFT if detector == "sift" else rtvm._ffi.DET_ORB)
     for t, f in enumerate(frames[1:], 1):
         assert vm.process_frame(f, t) is None
     assert vm.frame_cur is frames[-1]
@@ -73,7 +75,7 @@ def test_headless_pipeline_equals_frame_by_frame_and_oracle(batch, capsys):
     assert_same_state(got, want)
     stats = vm._pipe.stats
     assert stats["frames"] == len(frames) - 1 and stats["frames_detected_again"] > 0
-    if batch >= 4:
+    if batch >= 4 and detector == "orb":
         assert stats["pieces_with_pending_frames"] > 0
     # the object goes on from there, and reads in the middle of a video change nothing
     more = [synth.render_frame(rc.world(), rc.view(dx=5 + 2 * i, dy=-4 - i), FH, FW) for i in range(1, 6)]
@@ -136,3 +138,44 @@ def test_headless_at_720p_matches_oracle_through_a_mask_retry_episode():
     assert np.array_equal(H, om.H)
     assert matches == list(zip(om.matches[0].tolist(), om.matches[1].tolist()))
     assert np.array_equal(canvas, om.canvas)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 4, 7])
+def test_device_stream_with_the_sift_detector_matches_oracle(batch):
+    """Context(detector=DET_SIFT): SIFT features, knn-2 + ratio + sort and RANSAC on the device for the frames of a
+    batch, the reference's rules in k_batch_glue, against the oracle; with a frame without features in mid-batch."""
+    import torch
+    frames, _ = synth.make_video(FH, FW, 12, world_size=(520, 620), seed=6)
+    order = [1, 2, 3, 4, 5, "flat", 6, 7, 8, 9, 10, 11]
+    seq = [np.full_like(frames[0], 90) if s == "flat" else frames[s] for s in order]
+    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), detector=rtvm._ffi.DET_SIFT, nfeatures=400)
+    om = OracleMosaic(frames[0], nfeatures=400, glue="explicit", detector="sift")
+    first = torch.from_numpy(frames[0]).cuda()
+    dev = [torch.from_numpy(f).cuda() for f in seq]
+    torch.cuda.synchronize()
+    ctx.stream_begin(first.data_ptr(), om.w_offset, om.h_offset)
+    f0 = ctx.get_features(1)
+    for k in ("xy", "size", "angle", "response", "octave", "desc"):
+        assert np.array_equal(f0[k], om.feat_prev[k]), k
+    if batch == 1:
+        status = []
+        for d in dev:
+            ctx.process_frame(d.data_ptr())
+            status.append(ctx.frame_status()[0])
+    else:
+        status = ctx.process_video([d.data_ptr() for d in dev], batch=batch).tolist()
+    ref = []
+    for f in seq:
+        om.process_frame(f)
+        ref.append(om.status)
+    assert status == ref and ref.count(1) == 1
+    st, nk, nm, H = ctx.frame_status()
+    assert nm == om.n_matches and nm > 30
+    assert np.array_equal(H, om.H)
+    assert np.array_equal(ctx.canvas_read(), om.canvas)
+    fp = ctx.get_features(1)
+    assert np.array_equal(fp["desc"], om.feat_prev["desc"]) and fp["desc"].dtype == np.float32
+    with pytest.raises(RuntimeError):
+        ctx.orb(frames[0])
+    ctx.close()

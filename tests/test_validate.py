@@ -95,13 +95,16 @@ def test_device_validate_matches_oracle(ctx_small):
 
 
 @pytest.mark.gpu
-def test_rejected_frames_through_the_dropin_match_oracle(capsys):
+@pytest.mark.parametrize("display", [True, False])
+def test_rejected_frames_through_the_dropin_match_oracle(capsys, display):
+    """display: every call completes before it returns; headless: the frame is only taken, flush() settles it."""
     frames, labels = rc.sequence()
-    vm = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=False, show_intermediate=False, nfeatures=500)
+    vm = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=False, show_intermediate=display, nfeatures=500)
     om = OracleMosaic(frames[0], nfeatures=500, glue="numpy")
     texts = {0: "большое смещение", 1: "большое изменение масштаба", 2: "сильные перспективные искажения"}
     for t, (f, lab) in enumerate(zip(frames[1:], labels), 1):
         vm.process_frame(f, t)
+        vm.flush()
         om.process_frame(f)
         out = capsys.readouterr().out
         assert ("Невалидная гомография" in out) == bool(om.status & INVALID), "frame %d" % t
