@@ -170,26 +170,81 @@ __device__ __forceinline__ float col_taps_border(const Taps& t, const float* col
     return a;
 }
 
+// Outputs per thread in the two passes of the blur: a thread keeps the window of its outputs in
+// registers (SB_R + taps - 1 samples), so a sample is loaded once per SB_R outputs instead of once
+// per tap; every output is still its own chain of fused multiply-adds in tap order.  The kernels
+// are compiled per kernel length N (11, 13, 17, 21, 25 for sigma = 1.6 and three layers per
+// octave), so the window loads carry no conditions and are all in flight together; N = 0 is the
+// one-output-per-thread form for any length.
+constexpr int SB_R = 8, SB_C = 16;
+
+template <int N>
 __global__ __launch_bounds__(256) void k_sift_blur_rows(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w,
                                                         Taps t) {
     const SiftFrame& f = F[blockIdx.z];
     const float* __restrict__ src = plane(f, src_id);
     float* __restrict__ dst = plane(f, dst_id);
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const int half = t.n / 2;
-    const float* __restrict__ row = src + (size_t)y * w;
-    float a;
-    if (x >= half && x + half < w) {  // no border in reach: the same sum without the index folding
-        a = row_taps(t, row + (x - half));
-    } else {
-        a = row_taps_border(t, row, x, w);
+    if (N == 0) {
+        const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+        if (x >= w || y >= h) return;
+        const int half = t.n / 2;
+        const float* __restrict__ row = src + (size_t)y * w;
+        dst[(size_t)y * w + x] = (x >= half && x + half < w) ? row_taps(t, row + (x - half)) : row_taps_border(t, row, x, w);
+        return;
     }
-    dst[(size_t)y * w + x] = a;
+    // A wave takes 64 * SB_R consecutive outputs of one row.  Their samples (the segment plus half a
+    // kernel on either side, mirrored at the image border) go through LDS: consecutive lanes load
+    // consecutive floats, then every lane reads the window of its SB_R outputs as 16-byte words.
+    constexpr int NN = N > 0 ? N : 1, half = NN / 2, SEG = 64 * SB_R, STAGE = SEG + 32;
+    static_assert(NN - 1 <= 32 && (SB_R + NN - 1 + 3) / 4 * 4 <= SB_R + 32, "window fits the staged segment");
+    __shared__ __align__(16) float s_seg[4][STAGE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int xs0 = blockIdx.x * SEG, y = blockIdx.y * 4 + wv;
+    const bool row_ok = y < h;
+    if (row_ok) {
+        const auto row = as_global(src + (size_t)y * w);
+        const bool inner = xs0 >= half && xs0 + SEG + half <= w;
+#pragma unroll
+        for (int k = 0; k < (SEG + NN - 1 + 63) / 64; k++) {
+            const int i = lane + 64 * k;
+            if (i < SEG + NN - 1) {
+                const int x = xs0 - half + i;
+                s_seg[wv][i] = row[inner ? x : reflect101s(x, w)];
+            }
+        }
+    }
+    __syncthreads();
+    const int x0 = xs0 + lane * SB_R;
+    if (!row_ok || x0 >= w) return;
+    constexpr int WIN4 = (SB_R + NN - 1 + 3) / 4;
+    float v[4 * WIN4];
+#pragma unroll
+    for (int i = 0; i < WIN4; i++) {
+        const float4 q = *reinterpret_cast<const float4*>(&s_seg[wv][lane * SB_R + 4 * i]);
+        v[4 * i] = q.x, v[4 * i + 1] = q.y, v[4 * i + 2] = q.z, v[4 * i + 3] = q.w;
+    }
+    float a[SB_R];
+#pragma unroll
+    for (int r = 0; r < SB_R; r++) a[r] = t.k[0] * v[r];
+#pragma unroll
+    for (int q = 1; q < NN; q++) {
+#pragma unroll
+        for (int r = 0; r < SB_R; r++) a[r] = __builtin_fmaf(v[r + q], t.k[q], a[r]);
+    }
+    const auto o = as_global(dst + (size_t)y * w + x0);
+    if (x0 + SB_R <= w && (w & 3) == 0) {  // rows start 16-byte aligned: two 16-byte stores
+        store_u4(o, make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])));
+        store_u4(o + 4, make_uint4(__float_as_uint(a[4]), __float_as_uint(a[5]), __float_as_uint(a[6]), __float_as_uint(a[7])));
+    } else {
+#pragma unroll
+        for (int r = 0; r < SB_R; r++)
+            if (x0 + r < w) o[r] = a[r];
+    }
 }
 
 // Column pass; with `below` (the Gaussian layer under the one being made) it also writes the
 // difference of the two layers, dog = this - below, the value a separate subtraction would give.
+template <int N>
 __global__ __launch_bounds__(256) void k_sift_blur_cols(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w,
                                                         Taps t, int below_id, int dog_id) {
     const SiftFrame& f = F[blockIdx.z];
@@ -197,18 +252,58 @@ __global__ __launch_bounds__(256) void k_sift_blur_cols(const SiftFrame* __restr
     float* __restrict__ dst = plane(f, dst_id);
     const float* __restrict__ below = below_id >= 0 ? plane(f, below_id) : nullptr;
     float* __restrict__ dog = below_id >= 0 ? plane(f, dog_id) : nullptr;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const int half = t.n / 2;
-    const float* __restrict__ c0 = src + (size_t)y * w + x;
-    float a;
-    if (y >= half && y + half < h) {  // wave-uniform: a wave is one row
-        a = col_taps(t, c0, w);
-    } else {
-        a = col_taps_border(t, src + x, y, h, w);
+    if (N == 0) {
+        const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+        if (x >= w || y >= h) return;
+        const int half = t.n / 2;
+        const float a = (y >= half && y + half < h) ? col_taps(t, src + (size_t)y * w + x, w) : col_taps_border(t, src + x, y, h, w);
+        dst[(size_t)y * w + x] = a;
+        if (below) dog[(size_t)y * w + x] = a - below[(size_t)y * w + x];
+        return;
     }
-    dst[(size_t)y * w + x] = a;
-    if (below) dog[(size_t)y * w + x] = a - below[(size_t)y * w + x];
+    constexpr int NN = N > 0 ? N : 1, half = NN / 2, SB_R = SB_C;   // outputs per thread down the column
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * SB_R;
+    if (x >= w || y0 >= h) return;
+    float a[SB_R];
+    if (y0 >= half && y0 + SB_R - 1 + half < h) {  // wave-uniform: a wave is SB_R rows
+        float v[SB_R + NN - 1];
+        const auto p = as_global(src + (size_t)(y0 - half) * w + x);
+#pragma unroll
+        for (int i = 0; i < SB_R + NN - 1; i++) v[i] = p[(size_t)i * w];
+        // v[r + half] is the centre of output r
+#pragma unroll
+        for (int r = 0; r < SB_R; r++) a[r] = t.c[0] * v[r + half];
+#pragma unroll
+        for (int q = 1; q <= half; q++) {
+#pragma unroll
+            for (int r = 0; r < SB_R; r++) a[r] = __builtin_fmaf(v[r + half + q] + v[r + half - q], t.c[q], a[r]);
+        }
+        const auto od = as_global(dst + (size_t)y0 * w + x);
+        if (below) {
+            const auto pb = as_global(below + (size_t)y0 * w + x);
+            const auto og = as_global(dog + (size_t)y0 * w + x);
+            float b[SB_R];
+#pragma unroll
+            for (int r = 0; r < SB_R; r++) b[r] = pb[(size_t)r * w];
+#pragma unroll
+            for (int r = 0; r < SB_R; r++) {
+                od[(size_t)r * w] = a[r];
+                og[(size_t)r * w] = a[r] - b[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < SB_R; r++) od[(size_t)r * w] = a[r];
+        }
+        return;
+    }
+    for (int r = 0; r < SB_R; r++) {
+        const int y = y0 + r;
+        if (y >= h) break;
+        const float v = (y >= half && y + half < h) ? col_taps(t, src + (size_t)y * w + x, w) : col_taps_border(t, src + x, y, h, w);
+        const size_t o = (size_t)y * w + x;
+        dst[o] = v;
+        if (below) dog[o] = v - below[o];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sift_decimate(const SiftFrame* __restrict__ F, int src_id, int sw, int dst_id, int h,
@@ -289,6 +384,9 @@ struct ExtremaTiles {
     int tiles_x[MAX_OCT];
 };
 
+// One thread per position of an octave, all SL layers: the centre values decide first (most
+// positions are below the contrast floor in every layer), then the 3 x 3 neighbourhoods of the
+// SL + 2 difference planes are loaded once and serve all layers.
 __global__ __launch_bounds__(256) void k_sift_extrema(const SiftFrame* __restrict__ F, ExtremaTiles T, float threshold, int cap) {
     const SiftFrame& f = F[blockIdx.z];
     const SPyr* __restrict__ P = &f.pyr;
@@ -296,28 +394,51 @@ __global__ __launch_bounds__(256) void k_sift_extrema(const SiftFrame* __restric
     int* __restrict__ count = f.counts;
     int octave = 0;
     while (octave + 1 < T.n_oct && (int)blockIdx.x >= T.tile_start[octave + 1]) octave++;
-    const int tile = blockIdx.x - T.tile_start[octave], layer = blockIdx.y + 1;
+    const int tile = blockIdx.x - T.tile_start[octave];
     const int ty = tile / T.tiles_x[octave], tx = tile - ty * T.tiles_x[octave];
-    const SImg img = P->dog[octave * (SL + 2) + layer];
-    const float* __restrict__ prev = P->dog[octave * (SL + 2) + layer - 1].px;
-    const float* __restrict__ next = P->dog[octave * (SL + 2) + layer + 1].px;
+    const int iw = P->dog[octave * (SL + 2)].w, ih = P->dog[octave * (SL + 2)].h;
     const int c = SBORDER + tx * 64 + (threadIdx.x & 63), r = SBORDER + ty * 4 + (threadIdx.x >> 6);
-    if (c >= img.w - SBORDER || r >= img.h - SBORDER) return;
-    const float val = img.px[(size_t)r * img.w + c];
-    if (!(fabsf(val) > threshold)) return;
-    bool mx = val > 0, mn = val < 0;
-    for (int dy = -1; dy <= 1; dy++)
-        for (int dx = -1; dx <= 1; dx++) {
-            const size_t p = (size_t)(r + dy) * img.w + c + dx;
-            const float v0 = img.px[p], v1 = prev[p], v2 = next[p];
-            mx &= val >= v0 && val >= v1 && val >= v2;
-            mn &= val <= v0 && val <= v1 && val <= v2;
-        }
-    if (!(mx || mn)) return;
-    const int pos = atomicAdd(count, 1);
-    if (pos < cap)
-        keys[pos] = ((unsigned long long)octave << 56) | ((unsigned long long)layer << 48) | ((unsigned long long)r << 24) |
-                    (unsigned long long)c;
+    if (c >= iw - SBORDER || r >= ih - SBORDER) return;
+    gptr<const float> pl[SL + 2];
+#pragma unroll
+    for (int l = 0; l < SL + 2; l++) pl[l] = as_global<const float>(P->dog[octave * (SL + 2) + l].px);
+    const size_t p0 = (size_t)r * iw + c;
+    float ctr[SL];
+    bool any = false;
+#pragma unroll
+    for (int l = 0; l < SL; l++) {
+        ctr[l] = pl[l + 1][p0];
+        any |= fabsf(ctr[l]) > threshold;
+    }
+    if (!any) return;
+    // per plane: the largest and the smallest of the 3 x 3 neighbourhood (the centre included)
+    float hi[SL + 2], lo[SL + 2];
+#pragma unroll
+    for (int l = 0; l < SL + 2; l++) {
+        float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                const float v = pl[l][p0 + (size_t)((long)dy * iw + dx)];
+                mx = fmaxf(mx, v);
+                mn = fminf(mn, v);
+            }
+        hi[l] = mx, lo[l] = mn;
+    }
+#pragma unroll
+    for (int l = 0; l < SL; l++) {
+        const float val = ctr[l];
+        if (!(fabsf(val) > threshold)) continue;
+        // val >= every one of the 27 values  <=>  val >= the largest of them (likewise the smallest)
+        const bool mx = val > 0 && val >= fmaxf(fmaxf(hi[l], hi[l + 1]), hi[l + 2]);
+        const bool mn = val < 0 && val <= fminf(fminf(lo[l], lo[l + 1]), lo[l + 2]);
+        if (!(mx || mn)) continue;
+        const int pos = atomicAdd(count, 1);
+        if (pos < cap)
+            keys[pos] = ((unsigned long long)octave << 56) | ((unsigned long long)(l + 1) << 48) | ((unsigned long long)r << 24) |
+                        (unsigned long long)c;
+    }
 }
 
 __device__ bool solve3(const float a[3][3], const float b[3], float x[3]) {
@@ -522,10 +643,12 @@ __device__ __forceinline__ bool kp_before(const SKp& a, const SKp& b) {
 __global__ __launch_bounds__(256) void k_sift_rank(const SiftFrame* __restrict__ F, int list_cap) {
     const SiftFrame& f = F[blockIdx.y];
     const int n = min(f.counts[1], list_cap);
-    if ((int)blockIdx.x * 256 >= n) return;
+    if ((int)blockIdx.x * 64 >= n) return;
+    // 64 keypoints per workgroup; wave `sub` counts over a quarter of every tile of 256 list entries
     __shared__ SKp s[256];
-    __shared__ unsigned long long s_key[256];
-    const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    __shared__ __align__(16) unsigned long long s_key[256];
+    __shared__ int s_part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, sub = tid >> 6, i = blockIdx.x * 64 + lane;
     const SKp me = f.list[min(i, n - 1)];
     // x and y are positive, so their bit patterns order like the values: one 64-bit compare decides
     // all pairs except those at the same position
@@ -537,23 +660,32 @@ __global__ __launch_bounds__(256) void k_sift_rank(const SiftFrame* __restrict__
             const SKp o = f.list[j0 + tid];
             s[tid] = o;
             s_key[tid] = ((unsigned long long)__float_as_uint(o.x) << 32) | __float_as_uint(o.y);
+        } else {
+            s_key[tid] = ~0ull;   // sorts behind everything, equals nothing
         }
         __syncthreads();
-        const int m = min(256, n - j0);
-        for (int u = 0; u < m; u++) {
-            const unsigned long long ko = s_key[u];
-            if (ko == my_key) {
-                // same position: the remaining fields decide, then the place in the list (records that
-                // compare equal are equal in every field)
-                const SKp o = s[u];
-                const bool lt = kp_before(o, me), gtb = kp_before(me, o);
-                rank += (lt || (!gtb && j0 + u < i)) ? 1 : 0;
-            } else {
-                rank += ko < my_key ? 1 : 0;
+#pragma unroll 8
+        for (int u2 = 0; u2 < 32; u2++) {
+            const int u = 64 * sub + 2 * u2;
+            const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&s_key[u]);
+            const unsigned long long ks[2] = {kk.x, kk.y};
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (ks[e] == my_key) {
+                    // same position: the remaining fields decide, then the place in the list (records that
+                    // compare equal are equal in every field)
+                    const SKp o = s[u + e];
+                    const bool lt = kp_before(o, me), gtb = kp_before(me, o);
+                    rank += (lt || (!gtb && j0 + u + e < i)) ? 1 : 0;
+                } else {
+                    rank += ks[e] < my_key ? 1 : 0;
+                }
             }
         }
     }
-    if (i < n) f.sorted[rank] = me;
+    s_part[sub][lane] = rank;
+    __syncthreads();
+    if (sub == 0 && i < n) f.sorted[s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane]] = me;
 }
 
 // removeDuplicatedSorted keeps a keypoint iff it differs from its predecessor in x, y, size or
@@ -777,6 +909,9 @@ Taps gauss_taps(double sigma) {
 }
 
 dim3 grid3(int w, int h, int nb) { return dim3((w + 63) / 64, (h + 3) / 4, nb); }
+// the two passes of the blur: SB_R outputs per thread along the row / down the column
+dim3 grid_rows(int w, int h, int nb) { return dim3((w + 64 * SB_R - 1) / (64 * SB_R), (h + 3) / 4, nb); }
+dim3 grid_cols(int w, int h, int nb) { return dim3((w + 63) / 64, (h + 4 * SB_C - 1) / (4 * SB_C), nb); }
 
 // What depends on the frame size alone: octaves, plane offsets inside a frame's arena (in
 // floats), filter taps, the tiling of the extrema kernel.
@@ -878,6 +1013,31 @@ void sift_frame_init(SiftFrame& f, const SiftGeom& g, float* arena, char* work) 
     f.gt = (int*)take((size_t)SIFT_LIST_CAP * sizeof(int));
 }
 
+// The two passes of one blur for nb frames: the kernel compiled for the length of `t`, or the
+// general one.
+int sift_blur(rtvm_ctx* c, const SiftFrame* d_frames, int nb, int src, int dst, int h, int w, const Taps& t, int below,
+              int dog) {
+#define SIFT_BLUR_N(N)                                                                                                   \
+    case N:                                                                                                              \
+        RTVM_LAUNCH(c, k_sift_blur_rows<N>, grid_rows(w, h, nb), dim3(256), 0, d_frames, src, PLANE_SCRATCH, h, w, t);   \
+        RTVM_LAUNCH(c, k_sift_blur_cols<N>, grid_cols(w, h, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, dst, h, w, t,    \
+                    below, dog);                                                                                         \
+        break;
+    switch (t.n) {
+        SIFT_BLUR_N(11)
+        SIFT_BLUR_N(13)
+        SIFT_BLUR_N(17)
+        SIFT_BLUR_N(21)
+        SIFT_BLUR_N(25)
+        default:
+            RTVM_LAUNCH(c, k_sift_blur_rows<0>, grid3(w, h, nb), dim3(256), 0, d_frames, src, PLANE_SCRATCH, h, w, t);
+            RTVM_LAUNCH(c, k_sift_blur_cols<0>, grid3(w, h, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, dst, h, w, t, below,
+                        dog);
+    }
+#undef SIFT_BLUR_N
+    return RTVM_OK;
+}
+
 // Detection and description of nb frames (descriptors d_frames[0 .. nb-1], all of geometry g) on
 // the context's current stream.
 int sift_launch(rtvm_ctx* c, const SiftGeom& g, const SiftFrame* d_frames, int nb, int nfeatures, int out_cap) {
@@ -886,8 +1046,7 @@ int sift_launch(rtvm_ctx* c, const SiftGeom& g, const SiftFrame* d_frames, int n
     {
         const int dbl = PLANE_DOG + SL + 1;  // free until the DoG of octave 0 is formed
         RTVM_LAUNCH(c, k_sift_base, grid3(bw, bh, nb), dim3(256), 0, d_frames, g.h, g.w, dbl);
-        RTVM_LAUNCH(c, k_sift_blur_rows, grid3(bw, bh, nb), dim3(256), 0, d_frames, dbl, PLANE_SCRATCH, bh, bw, g.base);
-        RTVM_LAUNCH(c, k_sift_blur_cols, grid3(bw, bh, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, 0, bh, bw, g.base, -1, -1);
+        sift_blur(c, d_frames, nb, dbl, 0, bh, bw, g.base, -1, -1);
     }
     for (int o = 0; o < g.o_small; o++) {
         const int oh = g.oh[o], ow = g.ow[o];
@@ -898,10 +1057,7 @@ int sift_launch(rtvm_ctx* c, const SiftGeom& g, const SiftFrame* d_frames, int n
                 RTVM_LAUNCH(c, k_sift_decimate, grid3(ow, oh, nb), dim3(256), 0, d_frames, (o - 1) * (SL + 3) + SL, g.ow[o - 1],
                             dst, oh, ow);
             } else {
-                RTVM_LAUNCH(c, k_sift_blur_rows, grid3(ow, oh, nb), dim3(256), 0, d_frames, dst - 1, PLANE_SCRATCH, oh, ow,
-                            g.taps[i]);
-                RTVM_LAUNCH(c, k_sift_blur_cols, grid3(ow, oh, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, dst, oh, ow, g.taps[i],
-                            dst - 1, PLANE_DOG + o * (SL + 2) + i - 1);
+                sift_blur(c, d_frames, nb, dst - 1, dst, oh, ow, g.taps[i], dst - 1, PLANE_DOG + o * (SL + 2) + i - 1);
             }
         }
     }
@@ -913,13 +1069,13 @@ int sift_launch(rtvm_ctx* c, const SiftGeom& g, const SiftFrame* d_frames, int n
                     g.lds_px);
     }
     if (g.tiles.n_oct > 0)
-        RTVM_LAUNCH(c, k_sift_extrema, dim3(g.tiles.tile_start[g.tiles.n_oct], SL, nb), dim3(256), 0, d_frames, g.tiles,
+        RTVM_LAUNCH(c, k_sift_extrema, dim3(g.tiles.tile_start[g.tiles.n_oct], 1, nb), dim3(256), 0, d_frames, g.tiles,
                     g.threshold, SIFT_CAND_CAP);
     // refinement of every candidate, queued behind the extrema without a host round trip; then
     // removeDuplicatedSorted + retainBest on the device, then the descriptors of what is kept
     RTVM_LAUNCH(c, k_sift_refine, dim3(nb > 1 ? 2048 : 4096, nb), dim3(64), 0, d_frames, SIFT_CAND_CAP, SIFT_LIST_CAP);
     const dim3 gl(SIFT_LIST_CAP / 256, nb);
-    RTVM_LAUNCH(c, k_sift_rank, gl, dim3(256), 0, d_frames, SIFT_LIST_CAP);
+    RTVM_LAUNCH(c, k_sift_rank, dim3(SIFT_LIST_CAP / 64, nb), dim3(256), 0, d_frames, SIFT_LIST_CAP);
     RTVM_LAUNCH(c, k_sift_mark, gl, dim3(256), 0, d_frames, SIFT_LIST_CAP);
     RTVM_LAUNCH(c, k_sift_compact, gl, dim3(256), 0, d_frames, SIFT_LIST_CAP, nfeatures, out_cap);
     RTVM_LAUNCH(c, k_sift_describe, dim3(out_cap, nb), dim3(64), 0, d_frames);
