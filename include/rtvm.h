@@ -56,7 +56,11 @@ enum {
     RTVM_FLAG_WARP_FIXED = 1 << 0, /* warpPerspective arithmetic of OpenCV <= 4.10
                                       (1/32-pixel fixed point); default is the
                                       fp32 arithmetic of OpenCV >= 4.11 */
-    RTVM_FLAG_MATCH_LEGACY = 1 << 1, /* reserved: one-sided cross-check of OpenCV < 4.2 */
+    RTVM_FLAG_MATCH_LEGACY = 1 << 1, /* cross-check of BFMatcher before OpenCV 4.2 / 3.4.9: a query is matched
+                                        with the nearest of the train rows whose nearest query it is, whether or
+                                        not that row is the query's own nearest; default is the mutual rule */
+    RTVM_FLAG_GRAY_LEGACY = 1 << 3,  /* cvtColor(BGR2GRAY) with the 14-bit coefficients of OpenCV <= 3.x
+                                        ((B*1868 + G*9617 + R*4899 + 8192) >> 14); default the 15-bit ones of 4.x */
     RTVM_FLAG_SINGLE_STREAM = 1 << 2 /* the context owns one HIP stream: rtvm_process_batch
                                         queues everything on it (no overlap of consecutive
                                         batches).  Also the choice for contexts that only serve

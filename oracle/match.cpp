@@ -72,6 +72,36 @@ extern "C" int rtvm_oracle_match_hamming_xcheck(const uint8_t* q, int nq, const 
     return 0;
 }
 
+// The same call under BFMatcher's cross-check before OpenCV 4.2 / 3.4.9 (the match is taken from
+// the train -> query direction): query i gets the nearest of the train rows whose nearest query is
+// i (lowest train index on ties); queries that are no train row's nearest emit nothing.
+extern "C" int rtvm_oracle_match_hamming_legacy(const uint8_t* q, int nq, const uint8_t* t, int nt,
+                                                int32_t* qidx, int32_t* tidx, int32_t* dist, int* m_out, int sorted) {
+    if (nq < 0 || nt < 0 || !m_out) return -1;
+    std::vector<int> ridx, rdst;
+    nearest(t, nt, q, nq, ridx, rdst);
+    struct M {
+        int q, t, d;
+    };
+    std::vector<M> best(nq, M{-1, -1, 0x7fffffff});
+    for (int j = 0; j < nt; j++) {
+        const int i = ridx[j];
+        if (i >= 0 && rdst[j] < best[i].d) best[i] = M{i, j, rdst[j]};
+    }
+    std::vector<M> ms;
+    for (int i = 0; i < nq; i++)
+        if (best[i].t >= 0) ms.push_back(best[i]);
+    if (sorted)
+        std::stable_sort(ms.begin(), ms.end(), [](const M& a, const M& b) { return a.d < b.d; });
+    for (size_t k = 0; k < ms.size(); k++) {
+        qidx[k] = ms[k].q;
+        tidx[k] = ms[k].t;
+        dist[k] = ms[k].d;
+    }
+    *m_out = (int)ms.size();
+    return 0;
+}
+
 // main.py:34,688: BFMatcher() (NORM_L2, no cross-check).knnMatch(q, t, k=2).
 // Distance is sqrt of the float32 sum of squared differences; the two smallest
 // per query in ascending order, earlier train index first on ties (insertion

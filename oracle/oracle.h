@@ -30,8 +30,10 @@ extern "C" {
 extern int rtvm_oracle_nthreads;
 int rtvm_oracle_set_threads(int n);
 
-/* main.py:111,717  cv2.cvtColor(BGR2GRAY) */
+/* main.py:111,717  cv2.cvtColor(BGR2GRAY); rtvm_oracle_set_gray_legacy(1) switches every gray conversion of the
+ * detectors to the 14-bit coefficients of OpenCV <= 3.x (returns the previous setting) */
 void rtvm_oracle_gray(const uint8_t* bgr, int h, int w, uint8_t* gray);
+int rtvm_oracle_set_gray_legacy(int on);
 
 /* ORB parameters that are not fixed by the reference call site are OpenCV's defaults. */
 int rtvm_oracle_max_keypoints(int nfeatures);
@@ -51,6 +53,10 @@ int rtvm_oracle_sift(const uint8_t* bgr, int h, int w, int nfeatures, int* n_out
 
 /* main.py:37,695 (+698 when sorted != 0) */
 int rtvm_oracle_match_hamming_xcheck(const uint8_t* q, int nq, const uint8_t* t, int nt,
+                                     int32_t* qidx, int32_t* tidx, int32_t* dist, int* m_out,
+                                     int sorted);
+/* the same under the one-sided cross-check of BFMatcher before OpenCV 4.2 */
+int rtvm_oracle_match_hamming_legacy(const uint8_t* q, int nq, const uint8_t* t, int nt,
                                      int32_t* qidx, int32_t* tidx, int32_t* dist, int* m_out,
                                      int sorted);
 /* main.py:34,688 */

@@ -332,11 +332,21 @@ extern "C" void rtvm_oracle_set_orb_pattern(const int32_t* pattern1024) {
     g_pattern_ok = true;
 }
 
-// cvtColor(BGR2GRAY), 8-bit: (B*3735 + G*19235 + R*9798 + 16384) >> 15
+// cvtColor(BGR2GRAY), 8-bit: (B*3735 + G*19235 + R*9798 + 16384) >> 15 (OpenCV 4.x), or with the
+// 14-bit coefficients of OpenCV <= 3.x when rtvm_oracle_set_gray_legacy(1) was called:
+// (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+int rtvm_oracle_gray_legacy = 0;
+extern "C" int rtvm_oracle_set_gray_legacy(int on) {
+    const int old = rtvm_oracle_gray_legacy;
+    rtvm_oracle_gray_legacy = on ? 1 : 0;
+    return old;
+}
 extern "C" void rtvm_oracle_gray(const uint8_t* bgr, int h, int w, uint8_t* gray) {
+    const int cb = rtvm_oracle_gray_legacy ? 1868 : 3735, cg = rtvm_oracle_gray_legacy ? 9617 : 19235;
+    const int cr = rtvm_oracle_gray_legacy ? 4899 : 9798, sh = rtvm_oracle_gray_legacy ? 14 : 15;
 #pragma omp parallel for schedule(static) num_threads(rtvm_oracle_nthreads)
     for (size_t p = 0; p < (size_t)h * w; p++)
-        gray[p] = (uint8_t)((bgr[3 * p] * 3735 + bgr[3 * p + 1] * 19235 + bgr[3 * p + 2] * 9798 + (1 << 14)) >> 15);
+        gray[p] = (uint8_t)((bgr[3 * p] * cb + bgr[3 * p + 1] * cg + bgr[3 * p + 2] * cr + (1 << (sh - 1))) >> sh);
 }
 
 extern "C" int rtvm_oracle_max_keypoints(int nfeatures) { return nfeatures + 64 * NLEVELS; }

@@ -17,7 +17,9 @@ OK = 0
 E_ARG, E_HIP, E_NOMEM, E_DEGENERATE, E_STATE = -1, -2, -3, -4, -5
 DET_ORB, DET_SIFT_MATCH_ONLY, DET_SIFT = 0, 1, 2
 FLAG_WARP_FIXED = 1
+FLAG_MATCH_LEGACY = 2
 FLAG_SINGLE_STREAM = 4
+FLAG_GRAY_LEGACY = 8
 FRAME_FEW_MATCHES, FRAME_NO_HOMOGRAPHY, FRAME_INVALID_H = 1, 2, 4
 PENDING_NONE, PENDING_SKIPPED_FRAME, PENDING_MASK, PENDING_VOID = 0, 1, 2, 3
 

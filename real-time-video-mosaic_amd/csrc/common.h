@@ -346,6 +346,14 @@ struct rtvm_ctx {
     void* prof;            // timing records (prof.hip)
 };
 
+// cvtColor(BGR2GRAY) in fixed point: (B*cb + G*cg + R*cr + half) >> shift
+struct GrayCoef {
+    int cb, cg, cr, shift;
+};
+static inline GrayCoef rtvm_gray_coef(const rtvm_ctx* c) {
+    return (c->flags & RTVM_FLAG_GRAY_LEGACY) ? GrayCoef{1868, 9617, 4899, 14} : GrayCoef{3735, 19235, 9798, 15};
+}
+
 #define RTVM_FAIL(ctx, code, ...)                         \
     do {                                                  \
         snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); \

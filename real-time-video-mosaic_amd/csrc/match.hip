@@ -71,8 +71,22 @@ __global__ __launch_bounds__(256) void k_match_init(const FrameSlot* __restrict_
 // Single workgroup: mutual-NN filter, order-preserving compaction (ascending
 // query index) and, when sorted != 0, a bitonic sort of (dist << 16 | position)
 // keys, which is the stable sort by distance of main.py:698.
-__global__ __launch_bounds__(1024) void k_xcheck_compact(const FrameSlot* __restrict__ slots, int sb, int sorted) {
+// legacy != 0: the cross-check of BFMatcher before OpenCV 4.2: query i is matched with the
+// nearest (lowest index on ties) of the train rows whose nearest query is i; a query's own
+// nearest train row plays no part.  The per-query keys are rebuilt from the per-train keys
+// (the distance of train row j to its nearest query i is d(i, j)).
+__global__ __launch_bounds__(1024) void k_xcheck_compact(const FrameSlot* __restrict__ slots, int sb, int sorted, int legacy) {
     const FrameSlot& S = slots[sb + blockIdx.x];
+    if (legacy) {
+        const int nq = *S.feat.count, nt = *S.prev.count;
+        for (int i = threadIdx.x; i < nq; i += 1024) S.qkey[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (int j = threadIdx.x; j < nt; j += 1024) {
+            const uint32_t kt = S.tkey[j];
+            if (kt != 0xFFFFFFFFu) atomicMin(&S.qkey[kt & 0xFFFFu], (kt & 0xFFFF0000u) | (uint32_t)j);
+        }
+        __syncthreads();
+    }
     const uint32_t* __restrict__ qkey = S.qkey;
     const uint32_t* __restrict__ tkey = S.tkey;
     const int* __restrict__ nq_p = S.feat.count;
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(1024) void k_xcheck_compact(const FrameSlot* __rest
         if (i < nq && nt > 0) {
             kq = qkey[i];
             const uint32_t j = kq & 0xFFFFu;
-            ok = (tkey[j] & 0xFFFFu) == (uint32_t)i;
+            ok = legacy ? kq != 0xFFFFFFFFu : (tkey[j] & 0xFFFFu) == (uint32_t)i;
         }
         const unsigned long long bal = __ballot(ok);
         const int wrank = __popcll(bal & ((1ull << lane) - 1ull));
@@ -165,7 +179,8 @@ int rtvm_launch_hamming(rtvm_ctx* c, int sb, int nb, int cap_q, int cap_t, int s
         const int tiles = (nfill + 63) / 64;
         RTVM_LAUNCH(c, k_hamming_argmin, dim3(tiles, tiles, 2 * nb), dim3(64), 0, c->d_slots, sb);
     }
-    RTVM_LAUNCH(c, k_xcheck_compact, dim3(nb), dim3(1024), 0, c->d_slots, sb, sorted);
+    RTVM_LAUNCH(c, k_xcheck_compact, dim3(nb), dim3(1024), 0, c->d_slots, sb, sorted,
+                (c->flags & RTVM_FLAG_MATCH_LEGACY) ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
@@ -264,7 +279,7 @@ extern "C" int rtvm_match_hamming_xcheck_noalloc(const uint8_t* q_dev, int nq, c
         const int tiles = (nfill + 63) / 64;
         hipLaunchKernelGGL(k_hamming_argmin, dim3(tiles, tiles, 2), dim3(64), 0, stream, slots, 0);
     }
-    hipLaunchKernelGGL(k_xcheck_compact, dim3(1), dim3(1024), 0, stream, slots, 0, sorted ? 1 : 0);
+    hipLaunchKernelGGL(k_xcheck_compact, dim3(1), dim3(1024), 0, stream, slots, 0, sorted ? 1 : 0, 0);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_noalloc_err, sizeof(g_noalloc_err), "match_hamming_xcheck_noalloc: launch failed: %s", hipGetErrorString(e));

@@ -39,7 +39,8 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // ------------------------------------------------------------------ gray / pyramid
 // Also clears the slot's candidate counters and score histograms for the FAST stage.
 __global__ __launch_bounds__(256) void k_gray(const FrameSlot* __restrict__ slots, int sb, unsigned off0, int w, int h,
-                                              int pitch) {
+                                              int pitch, GrayCoef gc) {
+    const uint32_t cb = gc.cb, cg = gc.cg, cr = gc.cr, half = 1u << (gc.shift - 1), sh = gc.shift;
     const FrameSlot& S = slots[sb + blockIdx.z];
     const uint8_t* __restrict__ bgr = S.bgr;
     uint8_t* __restrict__ out = S.pyr + off0;
@@ -55,14 +56,14 @@ __global__ __launch_bounds__(256) void k_gray(const FrameSlot* __restrict__ slot
         const uint32_t b0 = v[0] & 255, g0 = (v[0] >> 8) & 255, r0 = (v[0] >> 16) & 255, b1 = v[0] >> 24;
         const uint32_t g1 = v[1] & 255, r1 = (v[1] >> 8) & 255, b2 = (v[1] >> 16) & 255, g2 = v[1] >> 24;
         const uint32_t r2 = v[2] & 255, b3 = (v[2] >> 8) & 255, g3 = (v[2] >> 16) & 255, r3 = v[2] >> 24;
-        const uint32_t y0 = (b0 * 3735 + g0 * 19235 + r0 * 9798 + (1 << 14)) >> 15;
-        const uint32_t y1 = (b1 * 3735 + g1 * 19235 + r1 * 9798 + (1 << 14)) >> 15;
-        const uint32_t y2 = (b2 * 3735 + g2 * 19235 + r2 * 9798 + (1 << 14)) >> 15;
-        const uint32_t y3 = (b3 * 3735 + g3 * 19235 + r3 * 9798 + (1 << 14)) >> 15;
+        const uint32_t y0 = (b0 * cb + g0 * cg + r0 * cr + half) >> sh;
+        const uint32_t y1 = (b1 * cb + g1 * cg + r1 * cr + half) >> sh;
+        const uint32_t y2 = (b2 * cb + g2 * cg + r2 * cr + half) >> sh;
+        const uint32_t y3 = (b3 * cb + g3 * cg + r3 * cr + half) >> sh;
         *reinterpret_cast<uint32_t*>(out + (size_t)y * pitch + x) = y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
     } else {
         for (int i = 0; x + i < w; i++)
-            out[(size_t)y * pitch + x + i] = (uint8_t)((p[3 * i] * 3735 + p[3 * i + 1] * 19235 + p[3 * i + 2] * 9798 + (1 << 14)) >> 15);
+            out[(size_t)y * pitch + x + i] = (uint8_t)((p[3 * i] * cb + p[3 * i + 1] * cg + p[3 * i + 2] * cr + half) >> sh);
     }
 }
 
@@ -780,7 +781,7 @@ int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
     const OrbDev& P = c->orb;
     const FrameSlot* sl = c->d_slots;
     RTVM_LAUNCH(c, k_gray, dim3((P.w[0] + 1023) / 1024, P.h[0], nb), dim3(256), 0, sl, sb, P.off[0], P.w[0], P.h[0],
-                P.pitch[0]);
+                P.pitch[0], rtvm_gray_coef(c));
     for (int l = 1; l < RTVM_NLEVELS; l++)
         RTVM_LAUNCH(c, k_resize, dim3((P.w[l] + 63) / 64, (P.h[l] + 15) / 16, nb), dim3(256), 0, sl, sb, P.off[l - 1],
                     P.pitch[l - 1], P.h[l - 1], P.off[l], P.w[l], P.h[l], P.pitch[l], c->d_xofs + P.xtab_off[l],

@@ -96,7 +96,7 @@ __device__ __forceinline__ int reflect101s(int p, int n) {
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_sift_base(const SiftFrame* __restrict__ F, int h, int w, int dst_id) {
+__global__ __launch_bounds__(256) void k_sift_base(const SiftFrame* __restrict__ F, int h, int w, int dst_id, GrayCoef gc) {
     const SiftFrame& f = F[blockIdx.z];
     const uint8_t* __restrict__ bgr = f.bgr;
     float* __restrict__ out = plane(f, dst_id);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_sift_base(const SiftFrame* __restrict__
     const int x1 = min(sx + 1, w - 1), y1 = min(sy + 1, h - 1);
     auto gray = [&](int yy, int xx) {
         const uint8_t* p = bgr + ((size_t)yy * w + xx) * 3;
-        return (float)((p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15);
+        return (float)((p[0] * gc.cb + p[1] * gc.cg + p[2] * gc.cr + (1 << (gc.shift - 1))) >> gc.shift);
     };
     const float a1 = fx, a0 = 1.f - a1, b1 = fy, b0 = 1.f - b1;
     const float r0 = gray(sy, sx) * a0 + gray(sy, x1) * a1;
@@ -1045,7 +1045,7 @@ int sift_launch(rtvm_ctx* c, const SiftGeom& g, const SiftFrame* d_frames, int n
     // base image: doubled, blurred by sqrt(sigma^2 - 1) (into gp[0] via the last DoG plane of octave 0 as a temporary)
     {
         const int dbl = PLANE_DOG + SL + 1;  // free until the DoG of octave 0 is formed
-        RTVM_LAUNCH(c, k_sift_base, grid3(bw, bh, nb), dim3(256), 0, d_frames, g.h, g.w, dbl);
+        RTVM_LAUNCH(c, k_sift_base, grid3(bw, bh, nb), dim3(256), 0, d_frames, g.h, g.w, dbl, rtvm_gray_coef(c));
         sift_blur(c, d_frames, nb, dbl, 0, bh, bw, g.base, -1, -1);
     }
     for (int o = 0; o < g.o_small; o++) {

@@ -53,6 +53,27 @@ def match_hamming(q, t, sorted_by_distance=False):
     return qi[:k].copy(), ti[:k].copy(), di[:k].copy()
 
 
+def match_hamming_legacy(q, t, sorted_by_distance=False):
+    """The cross-check of BFMatcher before OpenCV 4.2 (RTVM_FLAG_MATCH_LEGACY)."""
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    nq, nt = len(q), len(t)
+    qi = np.empty(max(nq, 1), np.int32)
+    ti = np.empty(max(nq, 1), np.int32)
+    di = np.empty(max(nq, 1), np.int32)
+    m = C.c_int(0)
+    rc = lib().rtvm_oracle_match_hamming_legacy(_p(q), nq, _p(t), nt, _p(qi), _p(ti), _p(di), C.byref(m),
+                                                int(sorted_by_distance))
+    assert rc == 0
+    k = m.value
+    return qi[:k].copy(), ti[:k].copy(), di[:k].copy()
+
+
+def set_gray_legacy(on):
+    """Gray conversion of the detectors with the coefficients of OpenCV <= 3.x; returns the previous setting."""
+    return lib().rtvm_oracle_set_gray_legacy(int(bool(on)))
+
+
 def match_l2_knn2(q, t):
     q = np.ascontiguousarray(q, np.float32)
     t = np.ascontiguousarray(t, np.float32)

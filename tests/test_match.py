@@ -193,3 +193,45 @@ def test_hip_l2_knn2_needs_two_train_rows(ctx_small):
     q, t = sift_like(1, 5, 5)
     with pytest.raises(rtvm.RtvmError):
         ctx_small.match_l2_knn2(q, t[:1])
+
+
+def test_legacy_cross_check_oracle_semantics():
+    """Before OpenCV 4.2 a query was matched with the nearest of the train rows that chose it, whether or not that row
+    was the query's own nearest: a superset of the queries of the mutual rule, with the same pairs where both apply."""
+    rng = np.random.default_rng(23)
+    t = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    q = t[rng.integers(0, 300, 260)].copy()
+    q ^= (rng.random(q.shape) < 0.08).astype(np.uint8) * np.uint8(1 << 3)
+    mq, mt, md = orc.match_hamming(q, t)
+    lq, lt, ld = orc.match_hamming_legacy(q, t)
+    assert set(mq.tolist()) < set(lq.tolist())            # strictly more queries matched
+    mutual = dict(zip(mq.tolist(), zip(mt.tolist(), md.tolist())))
+    legacy = dict(zip(lq.tolist(), zip(lt.tolist(), ld.tolist())))
+    assert all(legacy[i] == mutual[i] for i in mutual)
+    # brute force: per train row its nearest query (first minimum), per query the nearest of those rows
+    D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    owner = D.argmin(axis=0)
+    for i in range(len(q)):
+        js = np.nonzero(owner == i)[0]
+        if len(js) == 0:
+            assert i not in legacy
+        else:
+            j = js[np.argmin(D[i, js])]
+            assert legacy[i] == (int(j), int(D[i, j]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nt,seed", [(260, 300, 23), (1000, 1000, 3), (65, 4097, 4), (700, 1, 5), (0, 40, 6)])
+def test_hip_hamming_legacy_cross_check_bit_exact(nq, nt, seed):
+    import rtvm
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    q = t[rng.integers(0, nt, nq)].copy() if nq else np.zeros((0, 32), np.uint8)
+    q ^= (rng.random(q.shape) < 0.08).astype(np.uint8) * np.uint8(1 << 3)
+    ctx = rtvm.Context(flags=rtvm._ffi.FLAG_MATCH_LEGACY)
+    for srt in (False, True):
+        got = ctx.match_hamming(q, t, sorted_by_distance=srt)
+        want = orc.match_hamming_legacy(q, t, srt)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+    ctx.close()

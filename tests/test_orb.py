@@ -117,3 +117,27 @@ def test_hip_orb_many_ties():
     got, ref = c.orb(f), orc.orb(f, 60)
     _check_equal(got, ref)
     c.close()
+
+
+@pytest.mark.gpu
+def test_hip_legacy_gray_coefficients_match_oracle():
+    """RTVM_FLAG_GRAY_LEGACY: cvtColor(BGR2GRAY) with the 14-bit coefficients of OpenCV <= 3.x, and the ORB features
+    detected on that gray image, against the oracle in the same mode."""
+    import rtvm
+    frames, _ = rtvm.synth.make_video(240, 320, 1, world_size=(520, 620), seed=11)
+    f = frames[0]
+    ctx = rtvm.Context(240, 320, 480, 384, nfeatures=500, flags=rtvm._ffi.FLAG_GRAY_LEGACY)
+    plain = rtvm.Context(240, 320, 480, 384, nfeatures=500)
+    before = orc.set_gray_legacy(True)
+    try:
+        want_gray, want = orc.gray(f), orc.orb(f, 500)
+    finally:
+        orc.set_gray_legacy(before)
+    got_gray, got = ctx.gray(f), ctx.orb(f)
+    assert np.array_equal(got_gray, want_gray)
+    diff = got_gray.astype(int) - plain.gray(f).astype(int)
+    assert np.abs(diff).max() == 1 and 0 < (diff != 0).mean() < 0.5      # the two conversions differ by one level here and there
+    for k in ("xy", "size", "angle", "response", "octave", "desc"):
+        assert np.array_equal(got[k], want[k]), k
+    ctx.close()
+    plain.close()

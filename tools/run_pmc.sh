@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs on the GPU box: the rocprofv3 counter passes (one counter per run) over the calibration program and over the
+# 48-frame pipeline workload, then the kernel trace of the default bench.  Results under gpurun_out/r2/.
+set -u
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/r2
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+step() {  # name, limit, command...
+    local name=$1 limit=$2; shift 2
+    timeout -s KILL "$limit" "$@" > "$OUT/$name.log" 2>&1
+    local rc=$?
+    echo "[$name] exit $rc"; tail -n 2 "$OUT/$name.log"
+    [ $rc -eq 0 ] || exit $rc
+}
+step pmc_calib_fetch 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_calib_fetch" --output-format csv -- "$ROOT/tools/bin/pmc_calib"
+step pmc_calib_write 120 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_calib_write" --output-format csv -- "$ROOT/tools/bin/pmc_calib"
+step pmc_fetch 240 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" --output-format csv -- python3 "$ROOT/tools/pmc_run.py" 48 720p_orb1000
+step pmc_write 240 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" --output-format csv -- python3 "$ROOT/tools/pmc_run.py" 48 720p_orb1000
+cd "$ROOT"
+python3 tools/pmc_traffic.py "$OUT/r2_pmc_traffic.json" 48 720p_orb1000 "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_calib_fetch" "$OUT/pmc_calib_write" || exit 1
+echo "traffic summary written"
