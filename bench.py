@@ -26,6 +26,7 @@ import time
 
 import numpy as np
 
+T_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 rtvm = importlib.import_module("real-time-video-mosaic_amd")
@@ -366,6 +367,12 @@ def leg_host_ring(args, cfg, frames, local_rank, T, B):
     return leg
 
 
+def progress(msg):
+    """A line on stderr per phase: a run that prints nothing for minutes is taken to be hung."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -436,9 +443,11 @@ def main():
     else:
         side_h, side_w = fh + 2 * T + 256, fw + 2 * T + 256
         Gs = synth.camera_path(T, 64.0, side_h - fh - 64.0, seed=seed + 2)
+    progress("synthetic world %d x %d, %d frames" % (side_h, side_w, T))
     world_img = synth.make_world(side_h, side_w, seed=seed)
     frames = synth.render_video_torch(world_img, Gs, fh, fw, dev)
     torch.cuda.synchronize()
+    progress("frames resident in HBM")
 
     flags = rtvm._ffi.FLAG_WARP_FIXED if args.warp_mode == "fixed" else 0
     if args.single_stream:
@@ -469,6 +478,7 @@ def main():
     # batches run beside it on streams of their own.  The roofline kernel is the main-stream kernel with the
     # largest summed time over these K frames; the longest kernel of any stream is named next to it.
     restart()
+    progress("instrumented pass")
     ctx.profile_start(None)
     _, vstats1 = run(1 + W, K)
     table = merge_variants(ctx.profile_stop())
@@ -484,6 +494,7 @@ def main():
 
     # --- pass 2, the timed region: exactly frames 1+W .. W+K after W warm-up frames; only the dominant kernel
     # carries HIP events (on the stream it is launched on)
+    progress("timed pass")
     restart()
     ctx.profile_start(dominant)
     if world > 1:
@@ -549,6 +560,7 @@ def main():
                               "time of all main-stream kernels, K frames of the instrumented pass"}
         extras = {}
         solo = world == 1
+        progress("timed pass done: %.1f frames/s; host-frame legs" % (K / elapsed))
         if args.dropin_frames > 0 and solo:
             extras["dropin_pcie_inclusive"] = leg_dropin(args, cfg, frames, local_rank, T)
         if args.sift_frames > 0 and solo:
@@ -559,6 +571,7 @@ def main():
         if args.cpu_frames > 0 and solo:   # reported at N = 1 only
             orc, _ = oracle_modules()
             n1 = args.cpu_frames
+            progress("CPU baseline, %d frames on one thread" % n1)
             frames_np = frames[:2 * n1 + 1].cpu().numpy()
             fps_cpu, om = cpu_baseline(frames_np, cfg, n1, 1, "sift" if sift else "orb")
             cpu = {"value": fps_cpu, "unit": "frames/s", "cores": 1, "kind": "port",
@@ -574,14 +587,16 @@ def main():
                       "statuses_equal": bool(st_p.tolist() == [0] * n1 and om.status == 0)}
             threads = orc.default_threads()
             n2 = min(2 * n1, len(frames_np) - 1)
+            progress("parity checked; CPU baseline, %d frames on %d threads" % (n2, threads))
             fps_all, _ = cpu_baseline(frames_np, cfg, n2, threads, "sift" if sift else "orb")
             cpu_all = {"value": fps_all, "unit": "frames/s", "cores": threads, "kind": "port",
                        "host_cpus": os.cpu_count(),
                        "sample": "first %d frames, the restatement's per-pixel / per-row / per-descriptor loops on "
                                  "%d OpenMP threads (the box's CPU share; same results as one thread)" % (n2, threads)}
         out = {
-            "metric": "stitched frames/sec @720p ORB-1000 on 1xMI355X; warp GB/s vs HBM roofline" if not sift else
-                      "stitched frames/sec with the SIFT detector (knn-2 L2 + ratio) on 1xMI355X",
+            "metric": "stitched frames/sec @720p ORB-1000 on 1xMI355X; warp GB/s vs HBM roofline" if args.config == "720p_orb1000"
+                      else "stitched frames/sec with the SIFT detector (knn-2 L2 + ratio) on 1xMI355X, %s" % args.config if sift
+                      else "stitched frames/sec on 1xMI355X, %s; warp GB/s vs HBM roofline" % args.config,
             "value": world * K / elapsed, "unit": "frames/s", "n_gpus": 1 if same_gpu else world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",

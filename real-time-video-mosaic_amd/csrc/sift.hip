@@ -173,7 +173,7 @@ __device__ __forceinline__ float col_taps_border(const Taps& t, const float* col
 // Outputs per thread in the two passes of the blur: a thread keeps the window of its outputs in
 // registers (SB_R + taps - 1 samples), so a sample is loaded once per SB_R outputs instead of once
 // per tap; every output is still its own chain of fused multiply-adds in tap order.  The kernels
-// are compiled per kernel length N (11, 13, 17, 21, 25 for sigma = 1.6 and three layers per
+// are compiled per kernel length N (11, 13, 17, 21, 27 for sigma = 1.6 and three layers per
 // octave), so the window loads carry no conditions and are all in flight together; N = 0 is the
 // one-output-per-thread form for any length.
 constexpr int SB_R = 8, SB_C = 16;
@@ -1028,7 +1028,7 @@ int sift_blur(rtvm_ctx* c, const SiftFrame* d_frames, int nb, int src, int dst, 
         SIFT_BLUR_N(13)
         SIFT_BLUR_N(17)
         SIFT_BLUR_N(21)
-        SIFT_BLUR_N(25)
+        SIFT_BLUR_N(27)
         default:
             RTVM_LAUNCH(c, k_sift_blur_rows<0>, grid3(w, h, nb), dim3(256), 0, d_frames, src, PLANE_SCRATCH, h, w, t);
             RTVM_LAUNCH(c, k_sift_blur_cols<0>, grid3(w, h, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, dst, h, w, t, below,
