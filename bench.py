@@ -93,14 +93,13 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
         "k_rs_refine": nkp * 16,               # matched point pairs in (latency bound: fp64 solver chains)
     }
     # SIFT scale space: the doubled image and the octaves built layer by layer (the octaves of at most 4000
-    # pixels are built in LDS by one workgroup); a row pass reads and writes a float plane, a column pass reads
-    # the row pass and the layer below and writes the layer and the difference of Gaussians
+    # pixels are built in LDS by one workgroup); a blur reads a layer and the layer below it and writes the next
+    # layer and the difference of Gaussians (the first blur of the doubled image: one plane in, one out)
     big, oh, ow = [], 2 * fh, 2 * fw
     while oh * ow > 4000 or not big:
         big.append(oh * ow)
         oh, ow = oh // 2, ow // 2
-    table["k_sift_blur_rows"] = 8 * (big[0] + 5 * sum(big))
-    table["k_sift_blur_cols"] = 8 * big[0] + 16 * 5 * sum(big)
+    table["k_sift_blur"] = 8 * big[0] + 16 * 5 * sum(big)
     table["k_sift_extrema"] = 4 * 5 * sum(big)          # every difference plane once
     return table.get(name)
 
@@ -174,7 +173,7 @@ def merge_variants(table):
     length) added up under the kernel's name."""
     out = {}
     for k, (cnt, ms, stream) in table.items():
-        name = k.split("<")[0] if k.startswith("k_sift_blur_") else k
+        name = k.split("<")[0] if k.startswith("k_sift_blur") else k
         c0, m0, _ = out.get(name, (0, 0.0, stream))
         out[name] = (c0 + cnt, m0 + ms, stream)
     return out
@@ -184,14 +183,16 @@ def pmc_traffic(kernel, config):
     """HBM bytes per frame of `kernel` from the committed rocprofv3 --pmc summary (separate FETCH_SIZE and
     WRITE_SIZE passes over a known number of frames; the counters cannot be read from inside this process)."""
     try:
-        with open(PMC_FILE) as fjs:
+        path = PMC_FILE if config == "720p_orb1000" else PMC_FILE.replace(".json", "_%s.json" % config)
+        with open(path) as fjs:
             pmc = json.load(fjs)
         if pmc.get("config") != config:
             return None, None
-        ent = pmc["kernels"].get(kernel)
-        if not ent:
+        # the instantiations of a templated kernel (k_sift_blur<11>, ...) add up under the kernel's name
+        ents = [e for k, e in pmc["kernels"].items() if k == kernel or k.startswith(kernel + "<")]
+        if not ents:
             return None, None
-        return ent["hbm_bytes_per_frame"], pmc.get("_about")
+        return sum(e["hbm_bytes_per_frame"] for e in ents), pmc.get("_about")
     except (OSError, KeyError, ValueError):
         return None, None
 

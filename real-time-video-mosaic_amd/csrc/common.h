@@ -110,6 +110,28 @@ struct DtJob {
     int wpitch, znch, zg, zpitch, cpitch;
 };
 
+// Workgroups go to the eight XCDs (each with an L2 of its own) in turn by their linear index.  A
+// launch over `n` tiles uses xcd_grid(n) workgroups in x; workgroup i takes tile
+// (i % 8) * (grid / 8) + i / 8, so that every XCD works through one contiguous run of tiles and
+// the rows and cache lines that neighbouring tiles share are found in its L2.  Returns -1 for the
+// padding workgroups.
+__device__ __forceinline__ int xcd_tile(int i, int n) {
+    const int per = (n + 7) >> 3, j = i >> 3;
+    const int t = (i & 7) * per + j;
+    return j < per && t < n ? t : -1;  // the grid may be larger than xcd_grid(n)
+}
+__host__ __device__ inline int xcd_grid(int n) { return ((n + 7) >> 3) << 3; }
+
+// The same for tiles of unequal cost: runs of 16 consecutive tiles go to the XCDs in turn, so that
+// neighbours within a run share their cache lines and every XCD still gets tiles from all over
+// the image.  Grid: xcd_grid_runs(n) workgroups.
+__device__ __forceinline__ int xcd_tile_runs(int i, int n) {
+    const int x = i & 7, j = i >> 3;
+    const int t = (((j >> 4) << 3) + x) * 16 + (j & 15);
+    return t < n ? t : -1;
+}
+__host__ __device__ inline int xcd_grid_runs(int n) { return ((n + 127) >> 7) << 7; }
+
 // A pointer read from a structure in memory is a generic pointer to the compiler (flat loads,
 // 64-bit address arithmetic per lane); every such pointer of this library is device memory:
 // as_global says so (global loads, scalar base + lane offset).

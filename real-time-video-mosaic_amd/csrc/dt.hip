@@ -46,6 +46,13 @@ __device__ __forceinline__ uint32_t e_of(uint32_t s) {
     return s == 0xFFFFu ? INF32 : s * DT_B;
 }
 
+// minimum of the two 16-bit halves of a and b
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 r = __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+
 // A launch serves jobs[0 .. n_first) and then jobs[second ...]: the new-mask and the
 // old-mask jobs of a batch live in two arrays.
 __device__ __forceinline__ int job_index(int i, int n_first, int second) {
@@ -100,63 +107,71 @@ __device__ __forceinline__ LineGeom line_geom(const DtJobG& jb) {
     return g;
 }
 
-// blockIdx.z = 2 * job + orientation; one wave = 64 lines of one chunk, one workgroup =
-// the 16 chunks of a group.  Bit r of line j's word is bit (x_top(j) +- r) of bit row r, and
-// x_top grows by one per line: with w_r = the 32 bits of row r starting at x_top(first line)
-// +- r, the words of 32 consecutive lines are the transpose of the 32x32 bit matrix (w_r).
-// Each half-wave does one such block: lane r loads its window (two words), 32 ballots
-// transpose it.
-__global__ __launch_bounds__(1024) void k_dt_diag_a(const DtJob* __restrict__ jobs, int n_first, int second) {
+// blockIdx.z = 2 * job + orientation; a wave takes 64 lines of one chunk at a time, one workgroup
+// (four waves, four chunks each) the 16 chunks of a group.  Bit r of line j's word is bit
+// (x_top(j) +- r) of bit row r, and x_top grows by one per line: with w_r = the 32 bits of row r
+// starting at x_top(first line) +- r, the words of 32 consecutive lines are the transpose of the
+// 32x32 bit matrix (w_r).  Each half-wave does one such block: lane r loads its window (two words),
+// 32 ballots transpose it.  (Small workgroups on purpose: a workgroup of 16 waves waits for half a
+// compute unit to be free at once, which rarely happens while the other streams keep the GPU busy.)
+__global__ __launch_bounds__(256) void k_dt_diag_a(const DtJob* __restrict__ jobs, int n_first, int second) {
     const DtJobG jb(jobs[job_index(blockIdx.z >> 1, n_first, second)]);
     const int orient = blockIdx.z & 1;
     const LineGeom g = line_geom(jb);
     if (g.W <= 0 || g.H <= 0 || (int)blockIdx.x * 64 >= g.nlines || (int)blockIdx.y * GR >= g.nch) return;
-    __shared__ uint32_t s_any[GR][64];
+    __shared__ uint32_t s_any[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int line = blockIdx.x * 64 + lane;
-    const int c = blockIdx.y * GR + wave;
-    uint32_t z = 0;
-    if (c < g.nch) {  // wave-uniform
-        const int grp = lane >> 5, r = lane & 31;
-        const int dx = orient ? -1 : 1;
-        const int line0 = blockIdx.x * 64 + 32 * grp;
-        const int xs0 = orient ? jb.x0 + line0 : jb.x0 - (g.H - 1) + line0;
+    const int grp = lane >> 5, r = lane & 31;
+    const int dx = orient ? -1 : 1;
+    const int line0 = blockIdx.x * 64 + 32 * grp;
+    const int xs0 = orient ? jb.x0 + line0 : jb.x0 - (g.H - 1) + line0;
+    const int nw = jb.wpitch - 2;
+    // all windows first, so that the loads of the four chunks are in flight together
+    uint32_t w[GR / 4];
+#pragma unroll
+    for (int k = 0; k < GR / 4; k++) {
+        const int c = blockIdx.y * GR + wave * (GR / 4) + k;
         const int ya = jb.y0 + c * CH;
         const int xstart = xs0 + dx * (ya - jb.y0) + dx * r;  // first column of row r's window
         const int y = ya + r;
-        uint32_t w = 0;
-        if (y < jb.y1) {
-            const int wi = xstart >> 5, sh = xstart & 31, nw = jb.wpitch - 2;
+        w[k] = 0;
+        if (c < g.nch && y < jb.y1) {
+            const int wi = xstart >> 5, sh = xstart & 31;
             const auto rowp = jb.B + (size_t)y * jb.wpitch;
             const uint32_t lo = (wi >= 0 && wi < nw) ? rowp[wi] : 0u;
             const uint32_t hi = (wi + 1 >= 0 && wi + 1 < nw) ? rowp[wi + 1] : 0u;
-            w = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> sh);
+            uint32_t v = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> sh);
             // columns outside the rectangle are walls (their bits may be stale)
             const int j0 = jb.x0 - xstart, j1 = jb.x1 - xstart;  // window bits [j0, j1) are inside
-            if (j0 > 0) w &= j0 >= 32 ? 0u : 0xFFFFFFFFu << j0;
-            if (j1 < 32) w &= j1 <= 0 ? 0u : 0xFFFFFFFFu >> (32 - j1);
+            if (j0 > 0) v &= j0 >= 32 ? 0u : 0xFFFFFFFFu << j0;
+            if (j1 < 32) v &= j1 <= 0 ? 0u : 0xFFFFFFFFu >> (32 - j1);
+            w[k] = v;
         }
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < GR / 4; k++) {
+        const int c = blockIdx.y * GR + wave * (GR / 4) + k;
+        if (c >= g.nch) break;  // wave-uniform
+        uint32_t z = 0;
 #pragma unroll
         for (int j = 0; j < 32; j++) {
-            const unsigned long long b = __ballot((w >> j) & 1u);
+            const unsigned long long b = __ballot((w[k] >> j) & 1u);
             const uint32_t half = grp ? (uint32_t)(b >> 32) : (uint32_t)b;
             if (r == j) z = half;
         }
         if (line < g.nlines) jb.Z[((size_t)orient * jb.znch + c) * jb.zpitch + line] = z;
+        any |= (z != 0 ? 1u : 0u) << (wave * (GR / 4) + k);
     }
-    s_any[wave][lane] = z != 0 ? 1u : 0u;
+    s_any[wave][lane] = any;
     __syncthreads();
-    if (wave == 0 && line < g.nlines) {
-        uint32_t m = 0;
-#pragma unroll
-        for (int k = 0; k < GR; k++) m |= s_any[k][lane] << k;
-        jb.Z16[((size_t)orient * jb.zg + blockIdx.y) * jb.zpitch + line] = m;
-    }
+    if (wave == 0 && line < g.nlines)
+        jb.Z16[((size_t)orient * jb.zg + blockIdx.y) * jb.zpitch + line] = s_any[0][lane] | s_any[1][lane] | s_any[2][lane] | s_any[3][lane];
 }
 
-// Steps to the nearest zero along one line for the 32 rows of chunk c, written into the
-// LDS tile (first == true) or combined with what the other orientation left there.
-template <bool FIRST>
+// Steps to the nearest zero along one line for the 32 rows of chunk c, written into the LDS tile
+// of the line's orientation.
 __device__ __forceinline__ void diag_steps(const DtJobG& jb, const LineGeom& g, int orient, int c, int line, int col0,
                                            int dcol, uint16_t (*T)[TW]) {
     const auto Z = jb.Z + (size_t)orient * jb.znch * jb.zpitch + line;
@@ -195,20 +210,23 @@ __device__ __forceinline__ void diag_steps(const DtJobG& jb, const LineGeom& g, 
     int up = 1 << 20, down = 1 << 20;
     if (ka >= 0) up = (c - ka) * CH - (31 - __clz((int)Z[(size_t)ka * jb.zpitch]));
     if (kb >= 0) down = (kb - c) * CH + (__ffs((int)Z[(size_t)kb * jb.zpitch]) - 1) - (CH - 1);
+    // steps to the nearest zero below (e) and above (run) as running counts that a zero resets:
+    // count = (count + 1) & (zero here ? 0 : ~0); both stay below 2^21
+    const uint32_t nz = ~z;
+    int e[CH];
+    int run = down - 1;
+#pragma unroll
+    for (int r = CH - 1; r >= 0; r--) {
+        run = (run + 1) & __builtin_amdgcn_sbfe(nz, r, 1);
+        e[r] = run;
+    }
+    run = up - 1;
 #pragma unroll
     for (int r = 0; r < CH; r++) {
+        run = (run + 1) & __builtin_amdgcn_sbfe(nz, r, 1);
         const int col = col0 + dcol * r;
         if (col < 0 || col >= TW) continue;
-        const uint32_t lower = z & (0xFFFFFFFFu >> (31 - r));
-        const uint32_t upper = z >> r;
-        const int du = lower ? r - (31 - __clz((int)lower)) : up + r;
-        const int dd = upper ? __ffs((int)upper) - 1 : down + (CH - 1 - r);
-        const int d = du < dd ? du : dd;
-        const uint16_t s = (uint16_t)(d > 0xFFFE ? 0xFFFF : d);
-        if (FIRST)
-            T[r][col] = s;
-        else if (s < T[r][col])
-            T[r][col] = s;
+        T[r][col] = (uint16_t)min(min(run, e[r]), 0xFFFF);
     }
 }
 
@@ -225,19 +243,21 @@ __global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ job
     const bool rows_needed = ya < jb.oy1 && ya + CH > jb.oy0;
     const bool cols_needed = X < jb.ox1 && X + TW > jb.ox0;
     if (!rows_needed && !cols_needed) return;
-    __shared__ uint16_t T[CH][TW];
+    // one tile per orientation; a pixel of the rectangle lies on exactly one line of each family,
+    // pixels outside it keep "no zero" and are never stored
+    __shared__ __align__(16) uint16_t T[2][CH][TW];
     const int i = threadIdx.x;
-    // every pixel of the tile inside the rectangle lies on exactly one line of each family
+    if (jb.x0 > X || jb.x1 < X + TW) {
+        for (int e = i; e < 2 * CH * TW / 8; e += 320) reinterpret_cast<uint4*>(&T[0][0][0])[e] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        __syncthreads();
+    }
     if (i < TW + CH - 1) {
         // orientation 0: the line through column X - 31 + i at the chunk's first row
-        const int line = (X - 31 + i) - jb.x0 + (g.H - 1) - c * CH;
-        if (line >= 0 && line < g.nlines) diag_steps<true>(jb, g, 0, c, line, i - 31, 1, T);
-    }
-    __syncthreads();
-    if (i < TW + CH - 1) {
+        const int line0 = (X - 31 + i) - jb.x0 + (g.H - 1) - c * CH;
+        if (line0 >= 0 && line0 < g.nlines) diag_steps(jb, g, 0, c, line0, i - 31, 1, T[0]);
         // orientation 1: the line through column X + i at the chunk's first row
-        const int line = (X + i) - jb.x0 + c * CH;
-        if (line >= 0 && line < g.nlines) diag_steps<false>(jb, g, 1, c, line, i, -1, T);
+        const int line1 = (X + i) - jb.x0 + c * CH;
+        if (line1 >= 0 && line1 < g.nlines) diag_steps(jb, g, 1, c, line1, i, -1, T[1]);
     }
     __syncthreads();
     const int nrows = min(CH, jb.y1 - ya);
@@ -246,13 +266,15 @@ __global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ job
             const int r = e / (TW / 8), q = e % (TW / 8);
             const int x = X + q * 8;
             if (x + 8 <= jb.x0 || x >= jb.x1) continue;
-            store_u4(jb.S + (size_t)(ya + r) * jb.pitch + x, *reinterpret_cast<const uint4*>(&T[r][q * 8]));
+            const uint4 a = *reinterpret_cast<const uint4*>(&T[0][r][q * 8]), b = *reinterpret_cast<const uint4*>(&T[1][r][q * 8]);
+            store_u4(jb.S + (size_t)(ya + r) * jb.pitch + x, make_uint4(pk_min_u16(a.x, b.x), pk_min_u16(a.y, b.y),
+                                                                      pk_min_u16(a.z, b.z), pk_min_u16(a.w, b.w)));
         }
     } else {
         for (int e = i; e < nrows * TW; e += 320) {
             const int r = e / TW, x = X + e % TW;
             if (x < jb.x0 || x >= jb.x1) continue;
-            jb.S[(size_t)(ya + r) * jb.pitch + x] = T[r][e % TW];
+            jb.S[(size_t)(ya + r) * jb.pitch + x] = min(T[0][r][e % TW], T[1][r][e % TW]);
         }
     }
 }
@@ -528,9 +550,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     }
     const int b = blockIdx.x - nrow_blocks;
     const int nch = (H + CH - 1) / CH;
-    const int x = jb.ox0 + (b % ncol_x) * 64 + (threadIdx.x & 63);
+    const int x = (jb.ox0 & ~63) + (b % ncol_x) * 64 + (threadIdx.x & 63);  // column groups on the plane's 64-column grid
     const int c = (b / ncol_x) * 4 + (threadIdx.x >> 6);
-    if (c >= nch || x >= jb.ox1) return;
+    if (c >= nch || x < jb.ox0 || x >= jb.ox1) return;
     dt_col_summary(jb, x, c);
 }
 
@@ -541,8 +563,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 __global__ __launch_bounds__(64) void k_dt_chunks(const DtJob* __restrict__ jobs, int n_first, int second) {
     const DtJobG jb(jobs[job_index(blockIdx.y, n_first, second)]);
     const int H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
-    const int x = jb.ox0 + blockIdx.x * 64 + threadIdx.x;
-    if (H <= 0 || x >= jb.ox1) return;
+    const int x = (jb.ox0 & ~63) + blockIdx.x * 64 + threadIdx.x;
+    if (H <= 0 || x < jb.ox0 || x >= jb.ox1) return;
     const bool down = blockIdx.z == 0;
     const auto cs = jb.CS + (down ? 0 : (size_t)jb.znch * jb.cpitch) + x;
     uint32_t run = INF32;
@@ -569,9 +591,9 @@ __global__ __launch_bounds__(64) void k_dt_chunks(const DtJob* __restrict__ jobs
 __global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs, int n_first, int second) {
     const DtJobG jb(jobs[job_index(blockIdx.z, n_first, second)]);
     const int H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
-    const int x = jb.ox0 + blockIdx.x * 64 + threadIdx.x;
+    const int x = (jb.ox0 & ~63) + blockIdx.x * 64 + threadIdx.x;  // a wave's row accesses start on a cache line
     const int c = (jb.oy0 - jb.y0) / CH + blockIdx.y;
-    if (H <= 0 || c >= nch || x >= jb.ox1) return;
+    if (H <= 0 || c >= nch || x < jb.ox0 || x >= jb.ox1) return;
     const int ya = jb.y0 + c * CH;
     if (ya >= jb.oy1) return;
     uint32_t E[CH], F[CH], Rv[CH];
@@ -626,11 +648,11 @@ int rtvm_launch_dt2(rtvm_ctx* c, const DtJob* d_jobs, int n_first, int second, i
     const int njobs = n_first + n_second;
     const int nlines = max_w + max_h - 1;
     const int nch = (max_h + CH - 1) / CH;
-    const int ncol_x = (max_w + 63) / 64;
+    const int ncol_x = (max_w + 63) / 64 + 1;  // column groups on the 64-column grid: one more than the width needs
     if (with_bits)
         RTVM_LAUNCH(c, k_dt_bits, dim3((max_w / 32 + 2 + 63) / 64, (max_h + 3) / 4, njobs), dim3(256), 0, d_jobs, n_first,
                     second);
-    RTVM_LAUNCH(c, k_dt_diag_a, dim3((nlines + 63) / 64, (nch + GR - 1) / GR, 2 * njobs), dim3(1024), 0, d_jobs, n_first,
+    RTVM_LAUNCH(c, k_dt_diag_a, dim3((nlines + 63) / 64, (nch + GR - 1) / GR, 2 * njobs), dim3(256), 0, d_jobs, n_first,
                 second);
     RTVM_LAUNCH(c, k_dt_diag_b, dim3(max_w / TW + 2, nch, njobs), dim3(320), 0, d_jobs, n_first, second);
     RTVM_LAUNCH(c, k_dt_scan, dim3(max_h + ncol_x * ((nch + 3) / 4), njobs), dim3(256), 0, d_jobs, n_first, second, max_h,

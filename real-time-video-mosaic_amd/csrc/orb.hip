@@ -82,7 +82,10 @@ __global__ __launch_bounds__(256) void k_resize(const FrameSlot* __restrict__ sl
     const uint8_t* __restrict__ src = S.pyr + soff;
     uint8_t* __restrict__ dst = S.pyr + doff;
     __shared__ __align__(16) uint8_t t[TR][TC];
-    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 16;
+    const int tiles_x = (dw + 63) / 64;
+    const int tile = xcd_tile(blockIdx.x, tiles_x * ((dh + 15) / 16));
+    if (tile < 0) return;
+    const int tx0 = (tile % tiles_x) * 64, ty0 = (tile / tiles_x) * 16;
     const int tid = threadIdx.x;
     // footprint of the tile in the source level (block-uniform)
     const int xlast = min(tx0 + 63, dw - 1), ylast = min(ty0 + 15, dh - 1);
@@ -227,7 +230,9 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P, const FrameSlot* __restr
     int* __restrict__ cand_count = SL.cand_count;
     int* __restrict__ hist = SL.cand_count + RTVM_NLEVELS;
     int local;
-    const int l = tile_level(P, blockIdx.x, &local);
+    const int lin = xcd_tile_runs(blockIdx.x, P.tile_off[RTVM_NLEVELS]);
+    if (lin < 0) return;
+    const int l = tile_level(P, lin, &local);
     const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
     const int tiles_x = (W - 2 * EDGE + 63) / 64;
     const int tx0 = EDGE + (local % tiles_x) * 64, ty0 = EDGE + (local / tiles_x) * 32;
@@ -478,11 +483,13 @@ __global__ __launch_bounds__(256) void k_blur7(OrbDev P, const FrameSlot* __rest
     const FrameSlot& SL = slots[sb + blockIdx.y];
     const uint8_t* __restrict__ pyr = SL.pyr;
     uint8_t* __restrict__ out = SL.pyr_blur;
+    const int lin = xcd_tile(blockIdx.x, P.btile_off[RTVM_NLEVELS]);
+    if (lin < 0) return;
     int l = 0;
 #pragma unroll
     for (int k = 1; k < RTVM_NLEVELS; k++)
-        if ((int)blockIdx.x >= P.btile_off[k]) l = k;
-    const int local = blockIdx.x - P.btile_off[l];
+        if (lin >= P.btile_off[k]) l = k;
+    const int local = lin - P.btile_off[l];
     const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
     const int tiles_x = (W + 63) / 64;
     const int tx0 = (local % tiles_x) * 64, ty0 = (local / tiles_x) * 32;
@@ -783,14 +790,14 @@ int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
     RTVM_LAUNCH(c, k_gray, dim3((P.w[0] + 1023) / 1024, P.h[0], nb), dim3(256), 0, sl, sb, P.off[0], P.w[0], P.h[0],
                 P.pitch[0], rtvm_gray_coef(c));
     for (int l = 1; l < RTVM_NLEVELS; l++)
-        RTVM_LAUNCH(c, k_resize, dim3((P.w[l] + 63) / 64, (P.h[l] + 15) / 16, nb), dim3(256), 0, sl, sb, P.off[l - 1],
+        RTVM_LAUNCH(c, k_resize, dim3(xcd_grid(((P.w[l] + 63) / 64) * ((P.h[l] + 15) / 16)), 1, nb), dim3(256), 0, sl, sb, P.off[l - 1],
                     P.pitch[l - 1], P.h[l - 1], P.off[l], P.w[l], P.h[l], P.pitch[l], c->d_xofs + P.xtab_off[l],
                     c->d_xw + P.xtab_off[l], c->d_yofs + P.ytab_off[l], c->d_yw + P.ytab_off[l]);
     if (P.tile_off[RTVM_NLEVELS] > 0) {
-        RTVM_LAUNCH(c, k_fast, dim3(P.tile_off[RTVM_NLEVELS], nb), dim3(256), 0, P, sl, sb);
+        RTVM_LAUNCH(c, k_fast, dim3(xcd_grid_runs(P.tile_off[RTVM_NLEVELS]), nb), dim3(256), 0, P, sl, sb);
     }
     RTVM_LAUNCH(c, k_orb_select, dim3(RTVM_NLEVELS, nb), dim3(1024), 0, P, sl, sb);
-    RTVM_LAUNCH(c, k_blur7, dim3(P.btile_off[RTVM_NLEVELS], nb), dim3(256), 0, P, sl, sb);
+    RTVM_LAUNCH(c, k_blur7, dim3(xcd_grid(P.btile_off[RTVM_NLEVELS]), nb), dim3(256), 0, P, sl, sb);
     RTVM_LAUNCH(c, k_orb_describe, dim3(P.max_kp, nb), dim3(64), 0, P, sl, sb);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;

@@ -96,30 +96,47 @@ __device__ __forceinline__ int reflect101s(int p, int n) {
     return p;
 }
 
+// Gray (main.py:717) and the 2x INTER_LINEAR upsampling that SIFT starts from.  Output x samples the
+// source at (x + 0.5) / 2 - 0.5: column 2i lies between source columns i - 1 and i with weights
+// 0.25 / 0.75, column 2i + 1 between i and i + 1 with 0.75 / 0.25; at the image border the weight
+// of the one source pixel is 1 (cv::resize replicates the border).  A thread takes source pixel
+// (i, j): the gray values of its 3 x 3 neighbourhood (coordinates clamped) give the 2 x 2 outputs;
+// every output is g(y0, x0) * a0 + g(y0, x1) * a1 per row, then row0 * b0 + row1 * b1.
 __global__ __launch_bounds__(256) void k_sift_base(const SiftFrame* __restrict__ F, int h, int w, int dst_id, GrayCoef gc) {
     const SiftFrame& f = F[blockIdx.z];
-    const uint8_t* __restrict__ bgr = f.bgr;
-    float* __restrict__ out = plane(f, dst_id);
+    const auto bgr = as_global<const uint8_t>(f.bgr);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) f.counts[threadIdx.x] = 0;  // nothing found yet
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= 2 * w || y >= 2 * h) return;
-    float fx = (float)(((double)x + 0.5) * 0.5 - 0.5), fy = (float)(((double)y + 0.5) * 0.5 - 0.5);
-    int sx = (int)floorf(fx), sy = (int)floorf(fy);
-    fx -= sx;
-    fy -= sy;
-    if (sx < 0) fx = 0, sx = 0;
-    if (sx >= w - 1) fx = 0, sx = w - 1;
-    if (sy < 0) fy = 0, sy = 0;
-    if (sy >= h - 1) fy = 0, sy = h - 1;
-    const int x1 = min(sx + 1, w - 1), y1 = min(sy + 1, h - 1);
-    auto gray = [&](int yy, int xx) {
-        const uint8_t* p = bgr + ((size_t)yy * w + xx) * 3;
-        return (float)((p[0] * gc.cb + p[1] * gc.cg + p[2] * gc.cr + (1 << (gc.shift - 1))) >> gc.shift);
-    };
-    const float a1 = fx, a0 = 1.f - a1, b1 = fy, b0 = 1.f - b1;
-    const float r0 = gray(sy, sx) * a0 + gray(sy, x1) * a1;
-    const float r1 = gray(y1, sx) * a0 + gray(y1, x1) * a1;
-    out[(size_t)y * 2 * w + x] = r0 * b0 + r1 * b1;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= w || j >= h) return;
+    float G[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int yy = min(max(j - 1 + a, 0), h - 1);
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const int xx = min(max(i - 1 + b, 0), w - 1);
+            const auto p = bgr + ((size_t)yy * w + xx) * 3;
+            G[a][b] = (float)((p[0] * gc.cb + p[1] * gc.cg + p[2] * gc.cr + (1 << (gc.shift - 1))) >> gc.shift);
+        }
+    }
+    // weights of the left / upper source pixel (a0, b0) and of the other one (a1 = fx, a0 = 1 - fx)
+    const float ax1[2] = {i == 0 ? 0.f : 0.75f, i == w - 1 ? 0.f : 0.25f};
+    const float by1[2] = {j == 0 ? 0.f : 0.75f, j == h - 1 ? 0.f : 0.25f};
+    const auto out = as_global(plane(f, dst_id) + (size_t)(2 * j) * (2 * w) + 2 * i);
+#pragma unroll
+    for (int py = 0; py < 2; py++) {
+        const float b1 = by1[py], b0 = 1.f - b1;
+        float o[2];
+#pragma unroll
+        for (int px = 0; px < 2; px++) {
+            const float a1 = ax1[px], a0 = 1.f - a1;
+            const float r0 = G[py][px] * a0 + G[py][px + 1] * a1;
+            const float r1 = G[py + 1][px] * a0 + G[py + 1][px + 1] * a1;
+            o[px] = r0 * b0 + r1 * b1;
+        }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<gptr<f32x2>>(out + (size_t)py * (2 * w)) = f32x2{o[0], o[1]};
+    }
 }
 
 constexpr int MAX_HALF = MAX_TAPS / 2;
@@ -170,81 +187,23 @@ __device__ __forceinline__ float col_taps_border(const Taps& t, const float* col
     return a;
 }
 
-// Outputs per thread in the two passes of the blur: a thread keeps the window of its outputs in
-// registers (SB_R + taps - 1 samples), so a sample is loaded once per SB_R outputs instead of once
-// per tap; every output is still its own chain of fused multiply-adds in tap order.  The kernels
-// are compiled per kernel length N (11, 13, 17, 21, 27 for sigma = 1.6 and three layers per
-// octave), so the window loads carry no conditions and are all in flight together; N = 0 is the
-// one-output-per-thread form for any length.
-constexpr int SB_R = 8, SB_C = 16;
-
-template <int N>
+// The general form of the two passes, one output per thread, for any kernel length (OpenCV's
+// GaussianBlur as sepFilter2D: all rows first, then all columns); the lengths SIFT actually uses
+// go through k_sift_blur below.
 __global__ __launch_bounds__(256) void k_sift_blur_rows(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w,
                                                         Taps t) {
     const SiftFrame& f = F[blockIdx.z];
     const float* __restrict__ src = plane(f, src_id);
     float* __restrict__ dst = plane(f, dst_id);
-    if (N == 0) {
-        const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-        if (x >= w || y >= h) return;
-        const int half = t.n / 2;
-        const float* __restrict__ row = src + (size_t)y * w;
-        dst[(size_t)y * w + x] = (x >= half && x + half < w) ? row_taps(t, row + (x - half)) : row_taps_border(t, row, x, w);
-        return;
-    }
-    // A wave takes 64 * SB_R consecutive outputs of one row.  Their samples (the segment plus half a
-    // kernel on either side, mirrored at the image border) go through LDS: consecutive lanes load
-    // consecutive floats, then every lane reads the window of its SB_R outputs as 16-byte words.
-    constexpr int NN = N > 0 ? N : 1, half = NN / 2, SEG = 64 * SB_R, STAGE = SEG + 32;
-    static_assert(NN - 1 <= 32 && (SB_R + NN - 1 + 3) / 4 * 4 <= SB_R + 32, "window fits the staged segment");
-    __shared__ __align__(16) float s_seg[4][STAGE];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int xs0 = blockIdx.x * SEG, y = blockIdx.y * 4 + wv;
-    const bool row_ok = y < h;
-    if (row_ok) {
-        const auto row = as_global(src + (size_t)y * w);
-        const bool inner = xs0 >= half && xs0 + SEG + half <= w;
-#pragma unroll
-        for (int k = 0; k < (SEG + NN - 1 + 63) / 64; k++) {
-            const int i = lane + 64 * k;
-            if (i < SEG + NN - 1) {
-                const int x = xs0 - half + i;
-                s_seg[wv][i] = row[inner ? x : reflect101s(x, w)];
-            }
-        }
-    }
-    __syncthreads();
-    const int x0 = xs0 + lane * SB_R;
-    if (!row_ok || x0 >= w) return;
-    constexpr int WIN4 = (SB_R + NN - 1 + 3) / 4;
-    float v[4 * WIN4];
-#pragma unroll
-    for (int i = 0; i < WIN4; i++) {
-        const float4 q = *reinterpret_cast<const float4*>(&s_seg[wv][lane * SB_R + 4 * i]);
-        v[4 * i] = q.x, v[4 * i + 1] = q.y, v[4 * i + 2] = q.z, v[4 * i + 3] = q.w;
-    }
-    float a[SB_R];
-#pragma unroll
-    for (int r = 0; r < SB_R; r++) a[r] = t.k[0] * v[r];
-#pragma unroll
-    for (int q = 1; q < NN; q++) {
-#pragma unroll
-        for (int r = 0; r < SB_R; r++) a[r] = __builtin_fmaf(v[r + q], t.k[q], a[r]);
-    }
-    const auto o = as_global(dst + (size_t)y * w + x0);
-    if (x0 + SB_R <= w && (w & 3) == 0) {  // rows start 16-byte aligned: two 16-byte stores
-        store_u4(o, make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])));
-        store_u4(o + 4, make_uint4(__float_as_uint(a[4]), __float_as_uint(a[5]), __float_as_uint(a[6]), __float_as_uint(a[7])));
-    } else {
-#pragma unroll
-        for (int r = 0; r < SB_R; r++)
-            if (x0 + r < w) o[r] = a[r];
-    }
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int half = t.n / 2;
+    const float* __restrict__ row = src + (size_t)y * w;
+    dst[(size_t)y * w + x] = (x >= half && x + half < w) ? row_taps(t, row + (x - half)) : row_taps_border(t, row, x, w);
 }
 
 // Column pass; with `below` (the Gaussian layer under the one being made) it also writes the
 // difference of the two layers, dog = this - below, the value a separate subtraction would give.
-template <int N>
 __global__ __launch_bounds__(256) void k_sift_blur_cols(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w,
                                                         Taps t, int below_id, int dog_id) {
     const SiftFrame& f = F[blockIdx.z];
@@ -252,57 +211,136 @@ __global__ __launch_bounds__(256) void k_sift_blur_cols(const SiftFrame* __restr
     float* __restrict__ dst = plane(f, dst_id);
     const float* __restrict__ below = below_id >= 0 ? plane(f, below_id) : nullptr;
     float* __restrict__ dog = below_id >= 0 ? plane(f, dog_id) : nullptr;
-    if (N == 0) {
-        const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-        if (x >= w || y >= h) return;
-        const int half = t.n / 2;
-        const float a = (y >= half && y + half < h) ? col_taps(t, src + (size_t)y * w + x, w) : col_taps_border(t, src + x, y, h, w);
-        dst[(size_t)y * w + x] = a;
-        if (below) dog[(size_t)y * w + x] = a - below[(size_t)y * w + x];
-        return;
-    }
-    constexpr int NN = N > 0 ? N : 1, half = NN / 2, SB_R = SB_C;   // outputs per thread down the column
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * SB_R;
-    if (x >= w || y0 >= h) return;
-    float a[SB_R];
-    if (y0 >= half && y0 + SB_R - 1 + half < h) {  // wave-uniform: a wave is SB_R rows
-        float v[SB_R + NN - 1];
-        const auto p = as_global(src + (size_t)(y0 - half) * w + x);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int half = t.n / 2;
+    const float a = (y >= half && y + half < h) ? col_taps(t, src + (size_t)y * w + x, w) : col_taps_border(t, src + x, y, h, w);
+    dst[(size_t)y * w + x] = a;
+    if (below) dog[(size_t)y * w + x] = a - below[(size_t)y * w + x];
+}
+
+// Both passes of one blur for a tile of SBT_W x SBT_H outputs, compiled per kernel length N (11,
+// 13, 17, 21, 27 for sigma = 1.6 and three layers per octave): the row-passed values of the tile's
+// rows and of the N - 1 rows around them stay in LDS, so the plane between the passes never
+// reaches memory and the source is read once (plus the tiles' margins, from the caches).
+//   row pass: a wave takes four source rows at a time; their samples (the tile's columns plus half
+//     a kernel on either side, mirrored at the image border) are staged in LDS by consecutive lanes
+//     loading consecutive floats; 16 lanes per row then compute 8 outputs each from a window of
+//     8 + N - 1 samples read as 16-byte words; every output is its own chain of fused
+//     multiply-adds in tap order;
+//   column pass: a thread takes 16 consecutive rows of one column from a window of 16 + N - 1
+//     row-passed values in registers (centre first, then the symmetric pairs outwards) and writes
+//     the layer and, with `below`, the difference of Gaussians.
+constexpr int SBT_W = 128, SBT_H = 32, SB_R = 8, SB_C = 16, SBT_STAGE = SBT_W + 32;
+
+template <int N>
+__global__ __launch_bounds__(256) void k_sift_blur(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w, Taps t,
+                                                   int below_id, int dog_id) {
+    constexpr int half = N / 2, RB = SBT_H + N - 1, NIN = SBT_W + N - 1, WIN4 = (SB_R + N - 1 + 3) / 4;
+    static_assert(N % 2 == 1 && NIN <= SBT_STAGE && (SBT_W - SB_R) + 4 * WIN4 <= SBT_STAGE, "windows fit the staged row");
+    static_assert(SBT_W == 16 * SB_R && SBT_H == 2 * SB_C, "thread mapping of the two passes");
+    __shared__ __align__(16) float s_in[4][4][SBT_STAGE];
+    __shared__ __align__(16) float s_rp[RB][SBT_W];
+    const SiftFrame& f = F[blockIdx.z];
+    const auto src = as_global(plane(f, src_id));
+    const int tiles_x = (w + SBT_W - 1) / SBT_W;
+    const int tile = xcd_tile(blockIdx.x, tiles_x * ((h + SBT_H - 1) / SBT_H));
+    if (tile < 0) return;
+    const int x0 = (tile % tiles_x) * SBT_W, y0 = (tile / tiles_x) * SBT_H;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool inner = x0 >= half && x0 + SBT_W + half <= w;
+    const int q = lane >> 4, seg = lane & 15;
+    // the samples of the next four rows are requested before the current four are filtered
+    constexpr int NK = (NIN + 63) / 64;
+    float pre[4][NK];
+    auto request = [&](int rb) {
 #pragma unroll
-        for (int i = 0; i < SB_R + NN - 1; i++) v[i] = p[(size_t)i * w];
-        // v[r + half] is the centre of output r
+        for (int qq = 0; qq < 4; qq++) {
+            const int r = min(rb + qq, RB - 1);
+            const auto row = src + (size_t)reflect101s(y0 - half + r, h) * w;
 #pragma unroll
-        for (int r = 0; r < SB_R; r++) a[r] = t.c[0] * v[r + half];
-#pragma unroll
-        for (int q = 1; q <= half; q++) {
-#pragma unroll
-            for (int r = 0; r < SB_R; r++) a[r] = __builtin_fmaf(v[r + half + q] + v[r + half - q], t.c[q], a[r]);
+            for (int k = 0; k < NK; k++) {
+                const int i = min(lane + 64 * k, NIN - 1);
+                pre[qq][k] = row[inner ? x0 - half + i : reflect101s(x0 - half + i, w)];
+            }
         }
-        const auto od = as_global(dst + (size_t)y0 * w + x);
-        if (below) {
-            const auto pb = as_global(below + (size_t)y0 * w + x);
-            const auto og = as_global(dog + (size_t)y0 * w + x);
-            float b[SB_R];
+    };
+    request(4 * wv);
+    for (int rb = 4 * wv; rb < RB; rb += 16) {
 #pragma unroll
-            for (int r = 0; r < SB_R; r++) b[r] = pb[(size_t)r * w];
+        for (int qq = 0; qq < 4; qq++) {
 #pragma unroll
-            for (int r = 0; r < SB_R; r++) {
-                od[(size_t)r * w] = a[r];
-                og[(size_t)r * w] = a[r] - b[r];
+            for (int k = 0; k < NK; k++) {
+                const int i = lane + 64 * k;
+                if (i < SBT_STAGE) s_in[wv][qq][i] = pre[qq][k];
+            }
+        }
+        if (rb + 16 < RB) request(rb + 16);
+        // the rows staged by this wave are read by this wave only: LDS keeps a wave's accesses in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int r = rb + q;
+        if (r < RB) {
+            float v[4 * WIN4];
+#pragma unroll
+            for (int i = 0; i < WIN4; i++) {
+                const float4 u = *reinterpret_cast<const float4*>(&s_in[wv][q][seg * SB_R + 4 * i]);
+                v[4 * i] = u.x, v[4 * i + 1] = u.y, v[4 * i + 2] = u.z, v[4 * i + 3] = u.w;
+            }
+            float a[SB_R];
+#pragma unroll
+            for (int o = 0; o < SB_R; o++) a[o] = t.k[0] * v[o];
+#pragma unroll
+            for (int k = 1; k < N; k++) {
+#pragma unroll
+                for (int o = 0; o < SB_R; o++) a[o] = __builtin_fmaf(v[o + k], t.k[k], a[o]);
+            }
+            *reinterpret_cast<float4*>(&s_rp[r][seg * SB_R]) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float4*>(&s_rp[r][seg * SB_R + 4]) = make_float4(a[4], a[5], a[6], a[7]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    const int cx = threadIdx.x & (SBT_W - 1), ry = (threadIdx.x / SBT_W) * SB_C;
+    const int x = x0 + cx, yo = y0 + ry;
+    if (x >= w || yo >= h) return;
+    float v[SB_C + N - 1];
+#pragma unroll
+    for (int i = 0; i < SB_C + N - 1; i++) v[i] = s_rp[ry + i][cx];
+    float a[SB_C];
+#pragma unroll
+    for (int o = 0; o < SB_C; o++) a[o] = t.c[0] * v[o + half];
+#pragma unroll
+    for (int k = 1; k <= half; k++) {
+#pragma unroll
+        for (int o = 0; o < SB_C; o++) a[o] = __builtin_fmaf(v[o + half + k] + v[o + half - k], t.c[k], a[o]);
+    }
+    const auto od = as_global(plane(f, dst_id) + (size_t)yo * w + x);
+    if (below_id >= 0) {
+        const auto pb = as_global(plane(f, below_id) + (size_t)yo * w + x);
+        const auto og = as_global(plane(f, dog_id) + (size_t)yo * w + x);
+        if (yo + SB_C <= h) {
+            float b[SB_C];
+#pragma unroll
+            for (int o = 0; o < SB_C; o++) b[o] = pb[(size_t)o * w];
+#pragma unroll
+            for (int o = 0; o < SB_C; o++) {
+                od[(size_t)o * w] = a[o];
+                og[(size_t)o * w] = a[o] - b[o];
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < SB_R; r++) od[(size_t)r * w] = a[r];
+            for (int o = 0; o < SB_C; o++)
+                if (yo + o < h) {
+                    od[(size_t)o * w] = a[o];
+                    og[(size_t)o * w] = a[o] - pb[(size_t)o * w];
+                }
         }
-        return;
-    }
-    for (int r = 0; r < SB_R; r++) {
-        const int y = y0 + r;
-        if (y >= h) break;
-        const float v = (y >= half && y + half < h) ? col_taps(t, src + (size_t)y * w + x, w) : col_taps_border(t, src + x, y, h, w);
-        const size_t o = (size_t)y * w + x;
-        dst[o] = v;
-        if (below) dog[o] = v - below[o];
+    } else {
+#pragma unroll
+        for (int o = 0; o < SB_C; o++)
+            if (yo + o < h) od[(size_t)o * w] = a[o];
     }
 }
 
@@ -376,69 +414,89 @@ __global__ __launch_bounds__(1024) void k_sift_small_octaves(const SiftFrame* F,
     }
 }
 
-// Tiles of 64x4 positions of every octave in one launch: tile_start[o] is the first linear tile
-// of octave o, blockIdx.y + 1 the layer.
+// Tiles of EX_COLS x 4 * EX_ROWS positions of every octave in one launch: tile_start[o] is the
+// first linear tile of octave o.
 struct ExtremaTiles {
     int n_oct;
     int tile_start[MAX_OCT + 1];
     int tiles_x[MAX_OCT];
 };
 
-// One thread per position of an octave, all SL layers: the centre values decide first (most
-// positions are below the contrast floor in every layer), then the 3 x 3 neighbourhoods of the
-// SL + 2 difference planes are loaded once and serve all layers.
+// positions per wave: 62 columns (lanes 1..62; lanes 0 and 63 only carry the neighbouring columns) x 4 rows per lane
+constexpr int EX_COLS = 62, EX_ROWS = 4;
+
+// the value of the lane to the left / right (wave-wide shifts of the vector ALU)
+__device__ __forceinline__ float lane_left(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_right(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// A lane takes EX_ROWS consecutive positions of one column, all SL layers.  It loads its own column
+// only (EX_ROWS + 2 rows of the SL + 2 difference planes); the largest and smallest value of a
+// 3 x 3 neighbourhood is the column's maximum over three rows, then the maximum over the lane and
+// its two neighbours.  val >= every one of the 27 values  <=>  val >= the largest of them
+// (likewise the smallest).
 __global__ __launch_bounds__(256) void k_sift_extrema(const SiftFrame* __restrict__ F, ExtremaTiles T, float threshold, int cap) {
     const SiftFrame& f = F[blockIdx.z];
     const SPyr* __restrict__ P = &f.pyr;
     unsigned long long* __restrict__ keys = f.keys;
     int* __restrict__ count = f.counts;
+    const int lin = xcd_tile(blockIdx.x, T.tile_start[T.n_oct]);
+    if (lin < 0) return;
     int octave = 0;
-    while (octave + 1 < T.n_oct && (int)blockIdx.x >= T.tile_start[octave + 1]) octave++;
-    const int tile = blockIdx.x - T.tile_start[octave];
+    while (octave + 1 < T.n_oct && lin >= T.tile_start[octave + 1]) octave++;
+    const int tile = lin - T.tile_start[octave];
     const int ty = tile / T.tiles_x[octave], tx = tile - ty * T.tiles_x[octave];
     const int iw = P->dog[octave * (SL + 2)].w, ih = P->dog[octave * (SL + 2)].h;
-    const int c = SBORDER + tx * 64 + (threadIdx.x & 63), r = SBORDER + ty * 4 + (threadIdx.x >> 6);
-    if (c >= iw - SBORDER || r >= ih - SBORDER) return;
-    gptr<const float> pl[SL + 2];
-#pragma unroll
-    for (int l = 0; l < SL + 2; l++) pl[l] = as_global<const float>(P->dog[octave * (SL + 2) + l].px);
-    const size_t p0 = (size_t)r * iw + c;
-    float ctr[SL];
-    bool any = false;
-#pragma unroll
-    for (int l = 0; l < SL; l++) {
-        ctr[l] = pl[l + 1][p0];
-        any |= fabsf(ctr[l]) > threshold;
-    }
-    if (!any) return;
-    // per plane: the largest and the smallest of the 3 x 3 neighbourhood (the centre included)
-    float hi[SL + 2], lo[SL + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = SBORDER + tx * EX_COLS + lane - 1;
+    const int r0 = SBORDER + (ty * 4 + wv) * EX_ROWS;
+    if (r0 >= ih - SBORDER) return;  // wave-uniform
+    const int cc = min(c, iw - 1);
+    float v[SL + 2][EX_ROWS + 2];
 #pragma unroll
     for (int l = 0; l < SL + 2; l++) {
-        float mx = -INFINITY, mn = INFINITY;
+        const auto pl = as_global<const float>(P->dog[octave * (SL + 2) + l].px);
 #pragma unroll
-        for (int dy = -1; dy <= 1; dy++)
+        for (int k = 0; k < EX_ROWS + 2; k++) v[l][k] = pl[(size_t)min(r0 - 1 + k, ih - 1) * iw + cc];
+    }
+    float hi[SL + 2][EX_ROWS], lo[SL + 2][EX_ROWS];
 #pragma unroll
-            for (int dx = -1; dx <= 1; dx++) {
-                const float v = pl[l][p0 + (size_t)((long)dy * iw + dx)];
-                mx = fmaxf(mx, v);
-                mn = fminf(mn, v);
+    for (int l = 0; l < SL + 2; l++)
+#pragma unroll
+        for (int k = 0; k < EX_ROWS; k++) {
+            const float m = fmaxf(fmaxf(v[l][k], v[l][k + 1]), v[l][k + 2]);
+            const float n = fminf(fminf(v[l][k], v[l][k + 1]), v[l][k + 2]);
+            hi[l][k] = fmaxf(fmaxf(lane_left(m), m), lane_right(m));
+            lo[l][k] = fminf(fminf(lane_left(n), n), lane_right(n));
+        }
+    const bool col_ok = lane != 0 && lane != 63 && c < iw - SBORDER;
+#pragma unroll
+    for (int l = 0; l < SL; l++)
+#pragma unroll
+        for (int k = 0; k < EX_ROWS; k++) {
+            const float val = v[l + 1][k + 1];
+            bool hit = col_ok && fabsf(val) > threshold && r0 + k < ih - SBORDER;
+            if (hit) {
+                const bool mx = val > 0 && val >= fmaxf(fmaxf(hi[l][k], hi[l + 1][k]), hi[l + 2][k]);
+                const bool mn = val < 0 && val <= fminf(fminf(lo[l][k], lo[l + 1][k]), lo[l + 2][k]);
+                hit = mx || mn;
             }
-        hi[l] = mx, lo[l] = mn;
-    }
-#pragma unroll
-    for (int l = 0; l < SL; l++) {
-        const float val = ctr[l];
-        if (!(fabsf(val) > threshold)) continue;
-        // val >= every one of the 27 values  <=>  val >= the largest of them (likewise the smallest)
-        const bool mx = val > 0 && val >= fmaxf(fmaxf(hi[l], hi[l + 1]), hi[l + 2]);
-        const bool mn = val < 0 && val <= fminf(fminf(lo[l], lo[l + 1]), lo[l + 2]);
-        if (!(mx || mn)) continue;
-        const int pos = atomicAdd(count, 1);
-        if (pos < cap)
-            keys[pos] = ((unsigned long long)octave << 56) | ((unsigned long long)(l + 1) << 48) | ((unsigned long long)r << 24) |
-                        (unsigned long long)c;
-    }
+            // one addition to the frame's counter per wave and (layer, row), not one per candidate
+            const unsigned long long m = __ballot(hit);
+            if (m == 0) continue;  // wave-uniform
+            int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, __popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (hit) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (pos < cap)
+                    keys[pos] = ((unsigned long long)octave << 56) | ((unsigned long long)(l + 1) << 48) |
+                                ((unsigned long long)(r0 + k) << 24) | (unsigned long long)c;
+            }
+        }
 }
 
 __device__ bool solve3(const float a[3][3], const float b[3], float x[3]) {
@@ -970,7 +1028,7 @@ int sift_geometry(rtvm_ctx* c, int h, int w, SiftGeom& g) {
     memset(&g.tiles, 0, sizeof(g.tiles));
     for (int o = 0; o < g.n_oct; o++) {
         if (!(g.oh[o] > 2 * SBORDER && g.ow[o] > 2 * SBORDER)) break;  // the octaves only get smaller
-        const int tx = (g.ow[o] - 2 * SBORDER + 63) / 64, ty = (g.oh[o] - 2 * SBORDER + 3) / 4;
+        const int tx = (g.ow[o] - 2 * SBORDER + EX_COLS - 1) / EX_COLS, ty = (g.oh[o] - 2 * SBORDER + 4 * EX_ROWS - 1) / (4 * EX_ROWS);
         g.tiles.tiles_x[o] = tx;
         g.tiles.tile_start[o + 1] = g.tiles.tile_start[o] + tx * ty;
         g.tiles.n_oct = o + 1;
@@ -1019,9 +1077,8 @@ int sift_blur(rtvm_ctx* c, const SiftFrame* d_frames, int nb, int src, int dst, 
               int dog) {
 #define SIFT_BLUR_N(N)                                                                                                   \
     case N:                                                                                                              \
-        RTVM_LAUNCH(c, k_sift_blur_rows<N>, grid_rows(w, h, nb), dim3(256), 0, d_frames, src, PLANE_SCRATCH, h, w, t);   \
-        RTVM_LAUNCH(c, k_sift_blur_cols<N>, grid_cols(w, h, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, dst, h, w, t,    \
-                    below, dog);                                                                                         \
+        RTVM_LAUNCH(c, k_sift_blur<N>, dim3(xcd_grid(((w + SBT_W - 1) / SBT_W) * ((h + SBT_H - 1) / SBT_H)), 1, nb), dim3(256),  \
+                    0, d_frames, src, dst, h, w, t, below, dog);                                                         \
         break;
     switch (t.n) {
         SIFT_BLUR_N(11)
@@ -1030,8 +1087,8 @@ int sift_blur(rtvm_ctx* c, const SiftFrame* d_frames, int nb, int src, int dst, 
         SIFT_BLUR_N(21)
         SIFT_BLUR_N(27)
         default:
-            RTVM_LAUNCH(c, k_sift_blur_rows<0>, grid3(w, h, nb), dim3(256), 0, d_frames, src, PLANE_SCRATCH, h, w, t);
-            RTVM_LAUNCH(c, k_sift_blur_cols<0>, grid3(w, h, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, dst, h, w, t, below,
+            RTVM_LAUNCH(c, k_sift_blur_rows, grid3(w, h, nb), dim3(256), 0, d_frames, src, PLANE_SCRATCH, h, w, t);
+            RTVM_LAUNCH(c, k_sift_blur_cols, grid3(w, h, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, dst, h, w, t, below,
                         dog);
     }
 #undef SIFT_BLUR_N
@@ -1045,7 +1102,7 @@ int sift_launch(rtvm_ctx* c, const SiftGeom& g, const SiftFrame* d_frames, int n
     // base image: doubled, blurred by sqrt(sigma^2 - 1) (into gp[0] via the last DoG plane of octave 0 as a temporary)
     {
         const int dbl = PLANE_DOG + SL + 1;  // free until the DoG of octave 0 is formed
-        RTVM_LAUNCH(c, k_sift_base, grid3(bw, bh, nb), dim3(256), 0, d_frames, g.h, g.w, dbl, rtvm_gray_coef(c));
+        RTVM_LAUNCH(c, k_sift_base, grid3(g.w, g.h, nb), dim3(256), 0, d_frames, g.h, g.w, dbl, rtvm_gray_coef(c));
         sift_blur(c, d_frames, nb, dbl, 0, bh, bw, g.base, -1, -1);
     }
     for (int o = 0; o < g.o_small; o++) {
@@ -1069,7 +1126,7 @@ int sift_launch(rtvm_ctx* c, const SiftGeom& g, const SiftFrame* d_frames, int n
                     g.lds_px);
     }
     if (g.tiles.n_oct > 0)
-        RTVM_LAUNCH(c, k_sift_extrema, dim3(g.tiles.tile_start[g.tiles.n_oct], 1, nb), dim3(256), 0, d_frames, g.tiles,
+        RTVM_LAUNCH(c, k_sift_extrema, dim3(xcd_grid(g.tiles.tile_start[g.tiles.n_oct]), 1, nb), dim3(256), 0, d_frames, g.tiles,
                     g.threshold, SIFT_CAND_CAP);
     // refinement of every candidate, queued behind the extrema without a host round trip; then
     // removeDuplicatedSorted + retainBest on the device, then the descriptors of what is kept

@@ -417,9 +417,9 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
 
 // blockIdx.z = frame of the batch.  Tiles of BR_TILE x 4 pixels of the frame's region (rows of
 // the blend window, columns of the ROI), tile (0,0) holding the region's first pixel.
-// REST = false: one tile per workgroup, the grid (ex x ey tiles) sized for a region of about
-// the frame's size.  REST = true: a small grid that loops over the tiles beyond ex x ey, for
-// regions larger than expected (normally none).
+// REST = false: one tile per workgroup, the grid (xcd_grid(ex * ey) workgroups) sized for a region
+// of about the frame's size.  REST = true: a small grid that loops over the tiles beyond that many,
+// for regions larger than expected (normally none).
 template <bool REST>
 __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
                                                    const SideDev* __restrict__ sides, int cw, int ex, int ey) {
@@ -428,19 +428,18 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
     __shared__ __align__(16) f32x2 s_w[4][BR_STAGE];
     const int rx1 = wp->rx1, wy1 = wp->wy1;
     const int ox = wp->rx0 & ~3, oy = wp->wy0;
-    if (!REST) {
-        const int bx = ox + BR_TILE * (int)blockIdx.x, by = oy + 4 * (int)blockIdx.y;
-        if (bx < rx1 && by < wy1) blur_rows_tile(wp, gk, side, cw, bx, by, s_w);
+    const int ntx = rx1 > ox ? (rx1 - ox + BR_TILE - 1) / BR_TILE : 0, nty = wy1 > oy ? (wy1 - oy + 3) / 4 : 0;
+    const int T = ntx * nty, G = xcd_grid(ex * ey);
+    if (!REST) {  // G workgroups in x: the region's tiles in one contiguous run per XCD
+        const int t = T <= G ? xcd_tile(blockIdx.x, T) : (int)blockIdx.x;
+        if (t < 0 || t >= T) return;
+        blur_rows_tile(wp, gk, side, cw, ox + BR_TILE * (t % ntx), oy + 4 * (t / ntx), s_w);
         return;
     }
-    const int ntx = rx1 > ox ? (rx1 - ox + BR_TILE - 1) / BR_TILE : 0, nty = wy1 > oy ? (wy1 - oy + 3) / 4 : 0;
-    if (ntx <= ex && nty <= ey) return;
-    for (int ty = blockIdx.y; ty < nty; ty += gridDim.y)
-        for (int tx = blockIdx.x; tx < ntx; tx += gridDim.x) {
-            if (tx < ex && ty < ey) continue;  // done by the one-tile-per-workgroup launch
-            blur_rows_tile(wp, gk, side, cw, ox + BR_TILE * tx, oy + 4 * ty, s_w);
-            __syncthreads();  // the staging area is reused by the next tile
-        }
+    for (int t = G + blockIdx.y * gridDim.x + blockIdx.x; t < T; t += gridDim.x * gridDim.y) {
+        blur_rows_tile(wp, gk, side, cw, ox + BR_TILE * (t % ntx), oy + 4 * (t / ntx), s_w);
+        __syncthreads();  // the staging area is reused by the next tile
+    }
 }
 
 // Column pass of the blur (s = k15*r0, then s = fma(r[+t] + r[-t], k[15+t], s) outwards) for
@@ -511,18 +510,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     const SideDev side = sides[blockIdx.z];
     const int rx1 = wp->rx1, ry1 = wp->ry1;
     const int ox = wp->rx0 & ~63, oy = wp->ry0;
-    if (!REST) {
-        const int bx = ox + 64 * (int)blockIdx.x, by = oy + 4 * BC_ROWS * (int)blockIdx.y;
-        if (bx < rx1 && by < ry1) blur_cols_tile(wp, gk, side, ch, cw, bx, by);
+    const int ntx = rx1 > ox ? (rx1 - ox + 63) / 64 : 0, nty = ry1 > oy ? (ry1 - oy + 4 * BC_ROWS - 1) / (4 * BC_ROWS) : 0;
+    const int T = ntx * nty, G = xcd_grid(ex * ey);
+    if (!REST) {  // G workgroups in x: the region's tiles in one contiguous run per XCD
+        const int t = T <= G ? xcd_tile(blockIdx.x, T) : (int)blockIdx.x;
+        if (t < 0 || t >= T) return;
+        blur_cols_tile(wp, gk, side, ch, cw, ox + 64 * (t % ntx), oy + 4 * BC_ROWS * (t / ntx));
         return;
     }
-    const int ntx = rx1 > ox ? (rx1 - ox + 63) / 64 : 0, nty = ry1 > oy ? (ry1 - oy + 4 * BC_ROWS - 1) / (4 * BC_ROWS) : 0;
-    if (ntx <= ex && nty <= ey) return;
-    for (int ty = blockIdx.y; ty < nty; ty += gridDim.y)
-        for (int tx = blockIdx.x; tx < ntx; tx += gridDim.x) {
-            if (tx < ex && ty < ey) continue;
-            blur_cols_tile(wp, gk, side, ch, cw, ox + 64 * tx, oy + 4 * BC_ROWS * ty);
-        }
+    for (int t = G + blockIdx.y * gridDim.x + blockIdx.x; t < T; t += gridDim.x * gridDim.y)
+        blur_cols_tile(wp, gk, side, ch, cw, ox + 64 * (t % ntx), oy + 4 * BC_ROWS * (t / ntx));
 }
 
 // Blend and commit of all frames of a batch (main.py:905-927).  With the blend weights
@@ -753,14 +750,14 @@ int rtvm_launch_weights(rtvm_ctx* c, int n) {
     const int bw = c->fw + c->fh / 2, bh = c->fh + c->fw / 2;  // a region of about the frame's size
     {
         const unsigned ex = roi_tiles(c->cw, bw, BR_TILE), ey = roi_tiles(c->ch, bh + 30, 4);
-        RTVM_LAUNCH(c, k_blur_rows<false>, dim3(ex, ey, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
+        RTVM_LAUNCH(c, k_blur_rows<false>, dim3(xcd_grid(ex * ey), 1, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
                     (int)ey);
         RTVM_LAUNCH(c, k_blur_rows<true>, dim3(2, 8, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
                     (int)ey);
     }
     {
         const unsigned ex = roi_tiles(c->cw, bw, 64), ey = roi_tiles(c->ch, bh, 4 * BC_ROWS);
-        RTVM_LAUNCH(c, k_blur_cols<false>, dim3(ex, ey, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw,
+        RTVM_LAUNCH(c, k_blur_cols<false>, dim3(xcd_grid(ex * ey), 1, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw,
                     (int)ex, (int)ey);
         RTVM_LAUNCH(c, k_blur_cols<true>, dim3(4, 2, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw, (int)ex,
                     (int)ey);

@@ -14,10 +14,18 @@ step() {  # name, limit, command...
     echo "[$name] exit $rc"; tail -n 2 "$OUT/$name.log"
     [ $rc -eq 0 ] || exit $rc
 }
+CFG=${CONFIG:-720p_orb1000}
+if [ "$CFG" = 720p_orb1000 ]; then
 step pmc_calib_fetch 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_calib_fetch" --output-format csv -- "$ROOT/tools/bin/pmc_calib"
 step pmc_calib_write 120 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_calib_write" --output-format csv -- "$ROOT/tools/bin/pmc_calib"
-step pmc_fetch 240 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" --output-format csv -- python3 "$ROOT/tools/pmc_run.py" 48 720p_orb1000
-step pmc_write 240 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" --output-format csv -- python3 "$ROOT/tools/pmc_run.py" 48 720p_orb1000
+fi
+rm -rf "$OUT/pmc_fetch_$CFG" "$OUT/pmc_write_$CFG"
+step pmc_fetch_$CFG 240 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch_$CFG" --output-format csv -- python3 "$ROOT/tools/pmc_run.py" 48 $CFG
+step pmc_write_$CFG 240 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write_$CFG" --output-format csv -- python3 "$ROOT/tools/pmc_run.py" 48 $CFG
 cd "$ROOT"
-python3 tools/pmc_traffic.py "$OUT/r2_pmc_traffic.json" 48 720p_orb1000 "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_calib_fetch" "$OUT/pmc_calib_write" || exit 1
+if [ "$CFG" = 720p_orb1000 ]; then
+python3 tools/pmc_traffic.py "$OUT/r2_pmc_traffic.json" 48 $CFG "$OUT/pmc_fetch_$CFG" "$OUT/pmc_write_$CFG" "$OUT/pmc_calib_fetch" "$OUT/pmc_calib_write" || exit 1
+else
+python3 tools/pmc_traffic.py "$OUT/r2_pmc_traffic_$CFG.json" 48 $CFG "$OUT/pmc_fetch_$CFG" "$OUT/pmc_write_$CFG" || exit 1
+fi
 echo "traffic summary written"
