@@ -18,7 +18,7 @@
 //   k_dt_diag_a  per (line, chunk): the 32 zero bits of the line inside the chunk, by
 //                32x32 bit-matrix transposes of windows of the bit rows; per (line,
 //                16 chunks): which chunks hold a zero
-//   k_dt_diag_b  per tile of 32 rows x 256 columns: steps to the nearest zero along
+//   k_dt_diag_b  per tile of 32 rows x 192 columns: steps to the nearest zero along
 //                both diagonals (bit scans inside the chunk, the chunk summaries
 //                beyond it), minimum of the two through LDS, one u16 plane out
 //   k_dt_scan    row scans of the output window's rows (wave prefix minima), and
@@ -35,7 +35,8 @@ constexpr uint32_t DT_MAX = 0xFFFFFFFFu - DT_B;  // OpenCV's DIST_MAX
 constexpr uint32_t INF32 = 0xFFFFFFFFu;
 constexpr int CH = 32;                         // rows per chunk
 constexpr int GR = 16;                         // chunks per summary group
-constexpr int TW = 256;                        // columns per tile of k_dt_diag_b
+constexpr int TW = 192;                        // columns per tile of k_dt_diag_b: TW + 31 lines fit 256 threads
+constexpr int DB_THREADS = 256;
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t v, uint32_t k) {
     return v > INF32 - k ? INF32 : v + k;
@@ -231,9 +232,10 @@ __device__ __forceinline__ void diag_steps(const DtJobG& jb, const LineGeom& g, 
 }
 
 // One workgroup per tile of 32 rows x TW columns (columns on a grid of TW from 0, so the
-// rows of a tile are 16-byte aligned when the pitch is a multiple of 8).  Tiles that touch
+// rows of a tile are 16-byte aligned when the pitch is a multiple of 8).  Four waves and 24 KB of
+// LDS: a workgroup that needs more than the kernels of the other streams do waits for them.  Tiles that touch
 // neither the rows nor the columns of the output window are never read and are skipped.
-__global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ jobs, int n_first, int second) {
+__global__ __launch_bounds__(DB_THREADS) void k_dt_diag_b(const DtJob* __restrict__ jobs, int n_first, int second) {
     const DtJobG jb(jobs[job_index(blockIdx.z, n_first, second)]);
     const LineGeom g = line_geom(jb);
     const int c = blockIdx.y;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ job
     __shared__ __align__(16) uint16_t T[2][CH][TW];
     const int i = threadIdx.x;
     if (jb.x0 > X || jb.x1 < X + TW) {
-        for (int e = i; e < 2 * CH * TW / 8; e += 320) reinterpret_cast<uint4*>(&T[0][0][0])[e] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int e = i; e < 2 * CH * TW / 8; e += DB_THREADS) reinterpret_cast<uint4*>(&T[0][0][0])[e] = make_uint4(~0u, ~0u, ~0u, ~0u);
         __syncthreads();
     }
     if (i < TW + CH - 1) {
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ job
     __syncthreads();
     const int nrows = min(CH, jb.y1 - ya);
     if ((jb.pitch & 7) == 0 && X + TW <= jb.pitch) {
-        for (int e = i; e < nrows * (TW / 8); e += 320) {
+        for (int e = i; e < nrows * (TW / 8); e += DB_THREADS) {
             const int r = e / (TW / 8), q = e % (TW / 8);
             const int x = X + q * 8;
             if (x + 8 <= jb.x0 || x >= jb.x1) continue;
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(320) void k_dt_diag_b(const DtJob* __restrict__ job
                                                                       pk_min_u16(a.z, b.z), pk_min_u16(a.w, b.w)));
         }
     } else {
-        for (int e = i; e < nrows * TW; e += 320) {
+        for (int e = i; e < nrows * TW; e += DB_THREADS) {
             const int r = e / TW, x = X + e % TW;
             if (x < jb.x0 || x >= jb.x1) continue;
             jb.S[(size_t)(ya + r) * jb.pitch + x] = min(T[0][r][e % TW], T[1][r][e % TW]);
@@ -654,7 +656,7 @@ int rtvm_launch_dt2(rtvm_ctx* c, const DtJob* d_jobs, int n_first, int second, i
                     second);
     RTVM_LAUNCH(c, k_dt_diag_a, dim3((nlines + 63) / 64, (nch + GR - 1) / GR, 2 * njobs), dim3(256), 0, d_jobs, n_first,
                 second);
-    RTVM_LAUNCH(c, k_dt_diag_b, dim3(max_w / TW + 2, nch, njobs), dim3(320), 0, d_jobs, n_first, second);
+    RTVM_LAUNCH(c, k_dt_diag_b, dim3(max_w / TW + 2, nch, njobs), dim3(DB_THREADS), 0, d_jobs, n_first, second);
     RTVM_LAUNCH(c, k_dt_scan, dim3(max_h + ncol_x * ((nch + 3) / 4), njobs), dim3(256), 0, d_jobs, n_first, second, max_h,
                 ncol_x);
     if (max_w + 7 > 2048)  // rows that take more than one pass of the row scan
