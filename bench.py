@@ -290,6 +290,7 @@ def leg_dropin(args, cfg, frames, local_rank, T):
     n_warm = min(32, nd // 4)
     host_frames = frames[:nd + 1].cpu().numpy()
     kw = dict(detector_type="orb", nfeatures=nf, canvas_size=(ch, cw), device=local_rank, warp_mode=args.warp_mode)
+    progress("drop-in leg: headless process_frame, %d frames" % nd)
     vm = rtvm.VideMosaic(host_frames[0], show_intermediate=False, visualize=False, **kw)
     for t in range(1, n_warm + 1):
         vm.process_frame(host_frames[t], t)
@@ -308,6 +309,7 @@ def leg_dropin(args, cfg, frames, local_rank, T):
     vm.close()
     # the same class with a display flag set: every call completes before it returns
     ns = min(136, nd)
+    progress("drop-in leg: synchronous process_frame, %d frames" % ns)
     vm = rtvm.VideMosaic(host_frames[0], show_intermediate=True, visualize=False, **kw)
     vm.process_frame(host_frames[1], 1)
     td0 = time.perf_counter()
@@ -318,6 +320,7 @@ def leg_dropin(args, cfg, frames, local_rank, T):
     vm.close()
     if ns >= 16:
         # ... and through process_frames: detection, matching and RANSAC on four worker threads
+        progress("drop-in leg: process_frames with 4 workers")
         vm = rtvm.VideMosaic(host_frames[0], show_intermediate=True, visualize=False, **kw)
         vm.process_frames(list(host_frames[1:9]), 1, workers=4)
         td0 = time.perf_counter()
@@ -338,6 +341,7 @@ def leg_sift(args, cfg, frames, local_rank, T):
     kw = dict(detector_type="sift", nfeatures=700, canvas_size=(ch, cw), device=local_rank, warp_mode=args.warp_mode)
     # headless (main.py --hide): process_frame only takes the frame; 32 frames of warm-up (the pipeline's buffers
     # are reserved on the first call), then the rest, the clock stopping with every frame stitched
+    progress("SIFT leg: headless process_frame, %d frames" % ns)
     vm = rtvm.VideMosaic(host_frames[0], show_intermediate=False, visualize=False, **kw)
     nw = min(32, ns // 2)
     for t in range(1, nw + 1):
@@ -354,6 +358,7 @@ def leg_sift(args, cfg, frames, local_rank, T):
            "note": "VideMosaic(detector_type='sift').process_frame, headless, one host frame per call, PCIe included"}
     vm.close()
     # with a display flag every call completes before it returns
+    progress("SIFT leg: synchronous process_frame and process_frames")
     vm = rtvm.VideMosaic(host_frames[0], show_intermediate=True, visualize=False, **kw)
     n1 = min(16, ns - 1)
     vm.process_frame(host_frames[1], 1)
@@ -378,6 +383,7 @@ def leg_host_ring(args, cfg, frames, local_rank, T, B):
     fh, fw, ch, cw, nf = cfg
     nh = min(args.host_frames, T - 1)
     host_frames = frames[:nh + 1].cpu().numpy()
+    progress("host ring leg, %d frames" % nh)
     ctx2 = rtvm.Context(fh, fw, ch, cw, nfeatures=nf,
                         flags=(rtvm._ffi.FLAG_WARP_FIXED if args.warp_mode == "fixed" else 0), device=local_rank)
     ctx2.process_host_video(host_frames[0], host_frames[1:1 + min(64, nh)], ch - fh, int(cw / 2 - fw / 2), batch=B)

@@ -410,27 +410,18 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
     // points only, one call at a time: it gets a single stream.  (A process has few hardware queues and streams are dealt onto them in
     // turn; four streams per context would put the working streams of several such contexts, one
     // per host thread, onto the same queue.)
-    const bool four = frame_h > 0 && !(flags & RTVM_FLAG_SINGLE_STREAM);
-    // With four streams the canvas half (main stream) is the chain that bounds the frame rate and
-    // the other three work batches ahead of it: the main stream gets the high queue priority, so
-    // that its workgroups are placed first whenever a compute unit has room.
-    int prio_low = 0, prio_high = 0;
-    if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) {
-        delete c;
-        return RTVM_E_HIP;
-    }
-    const char* pe = getenv("RTVM_STREAM_PRIORITY");
-    const bool use_prio = four && !(pe && pe[0] == '0');
-    if ((use_prio ? hipStreamCreateWithPriority(&c->stream_main, hipStreamDefault, prio_high) : hipStreamCreate(&c->stream_main)) !=
-        hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream_main) != hipSuccess) {
         delete c;
         return RTVM_E_HIP;
     }
     c->stream_front = c->stream_rs = c->stream_lm = c->stream_main;
-    if (four) {
+    // (All streams at the default priority: with the main stream on a high-priority queue the frame
+    // rate rose by under 1 %, and a context used next to the single-stream contexts of worker
+    // threads stopped making progress.)
+    if (frame_h > 0 && !(flags & RTVM_FLAG_SINGLE_STREAM)) {
         hipStream_t* more[3] = {&c->stream_front, &c->stream_rs, &c->stream_lm};
         for (hipStream_t* st : more)
-            if ((use_prio ? hipStreamCreateWithPriority(st, hipStreamDefault, prio_low) : hipStreamCreate(st)) != hipSuccess) {
+            if (hipStreamCreate(st) != hipSuccess) {
                 *st = c->stream_main;
                 destroy_streams(c);
                 delete c;
