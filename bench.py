@@ -94,14 +94,14 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
         "k_rs_refine": nkp * 16,               # matched point pairs in (latency bound: fp64 solver chains)
     }
     # SIFT scale space: the doubled image and the octaves built layer by layer (the octaves of at most 4000
-    # pixels are built in LDS by one workgroup); a blur reads a layer and the layer below it and writes the next
-    # layer and the difference of Gaussians (the first blur of the doubled image: one plane in, one out)
+    # pixels are built in LDS by one workgroup); a blur reads a layer and writes the next one; the differences
+    # of Gaussians are not stored: the extrema kernel reads the six Gaussian layers of an octave
     big, oh, ow = [], 2 * fh, 2 * fw
     while oh * ow > 4000 or not big:
         big.append(oh * ow)
         oh, ow = oh // 2, ow // 2
-    table["k_sift_blur"] = 8 * big[0] + 16 * 5 * sum(big)
-    table["k_sift_extrema"] = 4 * 5 * sum(big)          # every difference plane once
+    table["k_sift_blur"] = 8 * big[0] + 8 * 5 * sum(big)
+    table["k_sift_extrema"] = 4 * 6 * sum(big)          # every Gaussian plane once
     return table.get(name)
 
 

@@ -247,6 +247,12 @@ long rtvm_batch_ticket(rtvm_ctx* ctx);
  * frames were left pending.  Waits for that batch only. */
 int rtvm_batch_status_of(rtvm_ctx* ctx, long ticket, int* n_done, int* reason, int* status,
                          int* n_matches, int* n_keypoints, int cap);
+/* Index (within the piece / batch `ticket`, one of the last 16) of the first frame whose blend
+ * turned a non-zero canvas pixel into zero, or -1: the event behind RTVM_PENDING_MASK, reported
+ * also when the frame was the last of its piece and nothing had to be left pending.  Such frames
+ * come in runs; a caller sizes its next pieces by it.  Waits for that batch only.  No counterpart
+ * in the reference (its blend, main.py:905-927, is one frame at a time). */
+int rtvm_batch_cleared(rtvm_ctx* ctx, long ticket, int* first);
 /* Queues the canvas half again (validate / smooth / chain, warp, blend) for frames first ..
  * first+count-1 of the batch `ticket` (queued with rtvm_process_batch or rtvm_batch_detect and still holding its slot set),
  * reusing its detection, matching and RANSAC results: for frames left pending with

@@ -74,6 +74,7 @@ SIGNATURES = {
     "rtvm_batch_status_at": (C.c_int, [_vp, C.c_int, _intp, _vp, _vp, _vp, C.c_int]),
     "rtvm_batch_ticket": (C.c_long, [_vp]),
     "rtvm_batch_status_of": (C.c_int, [_vp, C.c_long, _intp, _intp, _vp, _vp, _vp, C.c_int]),
+    "rtvm_batch_cleared": (C.c_int, [_vp, C.c_long, _intp]),
     "rtvm_batch_retry": (C.c_int, [_vp, C.c_long, C.c_int, C.c_int]),
     "rtvm_batch_detect": (C.c_int, [_vp, _vp, C.c_int]),
     "rtvm_batch_release": (C.c_int, [_vp, C.c_long]),
@@ -582,6 +583,12 @@ class Context:
         self._check(lib().rtvm_batch_status_of(self._h, ticket, C.byref(done), C.byref(reason), ptr(st), ptr(nm),
                                                ptr(nk), n))
         return done.value, reason.value, st, nm, nk
+
+    def batch_cleared(self, ticket):
+        """Index of the first frame of the piece / batch `ticket` whose blend cleared a canvas pixel, or -1."""
+        first = C.c_int(-1)
+        self._check(lib().rtvm_batch_cleared(self._h, ticket, C.byref(first)))
+        return first.value
 
     def batch_retry(self, ticket, first, count):
         """Queues the canvas half again for frames first .. first+count-1 of the batch `ticket`;

@@ -227,6 +227,7 @@ struct StreamState {
 struct BatchReport {
     int n_done, abort, tail_ok;
     int reason;   // why n_done < n: RTVM_PENDING_*
+    int cleared;  // first frame of the piece whose blend cleared a canvas pixel, or -1
     int status[RTVM_MAX_BATCH];
     int matches[RTVM_MAX_BATCH];
     int kp[RTVM_MAX_BATCH];

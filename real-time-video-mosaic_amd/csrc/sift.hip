@@ -9,7 +9,7 @@
 //   k_sift_blur_rows / k_sift_blur_cols
 //                    cv::GaussianBlur(Size(), sigma) on floats: row pass s = k0*x0,
 //                    fma(x_i, k_i, s); column pass centre then fma(r[+i] + r[-i], k_i, s); the
-//                    column pass also writes the difference of Gaussians to the layer below
+//                    differences of Gaussians are not stored (see SDog)
 //   k_sift_decimate  next octave = every second pixel of layer 3
 //   k_sift_extrema   26-neighbour extrema above the contrast floor -> candidate keys (every
 //                    octave and layer in one launch)
@@ -60,13 +60,26 @@ struct SKp {
 
 struct SPyr {
     SImg gp[MAX_OCT * (SL + 3)];
-    SImg dog[MAX_OCT * (SL + 2)];
 };
+
+// Difference-of-Gaussians layer d of an octave = Gaussian layer d + 1 minus layer d.  The
+// differences are not stored: whoever needs one subtracts the two Gaussian values (the same float
+// subtraction a stored plane would hold), which saves writing and reading five planes per octave.
+struct SDog {
+    const float* hi;
+    const float* lo;
+    int h, w;
+};
+__device__ __forceinline__ SDog dog_layer(const SPyr* __restrict__ P, int octave, int d) {
+    const SImg a = P->gp[octave * (SL + 3) + d + 1], b = P->gp[octave * (SL + 3) + d];
+    return SDog{a.px, b.px, a.h, a.w};
+}
+#define DAT(dg, y, x) ((dg).hi[(size_t)(y) * (dg).w + (x)] - (dg).lo[(size_t)(y) * (dg).w + (x)])
 
 // Everything one frame of a batch needs, in device memory; the kernels index an array of these
 // with the frame's position in the batch.  All frames of a batch have the same geometry.
 struct SiftFrame {
-    SPyr pyr;                   // planes of the frame's Gaussian and difference pyramids
+    SPyr pyr;                   // planes of the frame's Gaussian pyramid
     float* scratch;             // row-pass plane (size of the doubled image)
     const uint8_t* bgr;         // frame pixels
     unsigned long long* keys;   // scale-space extrema
@@ -84,10 +97,10 @@ struct SiftFrame {
     int* n_out;
 };
 
-// plane ids: Gaussian layer g, 256 + difference layer d, or the row-pass plane
-constexpr int PLANE_DOG = 256, PLANE_SCRATCH = 1024;
+// plane ids: Gaussian layer g (octave * (SL + 3) + layer), or the row-pass plane of the two-pass blur
+constexpr int PLANE_SCRATCH = 1024;
 __device__ __forceinline__ float* plane(const SiftFrame& f, int id) {
-    return id == PLANE_SCRATCH ? f.scratch : id >= PLANE_DOG ? f.pyr.dog[id - PLANE_DOG].px : f.pyr.gp[id].px;
+    return id == PLANE_SCRATCH ? f.scratch : f.pyr.gp[id].px;
 }
 
 __device__ __forceinline__ int reflect101s(int p, int n) {
@@ -202,21 +215,17 @@ __global__ __launch_bounds__(256) void k_sift_blur_rows(const SiftFrame* __restr
     dst[(size_t)y * w + x] = (x >= half && x + half < w) ? row_taps(t, row + (x - half)) : row_taps_border(t, row, x, w);
 }
 
-// Column pass; with `below` (the Gaussian layer under the one being made) it also writes the
-// difference of the two layers, dog = this - below, the value a separate subtraction would give.
+// Column pass.
 __global__ __launch_bounds__(256) void k_sift_blur_cols(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w,
-                                                        Taps t, int below_id, int dog_id) {
+                                                        Taps t) {
     const SiftFrame& f = F[blockIdx.z];
     const float* __restrict__ src = plane(f, src_id);
     float* __restrict__ dst = plane(f, dst_id);
-    const float* __restrict__ below = below_id >= 0 ? plane(f, below_id) : nullptr;
-    float* __restrict__ dog = below_id >= 0 ? plane(f, dog_id) : nullptr;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const int half = t.n / 2;
-    const float a = (y >= half && y + half < h) ? col_taps(t, src + (size_t)y * w + x, w) : col_taps_border(t, src + x, y, h, w);
-    dst[(size_t)y * w + x] = a;
-    if (below) dog[(size_t)y * w + x] = a - below[(size_t)y * w + x];
+    dst[(size_t)y * w + x] =
+        (y >= half && y + half < h) ? col_taps(t, src + (size_t)y * w + x, w) : col_taps_border(t, src + x, y, h, w);
 }
 
 // Both passes of one blur for a tile of SBT_W x SBT_H outputs, compiled per kernel length N (11,
@@ -230,12 +239,11 @@ __global__ __launch_bounds__(256) void k_sift_blur_cols(const SiftFrame* __restr
 //     multiply-adds in tap order;
 //   column pass: a thread takes 16 consecutive rows of one column from a window of 16 + N - 1
 //     row-passed values in registers (centre first, then the symmetric pairs outwards) and writes
-//     the layer and, with `below`, the difference of Gaussians.
+//     the layer.
 constexpr int SBT_W = 128, SBT_H = 32, SB_R = 8, SB_C = 16, SBT_STAGE = SBT_W + 32;
 
 template <int N>
-__global__ __launch_bounds__(256) void k_sift_blur(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w, Taps t,
-                                                   int below_id, int dog_id) {
+__global__ __launch_bounds__(256) void k_sift_blur(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w, Taps t) {
     constexpr int half = N / 2, RB = SBT_H + N - 1, NIN = SBT_W + N - 1, WIN4 = (SB_R + N - 1 + 3) / 4;
     static_assert(N % 2 == 1 && NIN <= SBT_STAGE && (SBT_W - SB_R) + 4 * WIN4 <= SBT_STAGE, "windows fit the staged row");
     static_assert(SBT_W == 16 * SB_R && SBT_H == 2 * SB_C, "thread mapping of the two passes");
@@ -317,31 +325,9 @@ __global__ __launch_bounds__(256) void k_sift_blur(const SiftFrame* __restrict__
         for (int o = 0; o < SB_C; o++) a[o] = __builtin_fmaf(v[o + half + k] + v[o + half - k], t.c[k], a[o]);
     }
     const auto od = as_global(plane(f, dst_id) + (size_t)yo * w + x);
-    if (below_id >= 0) {
-        const auto pb = as_global(plane(f, below_id) + (size_t)yo * w + x);
-        const auto og = as_global(plane(f, dog_id) + (size_t)yo * w + x);
-        if (yo + SB_C <= h) {
-            float b[SB_C];
 #pragma unroll
-            for (int o = 0; o < SB_C; o++) b[o] = pb[(size_t)o * w];
-#pragma unroll
-            for (int o = 0; o < SB_C; o++) {
-                od[(size_t)o * w] = a[o];
-                og[(size_t)o * w] = a[o] - b[o];
-            }
-        } else {
-#pragma unroll
-            for (int o = 0; o < SB_C; o++)
-                if (yo + o < h) {
-                    od[(size_t)o * w] = a[o];
-                    og[(size_t)o * w] = a[o] - pb[(size_t)o * w];
-                }
-        }
-    } else {
-#pragma unroll
-        for (int o = 0; o < SB_C; o++)
-            if (yo + o < h) od[(size_t)o * w] = a[o];
-    }
+    for (int o = 0; o < SB_C; o++)
+        if (yo + o < h) od[(size_t)o * w] = a[o];
 }
 
 __global__ __launch_bounds__(256) void k_sift_decimate(const SiftFrame* __restrict__ F, int src_id, int sw, int dst_id, int h,
@@ -364,11 +350,10 @@ struct TapsAll {
 };
 
 // Layer i of octave o from the layer below it in `cur` (LDS): row pass into rowp, column pass
-// into the pyramid, the difference of the two layers, and `cur` replaced by the new layer.
+// into the pyramid, and `cur` replaced by the new layer.
 __device__ __forceinline__ void small_layer(const SPyr* P, int o, int i, const Taps& t, float* cur, float* rowp, int h, int w) {
     const int tid = threadIdx.x, npx = h * w, half = t.n / 2;
     float* dst = P->gp[o * (SL + 3) + i].px;
-    float* dog = P->dog[o * (SL + 2) + i - 1].px;
     for (int p = tid; p < npx; p += 1024) {
         const int y = p / w, x = p - y * w;
         const float* row = cur + y * w;
@@ -379,7 +364,6 @@ __device__ __forceinline__ void small_layer(const SPyr* P, int o, int i, const T
         const int y = p / w, x = p - y * w;
         const float a = (y >= half && y + half < h) ? col_taps(t, rowp + p, w) : col_taps_border(t, rowp + x, y, h, w);
         dst[p] = a;
-        dog[p] = a - cur[p];
         cur[p] = a;  // only this thread reads cur[p] in this pass
     }
     __syncthreads();
@@ -434,7 +418,7 @@ __device__ __forceinline__ float lane_right(float v) {
 }
 
 // A lane takes EX_ROWS consecutive positions of one column, all SL layers.  It loads its own column
-// only (EX_ROWS + 2 rows of the SL + 2 difference planes); the largest and smallest value of a
+// only (EX_ROWS + 2 rows of the SL + 3 Gaussian planes, whose differences are the SL + 2 difference planes); the largest and smallest value of a
 // 3 x 3 neighbourhood is the column's maximum over three rows, then the maximum over the lane and
 // its two neighbours.  val >= every one of the 27 values  <=>  val >= the largest of them
 // (likewise the smallest).
@@ -449,18 +433,25 @@ __global__ __launch_bounds__(256) void k_sift_extrema(const SiftFrame* __restric
     while (octave + 1 < T.n_oct && lin >= T.tile_start[octave + 1]) octave++;
     const int tile = lin - T.tile_start[octave];
     const int ty = tile / T.tiles_x[octave], tx = tile - ty * T.tiles_x[octave];
-    const int iw = P->dog[octave * (SL + 2)].w, ih = P->dog[octave * (SL + 2)].h;
+    const int iw = P->gp[octave * (SL + 3)].w, ih = P->gp[octave * (SL + 3)].h;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = SBORDER + tx * EX_COLS + lane - 1;
     const int r0 = SBORDER + (ty * 4 + wv) * EX_ROWS;
     if (r0 >= ih - SBORDER) return;  // wave-uniform
     const int cc = min(c, iw - 1);
     float v[SL + 2][EX_ROWS + 2];
+    {
+        float g[SL + 3][EX_ROWS + 2];
 #pragma unroll
-    for (int l = 0; l < SL + 2; l++) {
-        const auto pl = as_global<const float>(P->dog[octave * (SL + 2) + l].px);
+        for (int l = 0; l < SL + 3; l++) {
+            const auto pl = as_global<const float>(P->gp[octave * (SL + 3) + l].px);
 #pragma unroll
-        for (int k = 0; k < EX_ROWS + 2; k++) v[l][k] = pl[(size_t)min(r0 - 1 + k, ih - 1) * iw + cc];
+            for (int k = 0; k < EX_ROWS + 2; k++) g[l][k] = pl[(size_t)min(r0 - 1 + k, ih - 1) * iw + cc];
+        }
+#pragma unroll
+        for (int l = 0; l < SL + 2; l++)
+#pragma unroll
+            for (int k = 0; k < EX_ROWS + 2; k++) v[l][k] = g[l + 1][k] - g[l][k];
     }
     float hi[SL + 2][EX_ROWS], lo[SL + 2][EX_ROWS];
 #pragma unroll
@@ -520,19 +511,19 @@ __device__ bool adjust_extremum(const SPyr* __restrict__ P, int octv, int& layer
     float xi = 0, xr = 0, xc = 0;
     int i = 0;
     for (; i < 5; i++) {
-        const SImg img = P->dog[octv * (SL + 2) + layer];
-        const SImg prev = P->dog[octv * (SL + 2) + layer - 1];
-        const SImg next = P->dog[octv * (SL + 2) + layer + 1];
-        const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
-                             (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
-                             (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
-        const float v2 = AT(img, r, c) * 2;
-        const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second;
-        const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second;
-        const float dss = (AT(next, r, c) + AT(prev, r, c) - v2) * second;
-        const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross;
-        const float dxs = (AT(next, r, c + 1) - AT(next, r, c - 1) - AT(prev, r, c + 1) + AT(prev, r, c - 1)) * cross;
-        const float dys = (AT(next, r + 1, c) - AT(next, r - 1, c) - AT(prev, r + 1, c) + AT(prev, r - 1, c)) * cross;
+        const SDog img = dog_layer(P, octv, layer);
+        const SDog prev = dog_layer(P, octv, layer - 1);
+        const SDog next = dog_layer(P, octv, layer + 1);
+        const float dD[3] = {(DAT(img, r, c + 1) - DAT(img, r, c - 1)) * deriv_scale,
+                             (DAT(img, r + 1, c) - DAT(img, r - 1, c)) * deriv_scale,
+                             (DAT(next, r, c) - DAT(prev, r, c)) * deriv_scale};
+        const float v2 = DAT(img, r, c) * 2;
+        const float dxx = (DAT(img, r, c + 1) + DAT(img, r, c - 1) - v2) * second;
+        const float dyy = (DAT(img, r + 1, c) + DAT(img, r - 1, c) - v2) * second;
+        const float dss = (DAT(next, r, c) + DAT(prev, r, c) - v2) * second;
+        const float dxy = (DAT(img, r + 1, c + 1) - DAT(img, r + 1, c - 1) - DAT(img, r - 1, c + 1) + DAT(img, r - 1, c - 1)) * cross;
+        const float dxs = (DAT(next, r, c + 1) - DAT(next, r, c - 1) - DAT(prev, r, c + 1) + DAT(prev, r, c - 1)) * cross;
+        const float dys = (DAT(next, r + 1, c) - DAT(next, r - 1, c) - DAT(prev, r + 1, c) + DAT(prev, r - 1, c)) * cross;
         const float H[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
         float X[3];
         if (!solve3(H, dD, X)) X[0] = X[1] = X[2] = 0;
@@ -546,19 +537,19 @@ __device__ bool adjust_extremum(const SPyr* __restrict__ P, int octv, int& layer
         if (layer < 1 || layer > SL || c < SBORDER || c >= img.w - SBORDER || r < SBORDER || r >= img.h - SBORDER) return false;
     }
     if (i >= 5) return false;
-    const SImg img = P->dog[octv * (SL + 2) + layer];
-    const SImg prev = P->dog[octv * (SL + 2) + layer - 1];
-    const SImg next = P->dog[octv * (SL + 2) + layer + 1];
-    const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
-                         (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
-                         (AT(next, r, c) - AT(prev, r, c)) * deriv_scale};
+    const SDog img = dog_layer(P, octv, layer);
+    const SDog prev = dog_layer(P, octv, layer - 1);
+    const SDog next = dog_layer(P, octv, layer + 1);
+    const float dD[3] = {(DAT(img, r, c + 1) - DAT(img, r, c - 1)) * deriv_scale,
+                         (DAT(img, r + 1, c) - DAT(img, r - 1, c)) * deriv_scale,
+                         (DAT(next, r, c) - DAT(prev, r, c)) * deriv_scale};
     const float t = (dD[0] * xc + dD[1] * xr) + dD[2] * xi;
-    const float contr = AT(img, r, c) * img_scale + t * 0.5f;
+    const float contr = DAT(img, r, c) * img_scale + t * 0.5f;
     if (fabsf(contr) * SL < SCONTRAST) return false;
-    const float v2 = AT(img, r, c) * 2.f;
-    const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second;
-    const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second;
-    const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross;
+    const float v2 = DAT(img, r, c) * 2.f;
+    const float dxx = (DAT(img, r, c + 1) + DAT(img, r, c - 1) - v2) * second;
+    const float dyy = (DAT(img, r + 1, c) + DAT(img, r - 1, c) - v2) * second;
+    const float dxy = (DAT(img, r + 1, c + 1) - DAT(img, r + 1, c - 1) - DAT(img, r - 1, c + 1) + DAT(img, r - 1, c - 1)) * cross;
     const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
     if (det <= 0 || tr * tr * SEDGE >= (SEDGE + 1) * (SEDGE + 1) * det) return false;
     kp.x = (c + xc) * (float)(1 << octv);
@@ -865,6 +856,7 @@ __global__ __launch_bounds__(64) void k_sift_describe(const SiftFrame* __restric
     for (unsigned base = 0; base < total; base += 64) {
         const unsigned t = base + lane;
         int idx = -1;
+        float sh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (t < total) {
             const int i = (int)(t / (unsigned)side) - radius, j = (int)(t % (unsigned)side) - radius;
             const float c_rot = j * cos_t - i * sin_t;
@@ -895,17 +887,27 @@ __global__ __launch_bounds__(64) void k_sift_describe(const SiftFrame* __restric
                 const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
                 const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
                 idx = ((r0 + 1) * (d + 2) + c0 + 1) * (nb + 2) + o0;
-                s_v[lane][0] = v_rco000, s_v[lane][1] = v_rco001, s_v[lane][2] = v_rco010, s_v[lane][3] = v_rco011;
-                s_v[lane][4] = v_rco100, s_v[lane][5] = v_rco101, s_v[lane][6] = v_rco110, s_v[lane][7] = v_rco111;
+                sh[0] = v_rco000, sh[1] = v_rco001, sh[2] = v_rco010, sh[3] = v_rco011;
+                sh[4] = v_rco100, sh[5] = v_rco101, sh[6] = v_rco110, sh[7] = v_rco111;
             }
         }
-        s_idx[lane] = idx;
+        // the samples that fall into the descriptor's window (about half of the square that is scanned) move
+        // up to the front, in scan order
+        const unsigned long long hit = __ballot(idx >= 0);
+        const int n_hit = __popcll(hit);
+        s_idx[lane] = -1;
+        if (idx >= 0) {
+            const int pos = __popcll(hit & ((1ull << lane) - 1ull));
+            s_idx[pos] = idx;
+#pragma unroll
+            for (int e = 0; e < 8; e++) s_v[pos][e] = sh[e];
+        }
         __syncthreads();
         // the eight shares of a sample go to eight different bins: lane e < 8 adds share e of every
         // sample, in sample order, so every bin still receives its terms in scan order
         if (lane < 8) {
             const int ofs = (lane & 1) + ((lane >> 1) & 1) * (nb + 2) + (lane >> 2) * (d + 2) * (nb + 2);
-            for (int l0 = 0; l0 < 64; l0 += 8) {
+            for (int l0 = 0; l0 < n_hit; l0 += 8) {
                 // indices and shares of eight samples first, then the additions one after the other
                 const int4 ka = *reinterpret_cast<const int4*>(&s_idx[l0]);
                 const int4 kb = *reinterpret_cast<const int4*>(&s_idx[l0 + 4]);
@@ -976,7 +978,7 @@ dim3 grid_cols(int w, int h, int nb) { return dim3((w + 63) / 64, (h + 4 * SB_C 
 struct SiftGeom {
     int h = 0, w = 0, bh, bw, n_oct, o_small, lds_px;
     int oh[MAX_OCT], ow[MAX_OCT];
-    size_t off_gp[MAX_OCT * (SL + 3)], off_dog[MAX_OCT * (SL + 2)], scratch_off, total;
+    size_t off_gp[MAX_OCT * (SL + 3)], scratch_off, total;
     Taps base, taps[SL + 3];
     TapsAll small;
     ExtremaTiles tiles;
@@ -1001,10 +1003,6 @@ int sift_geometry(rtvm_ctx* c, int h, int w, SiftGeom& g) {
         g.oh[o] = oh, g.ow[o] = ow;
         for (int i = 0; i < SL + 3; i++) {
             g.off_gp[o * (SL + 3) + i] = total;
-            total += (size_t)oh * ow;
-        }
-        for (int i = 0; i < SL + 2; i++) {
-            g.off_dog[o * (SL + 2) + i] = total;
             total += (size_t)oh * ow;
         }
         oh /= 2, ow /= 2;
@@ -1055,7 +1053,6 @@ void sift_frame_init(SiftFrame& f, const SiftGeom& g, float* arena, char* work) 
     memset(&f, 0, sizeof(f));
     for (int o = 0; o < g.n_oct; o++) {
         for (int i = 0; i < SL + 3; i++) f.pyr.gp[o * (SL + 3) + i] = SImg{arena + g.off_gp[o * (SL + 3) + i], g.oh[o], g.ow[o]};
-        for (int i = 0; i < SL + 2; i++) f.pyr.dog[o * (SL + 2) + i] = SImg{arena + g.off_dog[o * (SL + 2) + i], g.oh[o], g.ow[o]};
     }
     f.scratch = arena + g.scratch_off;
     auto take = [&](size_t bytes) {
@@ -1073,12 +1070,11 @@ void sift_frame_init(SiftFrame& f, const SiftGeom& g, float* arena, char* work) 
 
 // The two passes of one blur for nb frames: the kernel compiled for the length of `t`, or the
 // general one.
-int sift_blur(rtvm_ctx* c, const SiftFrame* d_frames, int nb, int src, int dst, int h, int w, const Taps& t, int below,
-              int dog) {
+int sift_blur(rtvm_ctx* c, const SiftFrame* d_frames, int nb, int src, int dst, int h, int w, const Taps& t) {
 #define SIFT_BLUR_N(N)                                                                                                   \
     case N:                                                                                                              \
         RTVM_LAUNCH(c, k_sift_blur<N>, dim3(xcd_grid(((w + SBT_W - 1) / SBT_W) * ((h + SBT_H - 1) / SBT_H)), 1, nb), dim3(256),  \
-                    0, d_frames, src, dst, h, w, t, below, dog);                                                         \
+                    0, d_frames, src, dst, h, w, t);                                                                     \
         break;
     switch (t.n) {
         SIFT_BLUR_N(11)
@@ -1088,8 +1084,7 @@ int sift_blur(rtvm_ctx* c, const SiftFrame* d_frames, int nb, int src, int dst, 
         SIFT_BLUR_N(27)
         default:
             RTVM_LAUNCH(c, k_sift_blur_rows, grid3(w, h, nb), dim3(256), 0, d_frames, src, PLANE_SCRATCH, h, w, t);
-            RTVM_LAUNCH(c, k_sift_blur_cols, grid3(w, h, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, dst, h, w, t, below,
-                        dog);
+            RTVM_LAUNCH(c, k_sift_blur_cols, grid3(w, h, nb), dim3(256), 0, d_frames, PLANE_SCRATCH, dst, h, w, t);
     }
 #undef SIFT_BLUR_N
     return RTVM_OK;
@@ -1099,11 +1094,11 @@ int sift_blur(rtvm_ctx* c, const SiftFrame* d_frames, int nb, int src, int dst, 
 // the context's current stream.
 int sift_launch(rtvm_ctx* c, const SiftGeom& g, const SiftFrame* d_frames, int nb, int nfeatures, int out_cap) {
     const int bh = g.bh, bw = g.bw;
-    // base image: doubled, blurred by sqrt(sigma^2 - 1) (into gp[0] via the last DoG plane of octave 0 as a temporary)
+    // base image: doubled, blurred by sqrt(sigma^2 - 1) (into layer 0 via layer 1 of octave 0 as a temporary)
     {
-        const int dbl = PLANE_DOG + SL + 1;  // free until the DoG of octave 0 is formed
+        const int dbl = 1;  // free until layer 1 is made from layer 0
         RTVM_LAUNCH(c, k_sift_base, grid3(g.w, g.h, nb), dim3(256), 0, d_frames, g.h, g.w, dbl, rtvm_gray_coef(c));
-        sift_blur(c, d_frames, nb, dbl, 0, bh, bw, g.base, -1, -1);
+        sift_blur(c, d_frames, nb, dbl, 0, bh, bw, g.base);
     }
     for (int o = 0; o < g.o_small; o++) {
         const int oh = g.oh[o], ow = g.ow[o];
@@ -1114,7 +1109,7 @@ int sift_launch(rtvm_ctx* c, const SiftGeom& g, const SiftFrame* d_frames, int n
                 RTVM_LAUNCH(c, k_sift_decimate, grid3(ow, oh, nb), dim3(256), 0, d_frames, (o - 1) * (SL + 3) + SL, g.ow[o - 1],
                             dst, oh, ow);
             } else {
-                sift_blur(c, d_frames, nb, dst - 1, dst, oh, ow, g.taps[i], dst - 1, PLANE_DOG + o * (SL + 2) + i - 1);
+                sift_blur(c, d_frames, nb, dst - 1, dst, oh, ow, g.taps[i]);
             }
         }
     }

@@ -296,6 +296,7 @@ __global__ void k_batch_finish(StreamState* __restrict__ st, const StreamState* 
         reason = st->n_done == 0 ? RTVM_PENDING_VOID : RTVM_PENDING_SKIPPED_FRAME;
     }
     st->bad_frame = 0x7FFFFFFF;
+    rep->cleared = bad >= 0 && bad < n ? bad : -1;
     rep->n_done = st->n_done;
     rep->abort = st->abort;
     rep->tail_ok = st->tail_ok;
@@ -652,6 +653,20 @@ static int read_state(rtvm_ctx* c, StreamState** hs_out) {
 }
 
 extern "C" long rtvm_batch_ticket(rtvm_ctx* c) { return c ? c->seq : 0; }
+
+extern "C" int rtvm_batch_cleared(rtvm_ctx* c, long ticket, int* first) {
+    if (!c) return RTVM_E_ARG;
+    if (!first) RTVM_FAIL(c, RTVM_E_ARG, "batch_cleared: null argument");
+    if (!c->stream_ready) RTVM_FAIL(c, RTVM_E_STATE, "batch_cleared: no stream");
+    if (ticket < 1 || ticket > c->seq || c->seq - ticket >= RTVM_REPORTS)
+        RTVM_FAIL(c, RTVM_E_STATE, "batch_cleared: ticket %ld is not one of the last %d (%ld queued)", ticket, RTVM_REPORTS,
+                  c->seq);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int slot = (int)(ticket % RTVM_REPORTS);
+    HIP_TRY(c, hipEventSynchronize(c->ev_done[slot]));
+    *first = c->h_rep[slot].cleared;
+    return RTVM_OK;
+}
 
 extern "C" int rtvm_batch_status_of(rtvm_ctx* c, long ticket, int* n_done, int* reason, int* status,
                                     int* n_matches, int* n_keypoints, int cap) {

@@ -286,8 +286,10 @@ def test_batch_retry_queues_only_the_canvas_half_again():
     assert t2 == t1 + 1
     done, reason, st, _, _ = ctx.batch_status_of(t1, 4)
     assert 1 <= done < 4 and reason == F.PENDING_MASK and st[done:].tolist() == [8] * (4 - done)
+    assert ctx.batch_cleared(t1) == done - 1   # the last frame that went through is the one that cleared a pixel
     done2, reason2, st2, _, _ = ctx.batch_status_of(t2, 4)
     assert done2 == 0 and reason2 == F.PENDING_VOID and st2.tolist() == [8] * 4
+    assert ctx.batch_cleared(t2) == -1
     retries = 0
     for ticket in (t1, t2):
         first = done if ticket == t1 else 0
