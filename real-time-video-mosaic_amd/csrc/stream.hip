@@ -103,13 +103,18 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
         uint32_t* l = reinterpret_cast<uint32_t*>(&S);
         for (int i = lane; i < WORDS; i += 64) l[i] = g[i];
     }
+    __shared__ int s_valid[RTVM_MAX_BATCH];
     if (lane < n) {
         const FrameSlot& F = slots[sb + lane];
         s_m[lane] = *F.m_count;
         s_found[lane] = *F.rs_found;
         s_kp[lane] = *F.feat.count;
-        for (int i = 0; i < 9; i++) s_H[lane][i] = F.rs_H[i];
+        double Hr[9];
+        for (int i = 0; i < 9; i++) Hr[i] = s_H[lane][i] = F.rs_H[i];
         s_skip[lane] = 1;
+        // validate_homography looks at the frame's own matrix only: all frames at once, one per lane,
+        // ahead of the chain through the frames
+        s_valid[lane] = validate_h(Hr, trans_thr, scale_thr) ? 1 : 0;
     }
     if (lane < 30) s_w[lane] = wtab[lane];
     __syncthreads();
@@ -146,11 +151,9 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
                 if (lane == 0) st->status = st->b_status[j] = status;
                 if (j < n - 1) abort = 2;  // the later frames were matched against this one
             } else {
-                double Hr[9];
-                for (int i = 0; i < 9; i++) Hr[i] = s_H[j][i];
-                const bool ok = validate_h(Hr, trans_thr, scale_thr);
+                const bool ok = s_valid[j] != 0;
                 if (!ok) status |= RTVM_FRAME_INVALID_H;
-                const double Hr_e = ok ? Hr[e] : ((e % 4 == 0) ? 1. : 0.);
+                const double Hr_e = ok ? s_H[j][e] : ((e % 4 == 0) ? 1. : 0.);
                 // smooth_homography: the history of element e
                 int k = st->hist_len;
                 double h[5];
