@@ -777,7 +777,8 @@ class Context:
                 e = next((r for r in det if r[3] < r[2]), None)
                 if e is None:
                     break
-                cnt = min(cb, e[2] - e[3])
+                rem = e[2] - e[3]
+                cnt = rem if rem <= cb + cb // 2 else cb   # no short piece at the end of a batch: it costs a piece's fixed time
                 inb.append((e, self.batch_retry(e[0], e[3], cnt), e[3], cnt))
                 e[3] += cnt
                 stats["canvas_pieces"] += 1

@@ -283,6 +283,7 @@ struct rtvm_ctx {
     hipStream_t stream_copy;
     hipEvent_t ev_ingest;      // the last copy queued
     int ingest_used;           // a copy was queued: streams that read frames wait for ev_ingest
+    int rs_alone = 0;   // at most a batch's worth of frames in flight: latency is what counts (ransac.hip)
     hipEvent_t ev_done[RTVM_REPORTS];  // batch number (seq % RTVM_REPORTS) is complete
     hipEvent_t ev_main;
     int back_rec[RTVM_NSETS];  // ev_back[k] has been recorded

@@ -814,7 +814,9 @@ int rtvm_launch_ransac_search(rtvm_ctx* c, int sb, int nb, double thresh, int ma
     // end of the first or second stage by the time it has been replayed, and the later stages exit at once.
     // One or two problems leave the GPU idle either way: 64 hypotheses take as long as 16 (one wave each), so
     // the first stage is skipped and a round of launches saved; a batch pays for every hypothesis it evaluates.
-    const int ends[3] = {nb <= 2 ? RS_BATCH0 : RS_BATCH0 / 4, RS_BATCH0, max_iters};
+    // The same goes for a batch with nothing else in flight (the first of a video, a short burst): the stage
+    // it saves is a fifth of a millisecond of latency nothing else would fill.
+    const int ends[3] = {nb <= 2 || c->rs_alone ? RS_BATCH0 : RS_BATCH0 / 4, RS_BATCH0, max_iters};
     int h0 = 0;
     for (int s = 0; s < 3 && h0 < max_iters; s++) {
         const int h1 = ends[s] < max_iters ? ends[s] : max_iters;

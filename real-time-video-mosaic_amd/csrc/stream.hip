@@ -536,10 +536,21 @@ int queue_detect(rtvm_ctx* c, const uint8_t* const* ptrs, int n, int* set_out, i
         if ((r = queue_features(c, sb, n))) return r;
         HIP_TRY(c, hipEventRecord(c->ev_feat[set], c->stream_front));
     }
+    // Few frames in flight (the start of a video, a short burst): latency counts, not work, and the RANSAC
+    // search starts with all 64 hypotheses of its first two stages at once (ransac.hip).  (Tried for such
+    // bursts and dropped: two half batches, the second with search and polish on the front stream so that
+    // the two polishes run side by side -- the search and polish streams share one hardware queue -- : the
+    // fixed costs of detection and of a canvas piece come twice, 2 % in all.)
+    int live = n;
+    for (int k = 0; k < RTVM_NSETS; k++)
+        if (c->set_live[k]) live += c->recs[k].n;
     HIP_TRY(c, hipStreamWaitEvent(c->stream_rs, c->ev_feat[set], 0));
     {
         StreamScope fs(c, c->stream_rs);
-        if ((r = rtvm_launch_ransac_search(c, sb, n, 2.0, 2000, 0.995))) return r;
+        c->rs_alone = live <= RTVM_MAX_BATCH ? 1 : 0;
+        r = rtvm_launch_ransac_search(c, sb, n, 2.0, 2000, 0.995);
+        c->rs_alone = 0;
+        if (r) return r;
         HIP_TRY(c, hipEventRecord(c->ev_search[set], c->stream_rs));
     }
     HIP_TRY(c, hipStreamWaitEvent(c->stream_lm, c->ev_search[set], 0));
