@@ -323,6 +323,10 @@ int rtvm_frame_status(rtvm_ctx* ctx, int* status, int* n_keypoints, int* n_match
  * beyond the loop itself.  rtvm_ingest_reserve allocates (once per context). */
 int rtvm_ingest_reserve(rtvm_ctx* ctx, int n_slots);
 int rtvm_ingest_host_slot(rtvm_ctx* ctx, int slot, uint8_t** host);
+/* Copies a frame (frame_h x frame_w x 3 bytes in ordinary host memory, e.g. what cap.read() returned,
+ * main.py:1597) into the pinned slot, on four threads for frames of a megabyte and more; returns when the
+ * copy is complete.  For callers whose decoder cannot write into the slot itself. */
+int rtvm_ingest_write(rtvm_ctx* ctx, int slot, const uint8_t* bgr_host);
 int rtvm_ingest_submit(rtvm_ctx* ctx, int slot, const uint8_t** dev);
 /* The same for `count` consecutive slots in one copy (a whole batch moves at about twice the
  * rate of frame-sized copies); dev receives the `count` device addresses. */

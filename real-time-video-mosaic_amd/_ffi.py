@@ -55,6 +55,7 @@ SIGNATURES = {
     "rtvm_sift": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _intp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtvm_ingest_reserve": (C.c_int, [_vp, C.c_int]),
     "rtvm_ingest_host_slot": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
+    "rtvm_ingest_write": (C.c_int, [_vp, C.c_int, _vp]),
     "rtvm_ingest_submit": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p)]),
     "rtvm_ingest_submit_range": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rtvm_crop_rect": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _intp]),
@@ -821,6 +822,10 @@ class Context:
     # ---- frame ingest (host frames -> device ring) ------------------------------
     def ingest_reserve(self, n_slots):
         self._check(lib().rtvm_ingest_reserve(self._h, int(n_slots)))
+
+    def ingest_write(self, slot, bgr):
+        """Copies a host frame into the pinned slot (several threads for large frames); complete on return."""
+        self._check(lib().rtvm_ingest_write(self._h, int(slot), ptr(self._frame(bgr, "ingest_write"))))
 
     def ingest_host_slot(self, slot):
         """The pinned host frame of a slot as a numpy array (frame_h, frame_w, 3) u8 to write into."""

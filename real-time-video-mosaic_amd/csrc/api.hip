@@ -334,6 +334,7 @@ void free_all(rtvm_ctx* c) {
         c->sift_buf[i] = nullptr;
         c->sift_bytes[i] = 0;
     }
+    rtvm_ingest_pool_free(c);
     if (c->stream_copy) {
         (void)hipStreamSynchronize(c->stream_copy);
         (void)hipStreamDestroy(c->stream_copy);

@@ -98,7 +98,10 @@ class _Pipeline:
         view = self.views[idx % self.R]
         if frame.shape != view.shape:
             raise ValueError("process_frame: frame of shape %s, the mosaic was created for %s" % (frame.shape, view.shape))
-        np.copyto(view, frame)
+        if frame.dtype == np.uint8 and frame.flags["C_CONTIGUOUS"]:
+            self.ctx.ingest_write(idx % self.R, frame)   # complete on return, on several threads for large frames
+        else:
+            np.copyto(view, frame)
         self.pend.append((idx, frame))
         self.n_in += 1
         self.stats["frames"] += 1
