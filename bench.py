@@ -83,9 +83,9 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
         "k_warp<true>": 3 * P + 4 * roi_px + roi_px / 8,
         "k_dt_diag_a": A / 8 + A / 4,          # zero bit rows in, one bit per pixel and orientation out
         "k_dt_diag_b": A / 4 + 2 * A,          # diagonal bitmaps in, u16 step plane out
-        "k_dt_scan": 2 * rows_px + 4 * win2 + 2 * cols_px + cols_px / 4,  # steps in; row scan + chunk summaries out
-        "k_dt_cols": 2 * win2 + 4 * win2 + cols_px / 4 + 4 * win2,      # steps, row scan, summaries in; f32 out
-        "k_dt_rows_wide": 2 * rows_px + 4 * win2,   # rows above 2048 pixels: steps of the window's rows in, row scan out
+        # steps of the windows' rows and columns in (the window itself once); column and row summaries out
+        "k_dt_sum": 2 * (rows_px + cols_px - win2) + cols_px / 4 + rows_px / 8,
+        "k_dt_final": 2 * win2 + cols_px / 4 + rows_px / 8 + 4 * win2,   # steps and summaries in; f32 out
         "k_blur_rows<false>": 4 * roi_px + 4 * win + 8 * roi_px,   # two distance planes in, two row-blurred weights out
         "k_blur_cols<false>": 8 * win + roi_px + 8 * roi_px,       # row-blurred weights + mask in, final weights out
         # per frame: mask + warped + two weights in; per batch: canvas + mask in/out and their snapshot

@@ -145,7 +145,7 @@ int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int kind) {
 // of the two distance transforms (kind 0 = new mask, 1 = predicted old mask).
 struct SidePlanes {
     uint16_t* S;
-    uint32_t* R;
+    uint32_t* RS;
     float* dist;
     uint32_t *B, *Z, *Z16, *CS;
 };
@@ -156,7 +156,8 @@ static void carve_side(const rtvm_ctx* c, Carver& k, SideDev& sd, SidePlanes p[2
     sd.mask_new = k.take<uint8_t>(n_px);
     for (int kind = 0; kind < 2; kind++) {
         p[kind].S = k.take<uint16_t>(n_px + 64);
-        p[kind].R = k.take<uint32_t>(n_px + 64);
+        // 2 * ceil(w / 64) * h words for any h x w the stage entry point accepts (h * w <= ch * cw, h + w <= ch + cw)
+        p[kind].RS = k.take<uint32_t>(n_px / 32 + 2 * (size_t)(c->ch + c->cw) + 64);
         p[kind].dist = k.take<float>(n_px);
         p[kind].B = k.take<uint32_t>(c->dt_b_words);
         p[kind].Z = k.take<uint32_t>(c->dt_z_words);
@@ -174,7 +175,7 @@ void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int side, int kind, int pi
     Carver k{(char*)c->side_arena[side], 0};
     carve_side(c, k, sd, p);
     jb->S = p[kind].S;
-    jb->R = p[kind].R;
+    jb->RS = p[kind].RS;
     jb->dist = p[kind].dist;
     jb->B = p[kind].B;
     jb->Z = p[kind].Z;
@@ -185,6 +186,8 @@ void rtvm_dt_job_planes(const rtvm_ctx* c, DtJob* jb, int side, int kind, int pi
     jb->zg = (jb->znch + 15) / 16;
     jb->zpitch = w + h;
     jb->cpitch = w;
+    jb->ng = (pitch + 63) / 64;
+    jb->rpitch = h;
 }
 
 // Allocates the planes of frame `side` of a batch and publishes them: d_side[side] and the

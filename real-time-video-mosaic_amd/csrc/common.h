@@ -94,20 +94,21 @@ struct FrameSlot {
 #define RTVM_STAGE_SLOT RTVM_MAX_SLOTS   // slot used by the host-buffer matcher / RANSAC entry points
 
 // One distance-transform job: a rectangle of a mask plane and the planes the
-// scans write (S, R and dist are indexed y*pitch + x like the mask).
+// scans write (S and dist are indexed y*pitch + x like the mask).
 struct DtJob {
     const uint8_t* mask;
     int pitch;
     int x0, y0, x1, y1;      // rectangle the transform is computed on (outside = wall)
     int ox0, oy0, ox1, oy1;  // sub-rectangle whose distances are needed
     uint16_t* S;       // steps to the nearest zero along the two diagonals through the pixel
-    uint32_t* R;       // row scan result
+    uint32_t* RS;      // row summaries per 64-column group: [2 directions][ng][rpitch], indexed by the row
     float* dist;
     uint32_t* B;       // one zero bit per pixel: [rows][wpitch] words
     uint32_t* Z;       // zero bits of the diagonal lines per 32-row chunk: [2 orientations][znch][zpitch]
     uint32_t* Z16;     // which chunks of a group of 16 hold a zero: [2][zg][zpitch]
     uint32_t* CS;      // column chunk summaries: [2][znch][cpitch]
     int wpitch, znch, zg, zpitch, cpitch;
+    int ng, rpitch;    // 64-column groups of the plane, rows of the plane
 };
 
 // Workgroups go to the eight XCDs (each with an L2 of its own) in turn by their linear index.  A
@@ -162,15 +163,15 @@ struct DtJobG {
     int x0, y0, x1, y1;
     int ox0, oy0, ox1, oy1;
     gptr<uint16_t> S;
-    gptr<uint32_t> R;
+    gptr<uint32_t> RS;
     gptr<float> dist;
     gptr<uint32_t> B, Z, Z16, CS;
-    int wpitch, znch, zg, zpitch, cpitch;
+    int wpitch, znch, zg, zpitch, cpitch, ng, rpitch;
     __device__ explicit DtJobG(const DtJob& j)
         : mask(as_global(j.mask)), pitch(j.pitch), x0(j.x0), y0(j.y0), x1(j.x1), y1(j.y1), ox0(j.ox0), oy0(j.oy0),
-          ox1(j.ox1), oy1(j.oy1), S(as_global(j.S)), R(as_global(j.R)), dist(as_global(j.dist)), B(as_global(j.B)),
+          ox1(j.ox1), oy1(j.oy1), S(as_global(j.S)), RS(as_global(j.RS)), dist(as_global(j.dist)), B(as_global(j.B)),
           Z(as_global(j.Z)), Z16(as_global(j.Z16)), CS(as_global(j.CS)), wpitch(j.wpitch), znch(j.znch), zg(j.zg),
-          zpitch(j.zpitch), cpitch(j.cpitch) {}
+          zpitch(j.zpitch), cpitch(j.cpitch), ng(j.ng), rpitch(j.rpitch) {}
 };
 
 // Two floats handled as one packed operand (v_pk_fma_f32 and friends).

@@ -21,10 +21,12 @@
 //   k_dt_diag_b  per tile of 32 rows x 192 columns: steps to the nearest zero along
 //                both diagonals (bit scans inside the chunk, the chunk summaries
 //                beyond it), minimum of the two through LDS, one u16 plane out
-//   k_dt_scan    row scans of the output window's rows (wave prefix minima), and
-//                per (column, chunk) the values leaving the chunk downwards / upwards
-//   k_dt_cols    carries from the other chunks' summaries, column scan in registers,
-//                min with the row scan, distance out
+//   k_dt_sum     per tile of 32 rows x 64 columns: what leaves the tile along its columns
+//                (downwards / upwards) and along its rows (to the right / left)
+//   k_dt_chunks  scans over those summaries: what arrives at every tile from the other tiles
+//                of its columns and of its rows
+//   k_dt_final   per tile: column scan in registers, row scan over the lanes, the arrivals,
+//                minimum of the two, distance out
 #include "common.h"
 
 namespace {
@@ -281,341 +283,210 @@ __global__ __launch_bounds__(DB_THREADS) void k_dt_diag_b(const DtJob* __restric
     }
 }
 
-// ---- row scans ---------------------------------------------------------------------
-// R(x) = min_k E(k) + a*|x-k| = min(prefix minimum of E(k) + a*(XR-k) minus a*(XR-x),
-//                                   suffix minimum of E(k) + a*k minus a*x)
-// with k, x relative to an 8-aligned origin.  A thread owns 8 consecutive pixels, a
-// workgroup 2048; wider rows take several passes with the running minimum carried over.
+// ---- row and column scans --------------------------------------------------------------
+// The plane is cut into tiles of 32 rows (a chunk) x 64 columns (a group, on the plane's
+// 64-column grid): one wave per tile, lane = column, the 32 rows of the column in registers.
+//   column direction  sequential in the lane; what arrives from the other chunks of the column
+//                     comes from the chunk summaries (k_dt_sum -> k_dt_chunks)
+//   row direction     R(i) = min_j E(j) + a*|i-j| inside the tile is a prefix and a suffix minimum
+//                     over the lanes of E(j) + a*(63-j) and E(j) + a*j (data-parallel-primitive row
+//                     shifts, no shared memory); what arrives from the other groups of the row comes
+//                     from the row summaries (k_dt_sum -> k_dt_chunks)
+// Inside the tile kernels "no zero reachable" is BIG rather than all ones, so that the few axial
+// steps added inside a tile cannot wrap; everything from BIG_MIN on is infinite (a real distance is
+// at most 16384 * (a + b) < 2^31.3).  The summary planes hold all ones for infinite.
+constexpr uint32_t BIG = 0xF0000000u;
+constexpr uint32_t BIG_MIN = 0xE0000000u;
 
-__device__ __forceinline__ uint32_t wg_prefix_min_excl(uint32_t v, uint32_t* s_w, uint32_t carry_in, uint32_t* total) {
-    // exclusive prefix minimum over the 256 threads (thread order), seeded with carry_in
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t p = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_up(p, o);
-        if (lane >= o) p = min(p, u);
-    }
-    __syncthreads();
-    if (lane == 63) s_w[wave] = p;
-    __syncthreads();
-    uint32_t ex = __shfl_up(p, 1);
-    if (lane == 0) ex = INF32;
-    uint32_t c = carry_in;
-    for (int w = 0; w < 4; w++)
-        if (w < wave) c = min(c, s_w[w]);
-    *total = min(min(min(s_w[0], s_w[1]), min(s_w[2], s_w[3])), carry_in);
-    return min(ex, c);
+__device__ __forceinline__ uint32_t e_soft(uint32_t s) { return s == 0xFFFFu ? BIG : s * DT_B; }
+__device__ __forceinline__ uint32_t inf_out(uint32_t v) { return v >= BIG_MIN ? INF32 : v; }
+
+// x of lane (lane op n) where the operation names a valid lane of the row of 16, `ident` elsewhere
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_or(uint32_t ident, uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)x, CTRL, ROW_MASK, 0xF, false);
 }
 
-__device__ __forceinline__ uint32_t wg_suffix_min_excl(uint32_t v, uint32_t* s_w, uint32_t carry_in, uint32_t* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t p = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_down(p, o);
-        if (lane + o < 64) p = min(p, u);
-    }
-    __syncthreads();
-    if (lane == 0) s_w[wave] = p;
-    __syncthreads();
-    uint32_t ex = __shfl_down(p, 1);
-    if (lane == 63) ex = INF32;
-    uint32_t c = carry_in;
-    for (int w = 0; w < 4; w++)
-        if (w > wave) c = min(c, s_w[w]);
-    *total = min(min(min(s_w[0], s_w[1]), min(s_w[2], s_w[3])), carry_in);
-    return min(ex, c);
+// inclusive minimum over lanes 0..lane (lane 63 ends up with the minimum of the wave); all 64 lanes active
+__device__ __forceinline__ uint32_t wave_prefix_min(uint32_t x) {
+    x = min(x, dpp_or<0x111>(INF32, x));        // row_shr:1
+    x = min(x, dpp_or<0x112>(INF32, x));        // row_shr:2
+    x = min(x, dpp_or<0x114>(INF32, x));        // row_shr:4
+    x = min(x, dpp_or<0x118>(INF32, x));        // row_shr:8
+    x = min(x, dpp_or<0x142, 0xA>(INF32, x));   // row_bcast:15 into rows 1 and 3
+    x = min(x, dpp_or<0x143, 0xC>(INF32, x));   // row_bcast:31 into rows 2 and 3
+    return x;
 }
 
-// E of the 8 pixels starting at x (8-aligned relative to the plane when the pitch allows)
-__device__ __forceinline__ void load_e8(const DtJobG& jb, size_t row, int x, uint32_t* E) {
-    uint16_t s[8];
-    if ((jb.pitch & 7) == 0 && x >= 0 && x + 8 <= jb.pitch) {
-        const uint4 v = load_u4(jb.S + row + x);
-        s[0] = v.x & 0xFFFF, s[1] = v.x >> 16, s[2] = v.y & 0xFFFF, s[3] = v.y >> 16;
-        s[4] = v.z & 0xFFFF, s[5] = v.z >> 16, s[6] = v.w & 0xFFFF, s[7] = v.w >> 16;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; i++) s[i] = (x + i >= jb.x0 && x + i < jb.x1) ? jb.S[row + x + i] : (uint16_t)0xFFFF;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) E[i] = (x + i >= jb.x0 && x + i < jb.x1) ? e_of(s[i]) : INF32;
+// inclusive minimum over lanes lane..63; all 64 lanes active
+__device__ __forceinline__ uint32_t wave_suffix_min(uint32_t x, int lane) {
+    x = min(x, dpp_or<0x101>(INF32, x));        // row_shl:1
+    x = min(x, dpp_or<0x102>(INF32, x));
+    x = min(x, dpp_or<0x104>(INF32, x));
+    x = min(x, dpp_or<0x108>(INF32, x));
+    // the minima of the rows of 16 are in lanes 0, 16, 32, 48: every row takes those of the rows after it
+    const uint32_t t3 = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+    const uint32_t t2 = min((uint32_t)__builtin_amdgcn_readlane((int)x, 32), t3);
+    const uint32_t t1 = min((uint32_t)__builtin_amdgcn_readlane((int)x, 16), t2);
+    const uint32_t after = lane < 16 ? t1 : lane < 32 ? t2 : lane < 48 ? t3 : INF32;
+    return min(x, after);
 }
 
-__device__ void dt_row(const DtJobG& jb, int y, uint32_t* s_w) {
-    const int xo = jb.x0 & ~7;                          // origin of the relative coordinate
-    const int span = jb.x1 - xo;
-    const int P = (span + 2047) / 2048;                 // passes
-    const uint32_t XR = (uint32_t)(P * 2048 - 1);
-    const size_t row = (size_t)y * jb.pitch;
-    const int t = threadIdx.x;
-    if (P == 1) {
-        const int xr = t * 8, x = xo + xr;
-        uint32_t E[8], F[8];
-        if (xr < span)
-            load_e8(jb, row, x, E);
-        else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) E[i] = INF32;
-        }
-        uint32_t mf = INF32, mb = INF32;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (E[i] != INF32) {
-                mf = min(mf, E[i] + DT_A * (XR - (uint32_t)(xr + i)));
-                mb = min(mb, E[i] + DT_A * (uint32_t)(xr + i));
-            }
-        }
-        uint32_t tot;
-        uint32_t run = wg_prefix_min_excl(mf, s_w, INF32, &tot);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (E[i] != INF32) run = min(run, E[i] + DT_A * (XR - (uint32_t)(xr + i)));
-            F[i] = run == INF32 ? INF32 : run - DT_A * (XR - (uint32_t)(xr + i));
-        }
-        run = wg_suffix_min_excl(mb, s_w, INF32, &tot);
-#pragma unroll
-        for (int i = 7; i >= 0; i--) {
-            if (E[i] != INF32) run = min(run, E[i] + DT_A * (uint32_t)(xr + i));
-            const uint32_t b = run == INF32 ? INF32 : run - DT_A * (uint32_t)(xr + i);
-            const uint32_t v = min(F[i], b);
-            F[i] = v > DT_MAX ? DT_MAX : v;
-        }
-        if (xr < span && x + 8 > jb.ox0 && x < jb.ox1) {
-            if ((jb.pitch & 3) == 0 && x >= jb.ox0 && x + 8 <= jb.ox1) {
-                const auto o = jb.R + row + x;
-                store_u4(o, make_uint4(F[0], F[1], F[2], F[3]));
-                store_u4(o + 4, make_uint4(F[4], F[5], F[6], F[7]));
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                    if (x + i >= jb.ox0 && x + i < jb.ox1) jb.R[row + x + i] = F[i];
-            }
-        }
-        return;
-    }
-    // wider rows are scanned by k_dt_rows_wide
+// `old` with lane `lane` (a constant) replaced by the wave-uniform value v
+__device__ __forceinline__ int write_lane(int v, int lane, int old) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(lane));
+    return old;
 }
 
-// The 8 step values starting at x as four words (0xFFFF outside the rectangle).
-__device__ __forceinline__ uint4 load_s8(const DtJobG& jb, size_t row, int x) {
-    if ((jb.pitch & 7) == 0 && x >= 0 && x + 8 <= jb.pitch) return load_u4(jb.S + row + x);
-    uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    for (int i = 0; i < 8; i++)
-        if (x + i >= jb.x0 && x + i < jb.x1) {
-            const uint32_t v = jb.S[row + x + i];
-            w[i >> 1] = (i & 1) ? (w[i >> 1] & 0x0000FFFFu) | (v << 16) : (w[i >> 1] & 0xFFFF0000u) | v;
-        }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-__device__ __forceinline__ uint32_t e_of_s8(const DtJobG& jb, const uint4& sv, int x, int i) {
-    const uint32_t w = i < 2 ? sv.x : i < 4 ? sv.y : i < 6 ? sv.z : sv.w;
-    const uint32_t sx = (i & 1) ? w >> 16 : w & 0xFFFFu;
-    return (x + i >= jb.x0 && x + i < jb.x1) ? e_of(sx) : INF32;
-}
-
-// Rows wider than one workgroup pass of dt_row (2048 pixels): thread t owns the 8 pixels at
-// 8*(256 p + t) of every pass p.  The wave scans of all passes run side by side and one
-// exchange through LDS gives every (pass, wave) the minima of everything before / after it;
-// the passes that hold pixels of the output window are then loaded again and finished.
-// One workgroup per row of the output window; blockIdx.y = job.
-__global__ __launch_bounds__(256) void k_dt_rows_wide(const DtJob* __restrict__ jobs, int n_first, int second) {
-    const DtJobG jb(jobs[job_index(blockIdx.y, n_first, second)]);
-    const int W = jb.x1 - jb.x0, H = jb.y1 - jb.y0;
-    const int y = jb.oy0 + blockIdx.x;
-    if (W <= 0 || H <= 0 || y >= jb.oy1) return;
-    const int xo = jb.x0 & ~7;
-    const int span = jb.x1 - xo;
-    const int P = (span + 2047) / 2048;
-    if (P == 1) return;  // done by k_dt_scan
-    constexpr int PM = 9;  // 16384 pixels + alignment slack
-    const uint32_t XR = (uint32_t)(P * 2048 - 1);
-    const size_t row = (size_t)y * jb.pitch;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    __shared__ uint32_t s_f[PM * 4], s_b[PM * 4];  // totals of (pass, wave): forward / backward keys
-    uint32_t pf[PM], pb[PM];
-#pragma unroll
-    for (int p = 0; p < PM; p++) {
-        uint32_t mf = INF32, mb = INF32;
-        const int xr = (p * 256 + t) * 8, x = xo + xr;
-        if (p < P && xr < span) {
-            const uint4 sv = load_s8(jb, row, x);
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t e = e_of_s8(jb, sv, x, i);
-                if (e != INF32) {
-                    mf = min(mf, e + DT_A * (XR - (uint32_t)(xr + i)));
-                    mb = min(mb, e + DT_A * (uint32_t)(xr + i));
-                }
-            }
-        }
-        pf[p] = mf;
-        pb[p] = mb;
-    }
-    // inclusive wave scans of all passes at once
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-#pragma unroll
-        for (int p = 0; p < PM; p++) {
-            const uint32_t uf = __shfl_up(pf[p], o), ub = __shfl_down(pb[p], o);
-            if (lane >= o) pf[p] = min(pf[p], uf);
-            if (lane + o < 64) pb[p] = min(pb[p], ub);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < PM; p++) {
-        if (lane == 63) s_f[p * 4 + wave] = pf[p];
-        if (lane == 0) s_b[p * 4 + wave] = pb[p];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < PM; p++) {
-        const int xr = (p * 256 + t) * 8, x = xo + xr;
-        // minima of everything before (forward) / after (backward) this thread's pixels in its wave
-        uint32_t runf = __shfl_up(pf[p], 1), runb = __shfl_down(pb[p], 1);
-        if (p < P && xr < span && x + 8 > jb.ox0 && x < jb.ox1) {  // some of the window is here
-            if (lane == 0) runf = INF32;
-            if (lane == 63) runb = INF32;
-            for (int q = 0; q < PM * 4; q++) {
-                if (q < p * 4 + wave) runf = min(runf, s_f[q]);
-                if (q > p * 4 + wave) runb = min(runb, s_b[q]);
-            }
-            const uint4 sv = load_s8(jb, row, x);
-            uint32_t F[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t e = e_of_s8(jb, sv, x, i);
-                if (e != INF32) runf = min(runf, e + DT_A * (XR - (uint32_t)(xr + i)));
-                F[i] = runf == INF32 ? INF32 : runf - DT_A * (XR - (uint32_t)(xr + i));
-            }
-#pragma unroll
-            for (int i = 7; i >= 0; i--) {
-                const uint32_t e = e_of_s8(jb, sv, x, i);
-                if (e != INF32) runb = min(runb, e + DT_A * (uint32_t)(xr + i));
-                const uint32_t bk = runb == INF32 ? INF32 : runb - DT_A * (uint32_t)(xr + i);
-                const uint32_t v = min(F[i], bk);
-                F[i] = v > DT_MAX ? DT_MAX : v;
-            }
-            if ((jb.pitch & 3) == 0 && x >= jb.ox0 && x + 8 <= jb.ox1) {
-                const auto o = jb.R + row + x;
-                store_u4(o, make_uint4(F[0], F[1], F[2], F[3]));
-                store_u4(o + 4, make_uint4(F[4], F[5], F[6], F[7]));
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                    if (x + i >= jb.ox0 && x + i < jb.ox1) jb.R[row + x + i] = F[i];
-            }
-        }
-    }
-}
-
-// E of the 32 rows of a chunk of column x (INF below the rectangle)
-__device__ __forceinline__ void load_chunk_e(const DtJobG& jb, int x, int ya, uint32_t* E) {
+// E of the 32 rows of the chunk starting at row ya for column x; BIG outside the rectangle
+__device__ __forceinline__ void load_tile_e(const DtJobG& jb, int x, int ya, uint32_t* E) {
+    const bool col_in = x >= jb.x0 && x < jb.x1;
+    const int xc = min(max(x, jb.x0), jb.x1 - 1);
     uint16_t s[CH];
 #pragma unroll
     for (int r = 0; r < CH; r++) {
         const int y = min(ya + r, jb.y1 - 1);
-        s[r] = jb.S[(size_t)y * jb.pitch + x];
+        s[r] = jb.S[(size_t)y * jb.pitch + xc];
     }
 #pragma unroll
-    for (int r = 0; r < CH; r++) E[r] = ya + r < jb.y1 ? e_of(s[r]) : INF32;
+    for (int r = 0; r < CH; r++) E[r] = (col_in && ya + r < jb.y1) ? e_soft(s[r]) : BIG;
 }
 
-// Per (column, chunk): fe = value at the chunk's last row from the chunk's own pixels
-// (going down), be = value at its first row (going up).  Only columns of the output window.
-__device__ void dt_col_summary(const DtJobG& jb, int x, int c) {
-    uint32_t E[CH];
-    load_chunk_e(jb, x, jb.y0 + c * CH, E);
-    uint32_t fe = INF32, be = INF32;
-#pragma unroll
-    for (int r = 0; r < CH; r++) {
-        fe = min(sat_add(fe, DT_A), E[r]);
-        be = min(be, sat_add(E[r], DT_A * (uint32_t)r));
-    }
-    jb.CS[((size_t)0 * jb.znch + c) * jb.cpitch + x] = fe;
-    jb.CS[((size_t)1 * jb.znch + c) * jb.cpitch + x] = be;
-}
-
-// blockIdx.y = job.  The first `nrow_blocks` workgroups scan one row of the output window
-// each; the others take 64 columns x 4 chunks of the column summaries.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dt_scan(const DtJob* __restrict__ jobs, int n_first, int second, int nrow_blocks,
-                                                 int ncol_x) {
-    const DtJobG jb(jobs[job_index(blockIdx.y, n_first, second)]);
+// Summaries of the tiles: per (column, chunk) what leaves the chunk downwards (value at its last
+// row from the chunk's own pixels) and upwards (at its first row), for the columns of the output
+// window; per (row, group) what leaves the group to the right (value at its last column from the
+// group's own pixels) and to the left, for the rows of the output window.
+// blockIdx.x = group of the rectangle, blockIdx.y = four chunks (one per wave), blockIdx.z = job.
+__global__ __launch_bounds__(256) void k_dt_sum(const DtJob* __restrict__ jobs, int n_first, int second) {
+    const DtJobG jb(jobs[job_index(blockIdx.z, n_first, second)]);
     const int W = jb.x1 - jb.x0, H = jb.y1 - jb.y0;
     if (W <= 0 || H <= 0) return;
-    __shared__ uint32_t s_w[4];
-    if ((int)blockIdx.x < nrow_blocks) {
-        const int y = jb.oy0 + blockIdx.x;
-        if (y < jb.oy1) dt_row(jb, y, s_w);
-        return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = (jb.x0 >> 6) + blockIdx.x;
+    const int c = blockIdx.y * 4 + wave, nch = (H + CH - 1) / CH;
+    if (G * 64 >= jb.x1 || c >= nch) return;  // the same for the whole wave, like every exit below
+    const int ya = jb.y0 + c * CH;
+    const bool rows_needed = ya < jb.oy1 && ya + CH > jb.oy0;
+    const bool cols_needed = G * 64 < jb.ox1 && G * 64 + 64 > jb.ox0;
+    if (!rows_needed && !cols_needed) return;
+    const int x = G * 64 + lane;
+    uint32_t E[CH];
+    load_tile_e(jb, x, ya, E);
+    if (cols_needed) {
+        uint32_t fe = BIG, be = BIG;
+#pragma unroll
+        for (int r = 0; r < CH; r++) {
+            fe = min(fe + DT_A, E[r]);
+            be = min(be, E[r] + DT_A * (uint32_t)r);
+        }
+        if (x >= jb.ox0 && x < jb.ox1) {
+            jb.CS[(size_t)c * jb.cpitch + x] = inf_out(fe);
+            jb.CS[((size_t)jb.znch + c) * jb.cpitch + x] = inf_out(be);
+        }
     }
-    const int b = blockIdx.x - nrow_blocks;
-    const int nch = (H + CH - 1) / CH;
-    const int x = (jb.ox0 & ~63) + (b % ncol_x) * 64 + (threadIdx.x & 63);  // column groups on the plane's 64-column grid
-    const int c = (b / ncol_x) * 4 + (threadIdx.x >> 6);
-    if (c >= nch || x < jb.ox0 || x >= jb.ox1) return;
-    dt_col_summary(jb, x, c);
+    if (rows_needed) {
+        const uint32_t kf = DT_A * (uint32_t)(63 - lane), kb = DT_A * (uint32_t)lane;
+        int fo = 0, bo = 0;  // lane r keeps the pair of row r
+#pragma unroll
+        for (int r = 0; r < CH; r++) {
+            const int y = ya + r;
+            if (y < jb.oy0 || y >= jb.oy1) continue;
+            const uint32_t tf = wave_prefix_min(E[r] + kf), tb = wave_prefix_min(E[r] + kb);
+            fo = write_lane(__builtin_amdgcn_readlane((int)tf, 63), r, fo);
+            bo = write_lane(__builtin_amdgcn_readlane((int)tb, 63), r, bo);
+        }
+        const int y = ya + lane;
+        if (lane < CH && y >= jb.oy0 && y < jb.oy1) {
+            jb.RS[(size_t)G * jb.rpitch + y] = inf_out((uint32_t)fo);
+            jb.RS[((size_t)jb.ng + G) * jb.rpitch + y] = inf_out((uint32_t)bo);
+        }
+    }
 }
 
-// Scan over the chunks of a column, in place over the chunk summaries: plane 0 of CS becomes
-// what reaches each chunk's first row from the chunks above it, plane 1 what reaches its last
-// row from the chunks below (chunk k's summary travels 32*|c-k| - 31 rows to chunk c).
-// blockIdx.x = 64 columns of the output window, blockIdx.y = job, blockIdx.z = plane.
-__global__ __launch_bounds__(64) void k_dt_chunks(const DtJob* __restrict__ jobs, int n_first, int second) {
+// Scans over the summaries, in place.  Workgroups below ncol_x take 64 columns of the output
+// window each and scan the chunks of a column: plane 0 of CS becomes what reaches each chunk's
+// first row from the chunks above it, plane 1 what reaches its last row from the chunks below
+// (chunk k's summary travels 32*|c-k| - 31 rows to chunk c).  The other workgroups take 64 rows
+// of the output window each and scan the groups of a row the same way: plane 0 of RS becomes what
+// reaches each group's first column from the groups left of it, plane 1 what reaches its last
+// column from the groups right of it.  blockIdx.y = job, blockIdx.z = plane.
+__global__ __launch_bounds__(64) void k_dt_chunks(const DtJob* __restrict__ jobs, int n_first, int second, int ncol_x) {
     const DtJobG jb(jobs[job_index(blockIdx.y, n_first, second)]);
-    const int H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
-    const int x = (jb.ox0 & ~63) + blockIdx.x * 64 + threadIdx.x;
-    if (H <= 0 || x < jb.ox0 || x >= jb.ox1) return;
+    const int W = jb.x1 - jb.x0, H = jb.y1 - jb.y0;
+    if (H <= 0 || W <= 0) return;
     const bool down = blockIdx.z == 0;
-    const auto cs = jb.CS + (down ? 0 : (size_t)jb.znch * jb.cpitch) + x;
+    gptr<uint32_t> cs;
+    size_t stride;
+    int n;
+    uint32_t step;
+    if ((int)blockIdx.x < ncol_x) {
+        const int x = (jb.ox0 & ~63) + blockIdx.x * 64 + threadIdx.x;
+        if (x < jb.ox0 || x >= jb.ox1) return;
+        cs = jb.CS + (down ? 0 : (size_t)jb.znch * jb.cpitch) + x;
+        stride = jb.cpitch;
+        n = (H + CH - 1) / CH;
+        step = DT_A * (uint32_t)CH;
+    } else {
+        const int y = jb.oy0 + ((int)blockIdx.x - ncol_x) * 64 + threadIdx.x;
+        if (y >= jb.oy1) return;
+        const int g0 = jb.x0 >> 6;
+        cs = jb.RS + ((down ? 0 : (size_t)jb.ng) + g0) * jb.rpitch + y;
+        stride = jb.rpitch;
+        n = ((jb.x1 - 1) >> 6) - g0 + 1;
+        step = DT_A * 64u;
+    }
     uint32_t run = INF32;
-    for (int i0 = 0; i0 < nch; i0 += 8) {
+    for (int i0 = 0; i0 < n; i0 += 8) {
         uint32_t v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int i = i0 + u, k = down ? i : nch - 1 - i;
-            v[u] = i < nch ? cs[(size_t)k * jb.cpitch] : INF32;
+            const int i = i0 + u, k = down ? i : n - 1 - i;
+            v[u] = i < n ? cs[(size_t)k * stride] : INF32;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int i = i0 + u, k = down ? i : nch - 1 - i;
-            if (i < nch) {
-                cs[(size_t)k * jb.cpitch] = run;
-                run = min(sat_add(run, DT_A * (uint32_t)CH), sat_add(v[u], DT_A));
+            const int i = i0 + u, k = down ? i : n - 1 - i;
+            if (i < n) {
+                cs[(size_t)k * stride] = run;
+                run = min(sat_add(run, step), sat_add(v[u], DT_A));
             }
         }
     }
 }
 
-// Final column scan of the chunks that intersect the output window, in registers;
-// d = min(column scan, row scan), clamped to DIST_MAX, as float / 65536.
-__global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs, int n_first, int second) {
+// The distances of one tile of the output window: column scan in registers with the arrivals from
+// the other chunks, row scan over the lanes with the arrivals from the other groups,
+// d = min of the two, clamped to DIST_MAX, as float / 65536.
+// blockIdx.x = group of the output window, blockIdx.y = chunk, blockIdx.z = job; one wave.
+__global__ __launch_bounds__(64) void k_dt_final(const DtJob* __restrict__ jobs, int n_first, int second) {
     const DtJobG jb(jobs[job_index(blockIdx.z, n_first, second)]);
-    const int H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
-    const int x = (jb.ox0 & ~63) + blockIdx.x * 64 + threadIdx.x;  // a wave's row accesses start on a cache line
+    const int W = jb.x1 - jb.x0, H = jb.y1 - jb.y0, nch = (H + CH - 1) / CH;
+    const int lane = threadIdx.x;
+    const int G = (jb.ox0 >> 6) + blockIdx.x;
     const int c = (jb.oy0 - jb.y0) / CH + blockIdx.y;
-    if (H <= 0 || c >= nch || x < jb.ox0 || x >= jb.ox1) return;
+    if (H <= 0 || W <= 0 || jb.ox1 <= jb.ox0 || c >= nch || G * 64 >= jb.ox1) return;  // whole wave
     const int ya = jb.y0 + c * CH;
     if (ya >= jb.oy1) return;
-    uint32_t E[CH], F[CH], Rv[CH];
-    // values arriving from the other chunks of the column: at the first row from above,
-    // at the last row from below
-    const uint32_t cf = jb.CS[(size_t)c * jb.cpitch + x];
-    const uint32_t cb = jb.CS[((size_t)jb.znch + c) * jb.cpitch + x];
-    load_chunk_e(jb, x, ya, E);
-#pragma unroll
-    for (int r = 0; r < CH; r++) {
-        const int y = ya + r;
-        Rv[r] = (y >= jb.oy0 && y < jb.oy1) ? jb.R[(size_t)y * jb.pitch + x] : INF32;
-    }
+    const int x = G * 64 + lane;
+    const bool col_out = x >= jb.ox0 && x < jb.ox1;
+    const int xw = min(max(x, jb.ox0), jb.ox1 - 1);
+    // arrivals from the other chunks of the column: at the first row from above, at the last row from below
+    const uint32_t cf = min(jb.CS[(size_t)c * jb.cpitch + xw], BIG);
+    const uint32_t cb = min(jb.CS[((size_t)jb.znch + c) * jb.cpitch + xw], BIG);
+    // arrivals from the other groups of the rows: lane r holds what reaches row r's first column from
+    // the left, lane 32 + r what reaches its last column from the right
+    const int yr = min(max(ya + (lane & 31), jb.oy0), jb.oy1 - 1);
+    const uint32_t io = min(jb.RS[((lane >> 5) * (size_t)jb.ng + G) * jb.rpitch + yr], BIG);
+    uint32_t E[CH], F[CH];
+    load_tile_e(jb, x, ya, E);
     uint32_t run = cf;
 #pragma unroll
     for (int r = 0; r < CH; r++) {
         run = min(run, E[r]);
         F[r] = run;
-        run = sat_add(run, DT_A);
+        run += DT_A;
     }
+    const uint32_t kf = DT_A * (uint32_t)(63 - lane), kb = DT_A * (uint32_t)lane;
     run = cb;  // only chunks that are not the last have a chunk below, and those are full
 #pragma unroll
     for (int r = CH - 1; r >= 0; r--) {
@@ -623,11 +494,15 @@ __global__ __launch_bounds__(64) void k_dt_cols(const DtJob* __restrict__ jobs, 
         if (y >= jb.y1) continue;
         run = min(run, E[r]);
         if (y >= jb.oy0 && y < jb.oy1) {
-            uint32_t d = min(min(run, F[r]), Rv[r]);
-            d = d > DT_MAX ? DT_MAX : d;
-            jb.dist[(size_t)y * jb.pitch + x] = (float)d * (1.f / 65536.f);
+            const uint32_t lin = (uint32_t)__builtin_amdgcn_readlane((int)io, r) + 63u * DT_A;
+            const uint32_t rin = (uint32_t)__builtin_amdgcn_readlane((int)io, 32 + r) + 63u * DT_A;
+            const uint32_t rf = min(wave_prefix_min(E[r] + kf), lin) - kf;
+            const uint32_t rb = min(wave_suffix_min(E[r] + kb, lane), rin) - kb;
+            uint32_t d = min(min(run, F[r]), min(rf, rb));
+            d = d >= BIG_MIN ? DT_MAX : d;
+            if (col_out) jb.dist[(size_t)y * jb.pitch + x] = (float)d * (1.f / 65536.f);
         }
-        run = sat_add(run, DT_A);
+        run += DT_A;
     }
 }
 
@@ -657,12 +532,9 @@ int rtvm_launch_dt2(rtvm_ctx* c, const DtJob* d_jobs, int n_first, int second, i
     RTVM_LAUNCH(c, k_dt_diag_a, dim3((nlines + 63) / 64, (nch + GR - 1) / GR, 2 * njobs), dim3(256), 0, d_jobs, n_first,
                 second);
     RTVM_LAUNCH(c, k_dt_diag_b, dim3(max_w / TW + 2, nch, njobs), dim3(DB_THREADS), 0, d_jobs, n_first, second);
-    RTVM_LAUNCH(c, k_dt_scan, dim3(max_h + ncol_x * ((nch + 3) / 4), njobs), dim3(256), 0, d_jobs, n_first, second, max_h,
-                ncol_x);
-    if (max_w + 7 > 2048)  // rows that take more than one pass of the row scan
-        RTVM_LAUNCH(c, k_dt_rows_wide, dim3(max_h, njobs), dim3(256), 0, d_jobs, n_first, second);
-    RTVM_LAUNCH(c, k_dt_chunks, dim3(ncol_x, njobs, 2), dim3(64), 0, d_jobs, n_first, second);
-    RTVM_LAUNCH(c, k_dt_cols, dim3(ncol_x, nch + 1, njobs), dim3(64), 0, d_jobs, n_first, second);
+    RTVM_LAUNCH(c, k_dt_sum, dim3(ncol_x, (nch + 3) / 4, njobs), dim3(256), 0, d_jobs, n_first, second);
+    RTVM_LAUNCH(c, k_dt_chunks, dim3(ncol_x + (max_h + 63) / 64, njobs, 2), dim3(64), 0, d_jobs, n_first, second, ncol_x);
+    RTVM_LAUNCH(c, k_dt_final, dim3(ncol_x, nch + 1, njobs), dim3(64), 0, d_jobs, n_first, second);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
