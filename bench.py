@@ -86,8 +86,8 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
         # steps of the windows' rows and columns in (the window itself once); column and row summaries out
         "k_dt_sum": 2 * (rows_px + cols_px - win2) + cols_px / 4 + rows_px / 8,
         "k_dt_final": 2 * win2 + cols_px / 4 + rows_px / 8 + 4 * win2,   # steps and summaries in; f32 out
-        "k_blur_rows<false>": 4 * roi_px + 4 * win + 8 * roi_px,   # two distance planes in, two row-blurred weights out
-        "k_blur_cols<false>": 8 * win + roi_px + 8 * roi_px,       # row-blurred weights + mask in, final weights out
+        "k_blur_rows": 4 * roi_px + 4 * win + 8 * roi_px,   # two distance planes in, two row-blurred weights out
+        "k_blur_cols": 8 * win + roi_px + 8 * roi_px,       # row-blurred weights + mask in, final weights out
         # per frame: mask + warped + two weights in; per batch: canvas + mask in/out and their snapshot
         "k_commit<false>": 12 * roi_px + 12 * roi_px / batch,
         "k_hamming_argmin": 2 * nkp * 32 * 2,

@@ -275,9 +275,7 @@ __global__ __launch_bounds__(64) void k_batch_collect(const FrameSlot* __restric
 // report the host reads.
 // host_glue: the homographies came from the host, which keeps the stream state itself; there is
 // no device state to go back to.
-__global__ void k_batch_finish(StreamState* __restrict__ st, const StreamState* __restrict__ snap, int n,
-                               BatchReport* __restrict__ rep, int host_glue) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void batch_finish(StreamState* st, const StreamState* snap, int n, BatchReport* rep, int host_glue) {
     const int bad = st->bad_frame;
     int reason = RTVM_PENDING_NONE;
     bool later = false;
@@ -341,6 +339,25 @@ __device__ __forceinline__ void copy_feat(const FeatSet& cur, const FeatSet& pre
     const uint4* s = reinterpret_cast<const uint4*>(cur.desc + (size_t)i * desc_bytes);
     uint4* d = reinterpret_cast<uint4*>(prev.desc + (size_t)i * desc_bytes);
     for (int w = part; w < desc_bytes / 16; w += parts) d[w] = s[w];
+}
+
+__global__ void k_batch_finish(StreamState* __restrict__ st, const StreamState* __restrict__ snap, int n,
+                               BatchReport* __restrict__ rep, int host_glue) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) batch_finish(st, snap, n, rep, host_glue);
+}
+
+// The end of a batch and the hand-over of the features in one workgroup (contexts with 32-byte
+// descriptors: a thousand keypoints are 100 KB; the 512-byte ones take k_advance_feats' grid).
+__global__ __launch_bounds__(1024) void k_batch_finish_advance(StreamState* st, const StreamState* snap, int n, BatchReport* rep,
+                                                               int host_glue, const FrameSlot* __restrict__ slots, int sb,
+                                                               FeatSet prev, int max_kp, int desc_bytes) {
+    if (threadIdx.x == 0) batch_finish(st, snap, n, rep, host_glue);
+    __syncthreads();
+    const int j = st->last_good;
+    if (j < 0) return;
+    const FeatSet cur = slots[sb + j].feat;
+    const int nk = min(*cur.count, max_kp);
+    for (int t = threadIdx.x; t < max(nk, 1); t += 1024) copy_feat(cur, prev, t, nk, desc_bytes);
 }
 
 // kp_prev, des_prev <- features of the last frame of the batch that advanced the state
@@ -479,8 +496,13 @@ int queue_back_half(rtvm_ctx* c, int set, int sb, const uint8_t* const* ptrs, in
     if ((r = rtvm_launch_sides(c, ptrs, n))) return r;
     if ((r = rtvm_launch_weights(c, n))) return r;
     if ((r = rtvm_launch_commit(c, n))) return r;
-    RTVM_LAUNCH(c, k_batch_finish, dim3(1), dim3(64), 0, c->d_state, c->d_snap, n, c->d_rep + slot, host_H ? 1 : 0);
-    launch_advance_feats(c, sb, -1);
+    if (c->desc_bytes <= 64) {
+        RTVM_LAUNCH(c, k_batch_finish_advance, dim3(1), dim3(1024), 0, c->d_state, (const StreamState*)c->d_snap, n, c->d_rep + slot,
+                    host_H ? 1 : 0, (const FrameSlot*)c->d_slots, sb, c->feat_prev, c->orb.max_kp, c->desc_bytes);
+    } else {
+        RTVM_LAUNCH(c, k_batch_finish, dim3(1), dim3(64), 0, c->d_state, c->d_snap, n, c->d_rep + slot, host_H ? 1 : 0);
+        launch_advance_feats(c, sb, -1);
+    }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->stream_main));
     return RTVM_OK;

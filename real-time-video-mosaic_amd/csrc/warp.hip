@@ -24,25 +24,21 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p < n ? p : period - p;
 }
 
-// One thread per frame (blockIdx.x = index in the batch): M = H^-1 (cv::invert's 3x3
-// closed form), the region of the canvas the frame can touch, and the two
-// distance-transform jobs of the frame.
-__global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restrict__ wp,
-                            DtJob* __restrict__ jobs_new, DtJob* __restrict__ jobs_old, int fh, int fw, int ch,
-                            int cw, int force_full, const int* __restrict__ skip, StreamState* __restrict__ st) {
-    if (threadIdx.x != 0) return;
-    if (st && blockIdx.x == 0) st->bad_frame = 0x7FFFFFFF;  // no blend of this batch has cleared a pixel yet
-    Hp += 9 * blockIdx.x;
-    wp += blockIdx.x;
-    DtJob* jobs[2] = {jobs_new ? jobs_new + blockIdx.x : nullptr, jobs_old ? jobs_old + blockIdx.x : nullptr};
-    if (skip) skip += blockIdx.x;
+// Frame j of the batch: M = H^-1 (cv::invert's 3x3 closed form), the region of the canvas the
+// frame can touch, and the two distance-transform jobs of the frame.
+__device__ void warp_prep_frame(int j, const double* Hp, WarpParams* wp, DtJob* jobs_new, DtJob* jobs_old, int fh, int fw,
+                                int ch, int cw, int force_full, const int* skip) {
+    Hp += 9 * j;
+    wp += j;
+    DtJob* jobs[2] = {jobs_new ? jobs_new + j : nullptr, jobs_old ? jobs_old + j : nullptr};
+    if (skip) skip += j;
     if (skip && *skip) {  // frame rejected upstream: nothing to stitch
         wp->rx0 = wp->ry0 = wp->rx1 = wp->ry1 = 0;
         wp->wx0 = wp->wy0 = wp->wx1 = wp->wy1 = 0;
-        for (int j = 0; j < 2; j++)
-            if (jobs[j]) {
-                jobs[j]->x0 = jobs[j]->y0 = jobs[j]->x1 = jobs[j]->y1 = 0;
-                jobs[j]->ox0 = jobs[j]->oy0 = jobs[j]->ox1 = jobs[j]->oy1 = 0;
+        for (int k = 0; k < 2; k++)
+            if (jobs[k]) {
+                jobs[k]->x0 = jobs[k]->y0 = jobs[k]->x1 = jobs[k]->y1 = 0;
+                jobs[k]->ox0 = jobs[k]->oy0 = jobs[k]->ox1 = jobs[k]->oy1 = 0;
             }
         return;
     }
@@ -137,8 +133,7 @@ __global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restric
 // distances.  cbox = bounding box so far (x0, y0, x1, y1; regions of interest, so a superset of
 // the non-zero pixels, which is the safe side); frame j also counts the frames before it in the
 // batch.  One block; thread j = frame j.
-__global__ __launch_bounds__(64) void k_old_rects(const WarpParams* __restrict__ wp, DtJob* __restrict__ jobs_old, int n,
-                                                  int* __restrict__ cbox, int ch, int cw) {
+__device__ void old_rects(const WarpParams* wp, DtJob* jobs_old, int n, int* cbox, int ch, int cw) {
     const int j = threadIdx.x;
     int x0 = cbox[0], y0 = cbox[1], x1 = cbox[2], y1 = cbox[3];
     __syncthreads();
@@ -172,6 +167,24 @@ __global__ __launch_bounds__(64) void k_old_rects(const WarpParams* __restrict__
             }
         for (int k = 0; k < 4; k++) cbox[k] = b[k], cbox[4 + k] = u[k];
     }
+}
+
+// Stage entry points: the parameters of one frame, no distance-transform jobs.
+__global__ void k_warp_prep(const double* __restrict__ Hp, WarpParams* __restrict__ wp, int fh, int fw, int ch, int cw,
+                            int force_full) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        warp_prep_frame(0, Hp, wp, nullptr, nullptr, fh, fw, ch, cw, force_full, nullptr);
+}
+
+// The frames of a batch: one block, thread j = frame j; then the rectangles of the old-mask jobs.
+__global__ __launch_bounds__(64) void k_warp_prep_batch(const double* Hp, WarpParams* wp, DtJob* jobs_new, DtJob* jobs_old,
+                                                        int n, int fh, int fw, int ch, int cw, const int* skip,
+                                                        StreamState* st, int* cbox) {
+    const int j = threadIdx.x;
+    if (st && j == 0) st->bad_frame = 0x7FFFFFFF;  // no blend of this batch has cleared a pixel yet
+    if (j < n) warp_prep_frame(j, Hp, wp, jobs_new, jobs_old, fh, fw, ch, cw, 0, skip);
+    __syncthreads();
+    old_rects(wp, jobs_old, n, cbox, ch, cw);
 }
 
 // The 2x2 taps at (ix, iy) .. (ix+1, iy+1), 3 channels each; taps outside the frame read 0
@@ -416,27 +429,24 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
 }
 
 // blockIdx.z = frame of the batch.  Tiles of BR_TILE x 4 pixels of the frame's region (rows of
-// the blend window, columns of the ROI), tile (0,0) holding the region's first pixel.
-// REST = false: one tile per workgroup, the grid (xcd_grid(ex * ey) workgroups) sized for a region
-// of about the frame's size.  REST = true: a small grid that loops over the tiles beyond that many,
-// for regions larger than expected (normally none).
-template <bool REST>
+// the blend window, columns of the ROI), tile (0,0) holding the region's first pixel.  The grid
+// (a multiple of 8 workgroups) is sized for a region of about the frame's size: one tile per
+// workgroup; a larger region (normally none) is walked with the grid as stride.
 __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
-                                                   const SideDev* __restrict__ sides, int cw, int ex, int ey) {
+                                                   const SideDev* __restrict__ sides, int cw) {
     const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const SideDev side = sides[blockIdx.z];
     __shared__ __align__(16) f32x2 s_w[4][BR_STAGE];
     const int rx1 = wp->rx1, wy1 = wp->wy1;
     const int ox = wp->rx0 & ~3, oy = wp->wy0;
     const int ntx = rx1 > ox ? (rx1 - ox + BR_TILE - 1) / BR_TILE : 0, nty = wy1 > oy ? (wy1 - oy + 3) / 4 : 0;
-    const int T = ntx * nty, G = xcd_grid(ex * ey);
-    if (!REST) {  // G workgroups in x: the region's tiles in one contiguous run per XCD
-        const int t = T <= G ? xcd_tile(blockIdx.x, T) : (int)blockIdx.x;
-        if (t < 0 || t >= T) return;
-        blur_rows_tile(wp, gk, side, cw, ox + BR_TILE * (t % ntx), oy + 4 * (t / ntx), s_w);
+    const int T = ntx * nty, G = gridDim.x;
+    if (T <= G) {  // the usual case: the region's tiles in one contiguous run per XCD
+        const int t = xcd_tile(blockIdx.x, T);
+        if (t >= 0) blur_rows_tile(wp, gk, side, cw, ox + BR_TILE * (t % ntx), oy + 4 * (t / ntx), s_w);
         return;
     }
-    for (int t = G + blockIdx.y * gridDim.x + blockIdx.x; t < T; t += gridDim.x * gridDim.y) {
+    for (int t = blockIdx.x; t < T; t += G) {  // a region larger than the grid was sized for
         blur_rows_tile(wp, gk, side, cw, ox + BR_TILE * (t % ntx), oy + 4 * (t / ntx), s_w);
         __syncthreads();  // the staging area is reused by the next tile
     }
@@ -502,23 +512,21 @@ __device__ __forceinline__ void blur_cols_tile(const WarpParams* __restrict__ wp
         blur_cols_window<true>(wp, gk, side, ch, cw, x, ya, need);
 }
 
-// blockIdx.z = frame of the batch.  Tiles of 64 x 4*BC_ROWS pixels of the ROI; REST as in k_blur_rows.
-template <bool REST>
+// blockIdx.z = frame of the batch.  Tiles of 64 x 4*BC_ROWS pixels of the ROI; grid as in k_blur_rows.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_blur_cols(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
-                                                   const SideDev* __restrict__ sides, int ch, int cw, int ex, int ey) {
+                                                   const SideDev* __restrict__ sides, int ch, int cw) {
     const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const SideDev side = sides[blockIdx.z];
     const int rx1 = wp->rx1, ry1 = wp->ry1;
     const int ox = wp->rx0 & ~63, oy = wp->ry0;
     const int ntx = rx1 > ox ? (rx1 - ox + 63) / 64 : 0, nty = ry1 > oy ? (ry1 - oy + 4 * BC_ROWS - 1) / (4 * BC_ROWS) : 0;
-    const int T = ntx * nty, G = xcd_grid(ex * ey);
-    if (!REST) {  // G workgroups in x: the region's tiles in one contiguous run per XCD
-        const int t = T <= G ? xcd_tile(blockIdx.x, T) : (int)blockIdx.x;
-        if (t < 0 || t >= T) return;
-        blur_cols_tile(wp, gk, side, ch, cw, ox + 64 * (t % ntx), oy + 4 * BC_ROWS * (t / ntx));
+    const int T = ntx * nty, G = gridDim.x;
+    if (T <= G) {  // the usual case: the region's tiles in one contiguous run per XCD
+        const int t = xcd_tile(blockIdx.x, T);
+        if (t >= 0) blur_cols_tile(wp, gk, side, ch, cw, ox + 64 * (t % ntx), oy + 4 * BC_ROWS * (t / ntx));
         return;
     }
-    for (int t = G + blockIdx.y * gridDim.x + blockIdx.x; t < T; t += gridDim.x * gridDim.y)
+    for (int t = blockIdx.x; t < T; t += G)  // a region larger than the grid was sized for
         blur_cols_tile(wp, gk, side, ch, cw, ox + 64 * (t % ntx), oy + 4 * BC_ROWS * (t / ntx));
 }
 
@@ -700,8 +708,7 @@ int rtvm_launch_canvas_init(rtvm_ctx* c, const uint8_t* d_bgr, int row_off, int 
 
 // Full-canvas warp into d_out (stage parity of cv2.warpPerspective alone).
 int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, uint8_t* d_out) {
-    RTVM_LAUNCH(c, k_warp_prep, dim3(1), dim3(64), 0, d_H, c->d_wp, (DtJob*)nullptr, (DtJob*)nullptr, c->fh, c->fw,
-                c->ch, c->cw, 1, (const int*)nullptr, (StreamState*)nullptr);
+    RTVM_LAUNCH(c, k_warp_prep, dim3(1), dim3(64), 0, d_H, c->d_wp, c->fh, c->fw, c->ch, c->cw, 1);
     BatchPtrs bp;
     memset(&bp, 0, sizeof(bp));
     bp.p[0] = d_bgr;
@@ -718,10 +725,8 @@ int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, 
 
 int rtvm_launch_warp_prep(rtvm_ctx* c, const double* d_H, const int* d_skip, int n) {
     if (n < 1 || n > c->n_side) RTVM_FAIL(c, RTVM_E_STATE, "warp: %d frames, planes for %d", n, c->n_side);
-    RTVM_LAUNCH(c, k_warp_prep, dim3(n), dim3(64), 0, d_H, c->d_wp, c->d_jobs, c->d_jobs + RTVM_MAX_BATCH, c->fh, c->fw,
-                c->ch, c->cw, 0, d_skip, c->d_state);
-    RTVM_LAUNCH(c, k_old_rects, dim3(1), dim3(64), 0, (const WarpParams*)c->d_wp, c->d_jobs + RTVM_MAX_BATCH, n, c->d_cbox,
-                c->ch, c->cw);
+    RTVM_LAUNCH(c, k_warp_prep_batch, dim3(1), dim3(64), 0, (const double*)d_H, c->d_wp, c->d_jobs, c->d_jobs + RTVM_MAX_BATCH,
+                n, c->fh, c->fw, c->ch, c->cw, d_skip, c->d_state, c->d_cbox);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
 }
@@ -750,17 +755,11 @@ int rtvm_launch_weights(rtvm_ctx* c, int n) {
     const int bw = c->fw + c->fh / 2, bh = c->fh + c->fw / 2;  // a region of about the frame's size
     {
         const unsigned ex = roi_tiles(c->cw, bw, BR_TILE), ey = roi_tiles(c->ch, bh + 30, 4);
-        RTVM_LAUNCH(c, k_blur_rows<false>, dim3(xcd_grid(ex * ey), 1, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
-                    (int)ey);
-        RTVM_LAUNCH(c, k_blur_rows<true>, dim3(2, 8, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw, (int)ex,
-                    (int)ey);
+        RTVM_LAUNCH(c, k_blur_rows, dim3(xcd_grid(ex * ey), 1, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw);
     }
     {
         const unsigned ex = roi_tiles(c->cw, bw, 64), ey = roi_tiles(c->ch, bh, 4 * BC_ROWS);
-        RTVM_LAUNCH(c, k_blur_cols<false>, dim3(xcd_grid(ex * ey), 1, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw,
-                    (int)ex, (int)ey);
-        RTVM_LAUNCH(c, k_blur_cols<true>, dim3(4, 2, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw, (int)ex,
-                    (int)ey);
+        RTVM_LAUNCH(c, k_blur_cols, dim3(xcd_grid(ex * ey), 1, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw);
     }
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;

@@ -20,6 +20,16 @@ print("\nvalue", round(d["value"]), "us/frame", round(1e3 * d["ms_per_step"], 2)
       "stage", d.get("warp_blend_stage", {}).get("us_per_frame"))
 print({k: round(1e3 * v, 1) for k, v in d["roofline"].get("stream_kernel_ms_per_frame", {}).items()})
 t = json.load(open(out + "/kernels.json"))
-for k in t["kernels"][:26]:
+ks = t["kernels"]
+ks = [dict(name=k, **v) for k, v in ks.items()] if isinstance(ks, dict) else ks
+ks.sort(key=lambda k: -k["total_ms"])
+for k in ks[:26]:
     print("%-22s s%d %7.2f us/frame  %8.1f us/launch x %d" % (k["name"], k["stream"], k["us_per_frame"], k["avg_us"], k["launches"]))
 P
+if [ -n "${EXTRA_BENCH:-}" ]; then
+    timeout -k 10 300 python3 bench.py $EXTRA_BENCH > "$OUT/bench_extra.log" 2>&1 || exit $?
+    python3 -c "
+import json,sys
+d=json.loads([l for l in open('$OUT/bench_extra.log') if l.startswith('{')][-1])
+print('extra:', round(d['value']), 'us/frame', round(1e3*d['ms_per_step'],2), 'parity', d.get('parity_checked'))"
+fi
