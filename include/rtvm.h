@@ -370,6 +370,11 @@ int rtvm_bgr2hsv(rtvm_ctx* ctx, const uint8_t* bgr, int h, int w, uint8_t* hsv);
  * of main.py:492-498,528-529,647-649).  ksize 1..31.  Allocates scratch; syncs. */
 int rtvm_morphology(rtvm_ctx* ctx, const uint8_t* mask, int h, int w, int op, int shape, int ksize,
                     int iterations, uint8_t* out);
+/* cv2.Canny(gray, low, high) with the reference's arguments (main.py:489 on the blurred gray
+ * image of _detect_buildings_cv2, main.py:1141): aperture 3, L1 gradient.  Host image h x w u8 in,
+ * edges h x w of 0 / 255 out.  Allocates scratch; syncs. */
+int rtvm_canny(rtvm_ctx* ctx, const uint8_t* gray, int h, int w, double low_thresh, double high_thresh,
+               uint8_t* edges);
 /* The obstacle masks of analyze_for_navigation (main.py:1065-1232) for a host image h x w x 3:
  * boxes = n_boxes rectangles x1, y1, x2, y2 as main.py:1106 hands them to cv2.rectangle (the
  * detections with their class buffer already applied, both corners included).  Outputs, each
@@ -378,8 +383,8 @@ int rtvm_morphology(rtvm_ctx* ctx, const uint8_t* mask, int h, int w, int op, in
  * (main.py:1228, what is_path_clear reads), obstacles_nav (main.py:1232, dilated by the 15x15
  * ellipse).  grid (may be NULL): find_path_astar's occupancy matrix of obstacles_nav at
  * grid_scale (main.py:1346-1359), max(1,h/scale) x max(1,w/scale) bytes of 0 / 1.
- * cv2.Canny of main.py:1141 is not computed: its edges enter the result only as
- * mask | (dilated_edges & mask), which is mask.  Allocates scratch; syncs. */
+ * cv2.Canny of main.py:1141 is not computed here: its edges enter the result only as
+ * mask | (dilated_edges & mask), which is mask (rtvm_canny computes them).  Allocates scratch; syncs. */
 int rtvm_nav_obstacles(rtvm_ctx* ctx, const uint8_t* bgr, int h, int w, const int32_t* boxes, int n_boxes,
                        uint8_t* mask_fire, uint8_t* mask_smoke, uint8_t* texture_mask, uint8_t* obstacles,
                        uint8_t* obstacles_nav, int grid_scale, uint8_t* grid);

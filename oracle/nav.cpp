@@ -283,6 +283,87 @@ extern "C" int rtvm_oracle_nav_obstacles(const uint8_t* bgr, int h, int w, const
 
 // main.py:1346-1359: cell (gy, gx) of the h/scale x w/scale grid is blocked when more than
 // 30 % of scale*scale pixels of its block are set.
+// cv2.Canny(gray, low, high) with the defaults the reference uses (main.py:489,1141: aperture 3,
+// L1 gradient).  [OpenCV-recall]  Sobel 3x3 in 16-bit with replicated borders; magnitude
+// |dx| + |dy| with a ring of zeros around the image; a pixel above `low` is a candidate when it is a
+// maximum along its gradient direction (sectors cut at tan 22.5 and tan 67.5 in 15-bit fixed point;
+// `>` towards the left / upper neighbour, `>=` towards the right / lower one on the axes, `>` on both
+// diagonals); candidates above `high` are edges, and so is every candidate connected to one through
+// candidates (8 neighbours).  OpenCV's stack order and its "neighbour already pushed" shortcuts do not
+// change that set.
+extern "C" int rtvm_oracle_canny(const uint8_t* gray, int h, int w, double low_thresh, double high_thresh,
+                                 uint8_t* edges) {
+    if (h < 1 || w < 1) return -1;
+    if (low_thresh > high_thresh) std::swap(low_thresh, high_thresh);
+    const int low = (int)std::floor(low_thresh), high = (int)std::floor(high_thresh);
+    auto px = [&](int y, int x) -> int {
+        y = std::min(std::max(y, 0), h - 1);
+        x = std::min(std::max(x, 0), w - 1);
+        return gray[(size_t)y * w + x];
+    };
+    std::vector<int16_t> dx((size_t)h * w), dy((size_t)h * w);
+    const int mw = w + 2;
+    std::vector<int> mag((size_t)(h + 2) * mw, 0);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int gx = (px(y - 1, x + 1) + 2 * px(y, x + 1) + px(y + 1, x + 1)) -
+                           (px(y - 1, x - 1) + 2 * px(y, x - 1) + px(y + 1, x - 1));
+            const int gy = (px(y + 1, x - 1) + 2 * px(y + 1, x) + px(y + 1, x + 1)) -
+                           (px(y - 1, x - 1) + 2 * px(y - 1, x) + px(y - 1, x + 1));
+            dx[(size_t)y * w + x] = (int16_t)gx;
+            dy[(size_t)y * w + x] = (int16_t)gy;
+            mag[(size_t)(y + 1) * mw + x + 1] = std::abs(gx) + std::abs(gy);
+        }
+    const int TG22 = 13573;  // (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
+    std::vector<uint8_t> map((size_t)h * w, 1);  // 0 candidate, 1 no edge, 2 edge
+    std::vector<int> stack;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int* m0 = &mag[(size_t)(y + 1) * mw + x + 1];
+            const int m = m0[0];
+            if (m <= low) continue;
+            const int xs = dx[(size_t)y * w + x], ys = dy[(size_t)y * w + x];
+            const int ax = std::abs(xs), ay = std::abs(ys) << 15;
+            const int tg22x = ax * TG22;
+            bool keep;
+            if (ay < tg22x) {
+                keep = m > m0[-1] && m >= m0[1];
+            } else {
+                const int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) {
+                    keep = m > m0[-mw] && m >= m0[mw];
+                } else {
+                    const int sgn = (xs ^ ys) < 0 ? -1 : 1;
+                    keep = m > m0[-mw - sgn] && m > m0[mw + sgn];
+                }
+            }
+            if (!keep) continue;
+            if (m > high) {
+                map[(size_t)y * w + x] = 2;
+                stack.push_back(y * w + x);
+            } else {
+                map[(size_t)y * w + x] = 0;
+            }
+        }
+    while (!stack.empty()) {
+        const int p = stack.back();
+        stack.pop_back();
+        const int y = p / w, x = p % w;
+        for (int j = -1; j <= 1; j++)
+            for (int i = -1; i <= 1; i++) {
+                const int yy = y + j, xx = x + i;
+                if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                uint8_t& q = map[(size_t)yy * w + xx];
+                if (q == 0) {
+                    q = 2;
+                    stack.push_back(yy * w + xx);
+                }
+            }
+    }
+    for (size_t i = 0; i < map.size(); i++) edges[i] = map[i] == 2 ? 255 : 0;
+    return 0;
+}
+
 extern "C" int rtvm_oracle_occupancy_grid(const uint8_t* mask, int h, int w, int scale, uint8_t* grid) {
     if (h < 1 || w < 1 || scale < 1) return -1;
     const int gh = std::max(1, h / scale), gw = std::max(1, w / scale);

@@ -97,6 +97,8 @@ int rtvm_oracle_nav_obstacles(const uint8_t* bgr, int h, int w, const int32_t* b
                               uint8_t* obstacles, uint8_t* obstacles_nav);
 /* main.py:1201: cv2.GaussianBlur(gray, (11,11), 0) on 8-bit pixels */
 int rtvm_oracle_gauss11_u8(const uint8_t* src, int h, int w, uint8_t* dst);
+/* cv2.Canny(gray, low, high), aperture 3, L1 gradient (main.py:489,1141); edges 0 / 255 */
+int rtvm_oracle_canny(const uint8_t* gray, int h, int w, double low_thresh, double high_thresh, uint8_t* edges);
 /* main.py:1346-1359: occupancy matrix of find_path_astar */
 int rtvm_oracle_occupancy_grid(const uint8_t* mask, int h, int w, int scale, uint8_t* grid);
 

@@ -8,4 +8,4 @@ from . import _ffi, synth  # noqa: F401
 from ._ffi import Context, RtvmError  # noqa: F401
 from .types import KeyPoint, DMatch  # noqa: F401
 from .mosaic import VideMosaic, crop_black_areas, scale_to_screen  # noqa: F401
-from .navigation import navigation_obstacles, obstacle_boxes, occupancy_grid  # noqa: F401
+from .navigation import canny_edges, navigation_obstacles, obstacle_boxes, occupancy_grid  # noqa: F401

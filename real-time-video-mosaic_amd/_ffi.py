@@ -64,6 +64,7 @@ SIGNATURES = {
     "rtvm_canvas_read_scaled": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
     "rtvm_bgr2hsv": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "rtvm_morphology": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "rtvm_canny": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
     "rtvm_nav_obstacles": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "rtvm_occupancy_grid": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "rtvm_stream_begin": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
@@ -443,6 +444,16 @@ class Context:
         out = np.empty_like(mask)
         self._check(lib().rtvm_morphology(self._h, ptr(mask), mask.shape[0], mask.shape[1], int(op), int(shape),
                                           int(ksize), int(iterations), ptr(out)))
+        return out
+
+    def canny(self, gray, threshold1, threshold2):
+        """cv2.Canny(gray, threshold1, threshold2) of a u8 image (aperture 3, L1 gradient): edges 0 / 255."""
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        if gray.ndim != 2:
+            raise ValueError("canny: a single-channel image is expected, got shape %r" % (gray.shape,))
+        out = np.empty_like(gray)
+        self._check(lib().rtvm_canny(self._h, ptr(gray), gray.shape[0], gray.shape[1], float(threshold1),
+                                     float(threshold2), ptr(out)))
         return out
 
     def nav_obstacles(self, image, boxes=(), grid_scale=None):

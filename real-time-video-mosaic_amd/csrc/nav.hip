@@ -252,6 +252,116 @@ __global__ __launch_bounds__(256) void k_occupancy(const uint8_t* __restrict__ m
     grid[(size_t)gy * gw + gx] = (double)count > (double)(scale * scale) * 0.3 ? 1 : 0;
 }
 
+// ---- cv2.Canny (main.py:489,1141): aperture 3, L1 gradient ----
+// Candidate map of one tile of 64 x 16 pixels: the gray tile with two pixels of replicated border in
+// LDS, Sobel 3x3 and |dx| + |dy| for the tile and a one-pixel rim (zero outside the image), then the
+// maximum test along the gradient direction.  map: 0 candidate (above `low`), 1 nothing, 2 edge
+// (candidate above `high`).
+constexpr int CN_TW = 64, CN_TH = 16;
+__global__ __launch_bounds__(256) void k_canny_nms(const uint8_t* __restrict__ gray, int h, int w, int low, int high,
+                                                   uint8_t* __restrict__ map) {
+    __shared__ uint8_t s_g[CN_TH + 4][CN_TW + 4];
+    __shared__ int s_m[CN_TH + 2][CN_TW + 2];
+    __shared__ short s_dx[CN_TH + 2][CN_TW + 2], s_dy[CN_TH + 2][CN_TW + 2];
+    const int x0 = blockIdx.x * CN_TW, y0 = blockIdx.y * CN_TH;
+    for (int i = threadIdx.x; i < (CN_TH + 4) * (CN_TW + 4); i += 256) {
+        const int r = i / (CN_TW + 4), c = i % (CN_TW + 4);
+        const int y = min(max(y0 - 2 + r, 0), h - 1), x = min(max(x0 - 2 + c, 0), w - 1);
+        s_g[r][c] = gray[(size_t)y * w + x];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (CN_TH + 2) * (CN_TW + 2); i += 256) {
+        const int r = i / (CN_TW + 2), c = i % (CN_TW + 2);
+        const int y = y0 - 1 + r, x = x0 - 1 + c;
+        int gx = 0, gy = 0, m = 0;
+        if (y >= 0 && y < h && x >= 0 && x < w) {
+            // pixel (y, x) is s_g[r + 1][c + 1]
+            const int a = s_g[r][c], b = s_g[r][c + 1], cc = s_g[r][c + 2];
+            const int d = s_g[r + 1][c], f = s_g[r + 1][c + 2];
+            const int g = s_g[r + 2][c], hh = s_g[r + 2][c + 1], k = s_g[r + 2][c + 2];
+            gx = (cc + 2 * f + k) - (a + 2 * d + g);
+            gy = (g + 2 * hh + k) - (a + 2 * b + cc);
+            m = abs(gx) + abs(gy);
+        }
+        s_m[r][c] = m;
+        s_dx[r][c] = (short)gx;
+        s_dy[r][c] = (short)gy;
+    }
+    __syncthreads();
+    const int TG22 = 13573;  // tan 22.5 degrees in 15-bit fixed point
+    for (int i = threadIdx.x; i < CN_TH * CN_TW; i += 256) {
+        const int r = i / CN_TW + 1, c = i % CN_TW + 1;
+        const int y = y0 + r - 1, x = x0 + c - 1;
+        if (y >= h || x >= w) continue;
+        const int m = s_m[r][c];
+        uint8_t out = 1;
+        if (m > low) {
+            const int xs = s_dx[r][c], ys = s_dy[r][c];
+            const int ax = abs(xs), ay = abs(ys) << 15;
+            const int tg22x = ax * TG22;
+            bool keep;
+            if (ay < tg22x) {
+                keep = m > s_m[r][c - 1] && m >= s_m[r][c + 1];
+            } else if (ay > tg22x + (ax << 16)) {
+                keep = m > s_m[r - 1][c] && m >= s_m[r + 1][c];
+            } else {
+                const int sgn = (xs ^ ys) < 0 ? -1 : 1;
+                keep = m > s_m[r - 1][c - sgn] && m > s_m[r + 1][c + sgn];
+            }
+            if (keep) out = m > high ? 2 : 0;
+        }
+        map[(size_t)y * w + x] = out;
+    }
+}
+
+// Hysteresis: a candidate with an edge among its 8 neighbours becomes an edge.  A workgroup takes a
+// tile of 64 x 16 pixels with a one-pixel rim and repeats the step inside the tile until nothing
+// changes there; *changed says whether any tile changed, and the host launches again until none did.
+__global__ __launch_bounds__(256) void k_canny_hyst(uint8_t* __restrict__ map, int h, int w, int* __restrict__ changed) {
+    __shared__ uint8_t s[CN_TH + 2][CN_TW + 2];
+    __shared__ int s_again, s_any;
+    const int x0 = blockIdx.x * CN_TW, y0 = blockIdx.y * CN_TH;
+    for (int i = threadIdx.x; i < (CN_TH + 2) * (CN_TW + 2); i += 256) {
+        const int r = i / (CN_TW + 2), c = i % (CN_TW + 2);
+        const int y = y0 - 1 + r, x = x0 - 1 + c;
+        s[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? map[(size_t)y * w + x] : (uint8_t)1;
+    }
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    for (;;) {
+        if (threadIdx.x == 0) s_again = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < CN_TH * CN_TW; i += 256) {
+            const int r = i / CN_TW + 1, c = i % CN_TW + 1;
+            if (s[r][c] != 0) continue;
+            const bool near = s[r - 1][c - 1] == 2 || s[r - 1][c] == 2 || s[r - 1][c + 1] == 2 || s[r][c - 1] == 2 ||
+                              s[r][c + 1] == 2 || s[r + 1][c - 1] == 2 || s[r + 1][c] == 2 || s[r + 1][c + 1] == 2;
+            if (near) {
+                s[r][c] = 2;  // only ever 0 -> 2: a neighbour reading the old value finds the new one next round
+                s_again = 1;
+            }
+        }
+        __syncthreads();
+        const int again = s_again;
+        __syncthreads();
+        if (!again) break;
+        if (threadIdx.x == 0) s_any = 1;
+    }
+    __syncthreads();
+    if (!s_any) return;
+    for (int i = threadIdx.x; i < CN_TH * CN_TW; i += 256) {
+        const int r = i / CN_TW + 1, c = i % CN_TW + 1;
+        const int y = y0 + r - 1, x = x0 + c - 1;
+        if (y < h && x < w && s[r][c] == 2) map[(size_t)y * w + x] = 2;
+    }
+    if (threadIdx.x == 0) *changed = 1;
+}
+
+__global__ __launch_bounds__(256) void k_canny_out(const uint8_t* __restrict__ map, size_t n, uint8_t* __restrict__ edges) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) edges[i] = map[i] == 2 ? 255 : 0;
+}
+
 // ---- host side ----
 
 int cv_round(double v) { return (int)std::lrint(v); }
@@ -381,6 +491,43 @@ extern "C" int rtvm_morphology(rtvm_ctx* c, const uint8_t* mask, int h, int w, i
         if (r) return r;
     }
     HIP_TRY(c, hipMemcpyAsync(out, m, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTVM_OK;
+}
+
+extern "C" int rtvm_canny(rtvm_ctx* c, const uint8_t* gray, int h, int w, double low_thresh, double high_thresh,
+                          uint8_t* edges) {
+    if (!c) return RTVM_E_ARG;
+    if (!gray || !edges || h < 1 || w < 1 || !(low_thresh == low_thresh) || !(high_thresh == high_thresh))
+        RTVM_FAIL(c, RTVM_E_ARG, "canny: bad argument");
+    if (low_thresh > high_thresh) std::swap(low_thresh, high_thresh);
+    const double lim = 1 << 20;  // magnitudes stay below 2040
+    const int low = (int)std::floor(std::min(std::max(low_thresh, -lim), lim));
+    const int high = (int)std::floor(std::min(std::max(high_thresh, -lim), lim));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)h * w;
+    DevBuf in, map, out, flag;
+    HIP_TRY(c, hipMalloc(&in.p, n));
+    HIP_TRY(c, hipMalloc(&map.p, n));
+    HIP_TRY(c, hipMalloc(&out.p, n));
+    HIP_TRY(c, hipMalloc(&flag.p, sizeof(int)));
+    HIP_TRY(c, hipMemcpyAsync(in.p, gray, n, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((w + CN_TW - 1) / CN_TW, (h + CN_TH - 1) / CN_TH);
+    RTVM_LAUNCH(c, k_canny_nms, grid, dim3(256), 0, (const uint8_t*)in.u8(), h, w, low, high, map.u8());
+    // an edge crosses at least one tile per launch: the diagonal of the tile grid bounds the rounds
+    const int max_rounds = (int)(grid.x * grid.y) + 2;
+    int* h_flag = (int*)c->h_pinned;
+    for (int round = 0; round < max_rounds; round++) {
+        HIP_TRY(c, hipMemsetAsync(flag.p, 0, sizeof(int), c->stream));
+        RTVM_LAUNCH(c, k_canny_hyst, grid, dim3(256), 0, map.u8(), h, w, (int*)flag.p);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(h_flag, flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!*h_flag) break;
+    }
+    RTVM_LAUNCH(c, k_canny_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const uint8_t*)map.u8(), n, out.u8());
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(edges, out.p, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RTVM_OK;
 }

@@ -51,6 +51,11 @@ def navigation_obstacles(frame, detections=(), grid_scale=None, ctx=None):
     return (ctx or _stage_ctx()).nav_obstacles(frame, boxes, grid_scale)
 
 
+def canny_edges(gray, threshold1, threshold2, ctx=None):
+    """cv2.Canny(gray, threshold1, threshold2) as main.py:489 and main.py:1141 call it."""
+    return (ctx or _stage_ctx()).canny(gray, threshold1, threshold2)
+
+
 def occupancy_grid(obstacle_mask, scale=4, ctx=None):
     """main.py:1346-1359: `matrix` of find_path_astar as a u8 array [h // scale, w // scale]."""
     return (ctx or _stage_ctx()).occupancy_grid(obstacle_mask, scale)

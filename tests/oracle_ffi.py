@@ -244,6 +244,13 @@ def morphology(mask, op, shape, ksize, iterations=1):
     return out
 
 
+def canny(gray, low, high):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    out = np.empty_like(gray)
+    assert lib().rtvm_oracle_canny(_p(gray), gray.shape[0], gray.shape[1], C.c_double(low), C.c_double(high), _p(out)) == 0
+    return out
+
+
 def nav_obstacles(bgr, boxes=()):
     bgr = np.ascontiguousarray(bgr, np.uint8)
     h, w = bgr.shape[:2]

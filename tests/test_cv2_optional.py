@@ -91,6 +91,13 @@ def test_gaussian_blur_31_main_py_897():
     assert np.abs(cv2.GaussianBlur(w, (31, 31), 0) - orc.gaussian_blur31(w)).max() <= 1e-6
 
 
+def test_canny_main_py_489_1141():
+    g = cv2.cvtColor(frames(1, seed=9)[0], cv2.COLOR_BGR2GRAY)
+    assert np.array_equal(cv2.Canny(g, 50, 150), orc.canny(g, 50, 150))
+    b = cv2.GaussianBlur(g, (3, 3), 0)
+    assert np.array_equal(cv2.Canny(b, 40, 120), orc.canny(b, 40, 120))
+
+
 def test_sift_keypoints_main_py_33():
     f = frames(1, seed=8)[0]
     kp, des = cv2.SIFT_create(700).detectAndCompute(cv2.cvtColor(f, cv2.COLOR_BGR2GRAY), None)
