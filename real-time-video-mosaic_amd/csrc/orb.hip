@@ -40,6 +40,7 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // Also clears the slot's candidate counters and score histograms for the FAST stage.
 __global__ __launch_bounds__(256) void k_gray(const FrameSlot* __restrict__ slots, int sb, unsigned off0, int w, int h,
                                               int pitch, GrayCoef gc) {
+    // 8-bit pixels times 15-bit coefficients: 24-bit multiplies (full rate; a 32-bit one takes four times as long)
     const uint32_t cb = gc.cb, cg = gc.cg, cr = gc.cr, half = 1u << (gc.shift - 1), sh = gc.shift;
     const FrameSlot& S = slots[sb + blockIdx.z];
     const uint8_t* __restrict__ bgr = S.bgr;
@@ -56,10 +57,10 @@ __global__ __launch_bounds__(256) void k_gray(const FrameSlot* __restrict__ slot
         const uint32_t b0 = v[0] & 255, g0 = (v[0] >> 8) & 255, r0 = (v[0] >> 16) & 255, b1 = v[0] >> 24;
         const uint32_t g1 = v[1] & 255, r1 = (v[1] >> 8) & 255, b2 = (v[1] >> 16) & 255, g2 = v[1] >> 24;
         const uint32_t r2 = v[2] & 255, b3 = (v[2] >> 8) & 255, g3 = (v[2] >> 16) & 255, r3 = v[2] >> 24;
-        const uint32_t y0 = (b0 * cb + g0 * cg + r0 * cr + half) >> sh;
-        const uint32_t y1 = (b1 * cb + g1 * cg + r1 * cr + half) >> sh;
-        const uint32_t y2 = (b2 * cb + g2 * cg + r2 * cr + half) >> sh;
-        const uint32_t y3 = (b3 * cb + g3 * cg + r3 * cr + half) >> sh;
+        const uint32_t y0 = (__umul24(b0, cb) + __umul24(g0, cg) + __umul24(r0, cr) + half) >> sh;
+        const uint32_t y1 = (__umul24(b1, cb) + __umul24(g1, cg) + __umul24(r1, cr) + half) >> sh;
+        const uint32_t y2 = (__umul24(b2, cb) + __umul24(g2, cg) + __umul24(r2, cr) + half) >> sh;
+        const uint32_t y3 = (__umul24(b3, cb) + __umul24(g3, cg) + __umul24(r3, cr) + half) >> sh;
         *reinterpret_cast<uint32_t*>(out + (size_t)y * pitch + x) = y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
     } else {
         for (int i = 0; x + i < w; i++)
@@ -93,12 +94,13 @@ __global__ __launch_bounds__(256) void k_resize(const FrameSlot* __restrict__ sl
     const int sy0 = yofs[ty0], sy1 = (int)yofs[ylast] + 1;           // inclusive last row
     const bool staged = sx1 - sx0 < TC && sy1 - sy0 < TR;
     if (staged) {
-        const int nq = (sx1 - sx0) / 4 + 1, nr = sy1 - sy0 + 1;
-        for (int i = tid; i < nr * nq; i += 256) {
-            const int r = i / nq, q = i % nq;
-            const int y = min(sy0 + r, sh - 1), x = min(sx0 + 4 * q, sp - 4);
-            *reinterpret_cast<uint32_t*>(&t[r][4 * q]) = *reinterpret_cast<const uint32_t*>(src + (size_t)y * sp + x);
-        }
+        const int nq = (sx1 - sx0) / 4 + 1, nr = sy1 - sy0 + 1;  // at most TC / 4 = 28 words per row
+        const int q = tid & 31;
+        if (q < nq)
+            for (int r = tid >> 5; r < nr; r += 8) {
+                const int y = min(sy0 + r, sh - 1), x = min(sx0 + 4 * q, sp - 4);
+                *reinterpret_cast<uint32_t*>(&t[r][4 * q]) = *reinterpret_cast<const uint32_t*>(src + (unsigned)(y * sp + x));
+            }
     }
     __syncthreads();
     const int x = tx0 + (tid & 63);
@@ -127,9 +129,10 @@ __global__ __launch_bounds__(256) void k_resize(const FrameSlot* __restrict__ sl
             a10 = src[(size_t)yo1 * sp + xo];
             a11 = src[(size_t)yo1 * sp + xo1];
         }
-        const unsigned h0 = (256u - cx) * a00 + cx * a01;
-        const unsigned h1 = (256u - cx) * a10 + cx * a11;
-        unsigned v = (256u - cy) * h0 + cy * h1;
+        // 9-bit weights, 8- and 16-bit values: 24-bit multiplies
+        const unsigned h0 = __umul24(256u - cx, a00) + __umul24(cx, a01);
+        const unsigned h1 = __umul24(256u - cx, a10) + __umul24(cx, a11);
+        unsigned v = __umul24(256u - cy, h0) + __umul24(cy, h1);
         v = (v + 32768u) >> 16;
         dst[(size_t)y * dp + x] = (uint8_t)(v > 255u ? 255u : v);
     }
@@ -218,6 +221,20 @@ __device__ __forceinline__ int fast_score_at(const uint8_t (*s)[LP], int row, in
     return best > FAST_T ? best - 1 : 0;
 }
 
+// The two axis pairs of the FAST test for two positions at once (16-bit halves): bit 15 of a half is
+// set when both the vertical pair (t, b) and the horizontal pair (l, r) hold a pixel brighter than
+// v + FAST_T or both hold one darker than v - FAST_T ... in the sense of fast_candidate's first two lines.
+__device__ __forceinline__ uint32_t quick_pair(uint32_t v, uint32_t t, uint32_t b, uint32_t l, uint32_t r) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 V = __builtin_bit_cast(us2, v), T = __builtin_bit_cast(us2, t), B = __builtin_bit_cast(us2, b);
+    const us2 L = __builtin_bit_cast(us2, l), R = __builtin_bit_cast(us2, r);
+    const us2 th = {FAST_T, FAST_T};
+    const us2 vt = V + th;
+    const us2 a = ((__builtin_elementwise_min(T, B) + th) - V) | (vt - __builtin_elementwise_max(T, B));
+    const us2 c = ((__builtin_elementwise_min(L, R) + th) - V) | (vt - __builtin_elementwise_max(L, R));
+    return __builtin_bit_cast(uint32_t, a & c) & 0x80008000u;
+}
+
 // FAST + 3x3 non-maximum suppression for one tile of 64 x 32 pixels of the region that
 // survives ORB's 31-pixel border: scores of the tile and a one-pixel rim in LDS, then a
 // pixel is kept iff its score beats its 8 neighbours strictly.  Keeps are appended as
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P, const FrameSlot* __restr
     const uint8_t* __restrict__ img = SL.pyr + P.off[l];
     // pixels: rows ty0-4 .. ty0+35, columns tx0-7 .. tx0+72 (tx0-7 is a multiple of 4)
     __shared__ __align__(16) uint8_t s[40][80];
-    __shared__ uint8_t sc[34][68];
+    __shared__ __align__(4) uint8_t sc[34][68];
     __shared__ int s_hist[256];
     __shared__ uint32_t s_list[512];
     __shared__ uint16_t s_surv[34 * 66], s_quick[34 * 66];
@@ -256,24 +273,54 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P, const FrameSlot* __restr
     // score-tile position (r, c) is pixel (tx0 - 1 + c, ty0 - 1 + r) = LDS (r + 3, c + 6).
     // First the two axis pairs on every position (five pixels), the few positions that pass into a
     // list; then the eight-pair necessary test on that list, its survivors into a second list ...
-    for (int i0 = 0; i0 < 34 * 66; i0 += 256) {
-        const int i = i0 + tid;
-        bool quick = false;
+    // A thread takes four neighbouring positions of a row at a time: their centres, the pixels three
+    // rows above and below and three columns to the left and right are five words cut out of aligned
+    // LDS words, and the test runs on 16-bit halves, two positions per operation:
+    //   max(v - p, v - q) >  t  <=>  (min(p, q) + t) - v < 0
+    //   min(v - p, v - q) < -t  <=>  (v + t) - max(p, q) < 0        (differences of at most 275: no wrap)
+    for (int g0 = 0; g0 < 34 * 17; g0 += 256) {
+        const int gi = g0 + tid;
+        uint32_t flags = 0;
         int r = 0, c = 0;
-        if (i < 34 * 66) {
-            r = i / 66, c = i % 66;
-            sc[r][c] = 0;
-            const int v = s[r + 3][c + 6];
-            const int d0 = v - s[r + 6][c + 6], d8 = v - s[r][c + 6];
-            const int d4 = v - s[r + 3][c + 9], d12 = v - s[r + 3][c + 3];
-            quick = (max(d0, d8) > FAST_T || min(d0, d8) < -FAST_T) && (max(d4, d12) > FAST_T || min(d4, d12) < -FAST_T);
+        if (gi < 34 * 17) {
+            r = gi / 17, c = 4 * (gi % 17);
+            *reinterpret_cast<uint32_t*>(&sc[r][c]) = 0;
+            const uint32_t* mid = reinterpret_cast<const uint32_t*>(&s[r + 3][c]);  // columns c .. c + 15
+            const uint32_t* top = reinterpret_cast<const uint32_t*>(&s[r][c + 4]);  // columns c + 4 .. c + 11
+            const uint32_t* bot = reinterpret_cast<const uint32_t*>(&s[r + 6][c + 4]);
+            const uint32_t m0 = mid[0], m1 = mid[1], m2 = mid[2], m3 = mid[3];
+            const uint32_t t0 = top[0], t1 = top[1], b0 = bot[0], b1 = bot[1];
+            // byte selects: the pixels of positions c, c + 2 (even) and c + 1, c + 3 (odd) as 16-bit halves.
+            // perm(hi, lo, sel) picks bytes 0..3 of lo, 4..7 of hi, 0x0c = zero.
+            // centres: columns c + 6 .. c + 9 of (m2:m1) = bytes 2 .. 5
+            const uint32_t Ve = __builtin_amdgcn_perm(m2, m1, 0x0c040c02u), Vo = __builtin_amdgcn_perm(m2, m1, 0x0c050c03u);
+            // left: columns c + 3 .. c + 6 of (m1:m0) = bytes 3 .. 6; right: c + 9 .. c + 12 of (m3:m2) = bytes 1 .. 4
+            const uint32_t Le = __builtin_amdgcn_perm(m1, m0, 0x0c050c03u), Lo = __builtin_amdgcn_perm(m1, m0, 0x0c060c04u);
+            const uint32_t Re = __builtin_amdgcn_perm(m3, m2, 0x0c030c01u), Ro = __builtin_amdgcn_perm(m3, m2, 0x0c040c02u);
+            // above and below: columns c + 6 .. c + 9 of (t1:t0) = bytes 2 .. 5
+            const uint32_t Te = __builtin_amdgcn_perm(t1, t0, 0x0c040c02u), To = __builtin_amdgcn_perm(t1, t0, 0x0c050c03u);
+            const uint32_t Be = __builtin_amdgcn_perm(b1, b0, 0x0c040c02u), Bo = __builtin_amdgcn_perm(b1, b0, 0x0c050c03u);
+            const uint32_t fe = quick_pair(Ve, Te, Be, Le, Re);
+            const uint32_t fo = quick_pair(Vo, To, Bo, Lo, Ro);
+            // positions c, c + 2 in the halves of fe, c + 1, c + 3 in those of fo
+            flags = ((fe >> 15) & 1u) | ((fo >> 14) & 2u) | ((fe >> 29) & 4u) | ((fo >> 28) & 8u);
+            if (c == 64) flags &= 3u;  // the score tile is 66 positions wide
         }
-        const unsigned long long m = __ballot(quick);
-        if (m) {
+        // place in the list (its order does not matter): per position of the group, the lanes before
+        // this one that pass; waves in the order they arrive
+        const unsigned long long q0 = __ballot(flags & 1u), q1 = __ballot(flags & 2u), q2 = __ballot(flags & 4u),
+                                 q3 = __ballot(flags & 8u);
+        const int c0 = __popcll(q0), c1 = __popcll(q1), c2 = __popcll(q2), total = c0 + c1 + c2 + __popcll(q3);
+        if (total) {
             int base = 0;
-            if ((tid & 63) == 0) base = atomicAdd(&s_nquick, __popcll(m));
-            base = __shfl(base, 0);
-            if (quick) s_quick[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)(r * 68 + c);
+            if ((tid & 63) == 0) base = atomicAdd(&s_nquick, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+            const uint16_t pos = (uint16_t)(r * 68 + c);
+            if (flags & 1u) s_quick[base + __popcll(q0 & below)] = pos;
+            if (flags & 2u) s_quick[base + c0 + __popcll(q1 & below)] = (uint16_t)(pos + 1);
+            if (flags & 4u) s_quick[base + c0 + c1 + __popcll(q2 & below)] = (uint16_t)(pos + 2);
+            if (flags & 8u) s_quick[base + c0 + c1 + c2 + __popcll(q3 & below)] = (uint16_t)(pos + 3);
         }
     }
     __syncthreads();
@@ -302,19 +349,19 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P, const FrameSlot* __restr
         sc[r][c] = (uint8_t)fast_score_at<80>(s, r + 3, c + 6);
     }
     __syncthreads();
-    const int cx = tid & 63, x = tx0 + cx;
-    if (x < W - EDGE) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int cy = (tid >> 6) + 4 * k, y = ty0 + cy;
-            if (y >= H - EDGE) break;
-            const int v = sc[cy + 1][cx + 1];
-            if (v && v > sc[cy][cx] && v > sc[cy][cx + 1] && v > sc[cy][cx + 2] && v > sc[cy + 1][cx] &&
-                v > sc[cy + 1][cx + 2] && v > sc[cy + 2][cx] && v > sc[cy + 2][cx + 1] && v > sc[cy + 2][cx + 2]) {
-                const int pos = atomicAdd(&s_cnt, 1);
-                s_list[pos] = ((uint32_t)v << 24) | ((uint32_t)y << 12) | (uint32_t)x;
-                atomicAdd(&s_hist[v], 1);
-            }
+    // only a survivor can be a maximum: the 3x3 test runs on the list (positions of the tile proper,
+    // inside the level's border), all eight neighbours read at once
+    for (int i = tid; i < nsurv; i += 256) {
+        const int pos = s_surv[i], r = pos / 68, c = pos % 68;
+        const int x = tx0 + c - 1, y = ty0 + r - 1;
+        if (r < 1 || r > 32 || c < 1 || c > 64 || x >= W - EDGE || y >= H - EDGE) continue;
+        const int v = sc[r][c];
+        const int n0 = sc[r - 1][c - 1], n1 = sc[r - 1][c], n2 = sc[r - 1][c + 1], n3 = sc[r][c - 1];
+        const int n4 = sc[r][c + 1], n5 = sc[r + 1][c - 1], n6 = sc[r + 1][c], n7 = sc[r + 1][c + 1];
+        if (v && v > max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)))) {
+            const int at = atomicAdd(&s_cnt, 1);
+            s_list[at] = ((uint32_t)v << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+            atomicAdd(&s_hist[v], 1);
         }
     }
     __syncthreads();
@@ -530,7 +577,7 @@ __global__ __launch_bounds__(256) void k_blur7(OrbDev P, const FrameSlot* __rest
         for (int o = 0; o < 4; o++) {
             a[o] = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) a[o] += (uint32_t)P.gk7[k] * px[o + 1 + k];
+            for (int k = 0; k < 7; k++) a[o] += __umul24((uint32_t)P.gk7[k], px[o + 1 + k]);  // 9 x 8 bits
         }
         r[rr][2 * g] = a[0] | (a[1] << 16);
         r[rr][2 * g + 1] = a[2] | (a[3] << 16);
@@ -550,8 +597,8 @@ __global__ __launch_bounds__(256) void k_blur7(OrbDev P, const FrameSlot* __rest
         uint32_t a0 = 0, a1 = 0;
 #pragma unroll
         for (int k = 0; k < 7; k++) {
-            a0 += (uint32_t)P.gk7[k] * (v[i + k] & 0xFFFFu);
-            a1 += (uint32_t)P.gk7[k] * (v[i + k] >> 16);
+            a0 += __umul24((uint32_t)P.gk7[k], v[i + k] & 0xFFFFu);  // 9 x 16 bits
+            a1 += __umul24((uint32_t)P.gk7[k], v[i + k] >> 16);
         }
         uint32_t q0 = a0 >> 16, q1 = a1 >> 16;
         const uint32_t m0 = a0 & 0xFFFFu, m1 = a1 & 0xFFFFu;

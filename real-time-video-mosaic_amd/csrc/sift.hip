@@ -128,8 +128,10 @@ __global__ __launch_bounds__(256) void k_sift_base(const SiftFrame* __restrict__
 #pragma unroll
         for (int b = 0; b < 3; b++) {
             const int xx = min(max(i - 1 + b, 0), w - 1);
-            const auto p = bgr + ((size_t)yy * w + xx) * 3;
-            G[a][b] = (float)((p[0] * gc.cb + p[1] * gc.cg + p[2] * gc.cr + (1 << (gc.shift - 1))) >> gc.shift);
+            // offsets in 32 bits and 24-bit multiplies (full rate): rows, widths and coefficients are below 2^24
+            const auto p = bgr + (__umul24((uint32_t)yy, (uint32_t)w) + (uint32_t)xx) * 3u;
+            G[a][b] = (float)((__umul24(p[0], (uint32_t)gc.cb) + __umul24(p[1], (uint32_t)gc.cg) + __umul24(p[2], (uint32_t)gc.cr) +
+                               (1u << (gc.shift - 1))) >> gc.shift);
         }
     }
     // weights of the left / upper source pixel (a0, b0) and of the other one (a1 = fx, a0 = 1 - fx)

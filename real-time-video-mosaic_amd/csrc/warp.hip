@@ -15,12 +15,14 @@
 
 namespace {
 
-// BORDER_REFLECT_101 index, without a loop: fold |p| into one period 2n-2 of the mirror.
+// BORDER_REFLECT_101 index: fold |p| into one period 2n-2 of the mirror.  The subtraction loop runs
+// only for an image narrower than the filter's reach (a modulo here would be evaluated, at a quarter
+// of the multiply rate, for every index).
 __device__ __forceinline__ int reflect101(int p, int n) {
     if (n == 1) return 0;
     const int period = 2 * n - 2;
     p = p < 0 ? -p : p;
-    if (p >= period) p %= period;
+    while (p >= period) p -= period;
     return p < n ? p : period - p;
 }
 
@@ -196,9 +198,11 @@ __device__ __forceinline__ void taps4(const uint8_t* __restrict__ src, int fh, i
     const bool vy0 = (unsigned)iy < (unsigned)fh, vy1 = (unsigned)(iy + 1) < (unsigned)fh;
     const int xlo = min(max(ix, 0), fw - 2);  // column of the first of the six bytes
     const int y0 = min(max(iy, 0), fh - 1), y1 = min(max(iy + 1, 0), fh - 1);
-    const size_t last = (size_t)fh * fw * 3 - 8;
-    const size_t a0 = ((size_t)y0 * fw + xlo) * 3, a1 = ((size_t)y1 * fw + xlo) * 3;
-    const size_t b0 = min(a0, last), b1 = min(a1, last);
+    // byte offsets in 32 bits (a frame is far below 4 GB), rows and widths below 2^24: full-rate multiplies
+    const uint32_t last = (uint32_t)fh * (uint32_t)fw * 3u - 8u;
+    const uint32_t a0 = (__umul24((uint32_t)y0, (uint32_t)fw) + (uint32_t)xlo) * 3u;
+    const uint32_t a1 = (__umul24((uint32_t)y1, (uint32_t)fw) + (uint32_t)xlo) * 3u;
+    const uint32_t b0 = min(a0, last), b1 = min(a1, last);
     uint64_t r0, r1;
     __builtin_memcpy(&r0, src + b0, 8);
     __builtin_memcpy(&r1, src + b1, 8);
@@ -360,9 +364,14 @@ __global__ __launch_bounds__(256) void k_pred_bits(const uint32_t* __restrict__ 
 // window of 34 staged pairs; a workgroup takes 4 rows; blockIdx.z = frame of the batch.
 // outputs per lane in the row pass of the blur: a wave takes BR_TILE consecutive pixels of a row
 constexpr int BR_OUT = 4, BR_TILE = 64 * BR_OUT, BR_STAGE = BR_TILE + 32, BR_LOADS = (BR_TILE + 30 + 63) / 64;
+// The staged pairs are read back as 16-byte words at a lane stride of 32 bytes: without padding lanes l
+// and l + 8 of a group of 16 meet in the same four banks while every other group of four banks idles.
+// Two pairs (16 bytes) of padding after every 32 pairs shift lanes 8..15 into the idle banks.
+constexpr int BR_STAGE_PAD = BR_STAGE + 2 * ((BR_STAGE + 31) / 32);
+__device__ __forceinline__ int br_pad(int e) { return e + 2 * (e >> 5); }
 
 __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
-                                               const SideDev& side, int cw, int bx, int by, f32x2 (*s_w)[BR_STAGE]) {
+                                               const SideDev& side, int cw, int bx, int by, f32x2 (*s_w)[BR_STAGE_PAD]) {
     const int rx0 = wp->rx0, rx1 = wp->rx1, wy0 = wp->wy0, wy1 = wp->wy1;
     const auto dn = as_global<const float>(side.dist_new);
     const auto dold = as_global<const float>(side.dist_old);
@@ -395,7 +404,7 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
                 wn = a[q] / sum;
                 wo = b[q] / sum;
             }
-            if (i < BR_STAGE) s_w[wv][i] = f32x2{wn, wo};
+            if (i < BR_STAGE) s_w[wv][br_pad(i)] = f32x2{wn, wo};
         }
     }
     __syncthreads();
@@ -405,7 +414,7 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
     f32x2 v[BR_OUT + 32];
 #pragma unroll
     for (int q = 0; q < (BR_OUT + 32) / 2; q++) {
-        const float4 a = *reinterpret_cast<const float4*>(&s_w[wv][BR_OUT * lane + 2 * q]);
+        const float4 a = *reinterpret_cast<const float4*>(&s_w[wv][br_pad(BR_OUT * lane + 2 * q)]);
         v[2 * q] = f32x2{a.x, a.y};
         v[2 * q + 1] = f32x2{a.z, a.w};
     }
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
                                                    const SideDev* __restrict__ sides, int cw) {
     const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const SideDev side = sides[blockIdx.z];
-    __shared__ __align__(16) f32x2 s_w[4][BR_STAGE];
+    __shared__ __align__(16) f32x2 s_w[4][BR_STAGE_PAD];
     const int rx1 = wp->rx1, wy1 = wp->wy1;
     const int ox = wp->rx0 & ~3, oy = wp->wy0;
     const int ntx = rx1 > ox ? (rx1 - ox + BR_TILE - 1) / BR_TILE : 0, nty = wy1 > oy ? (wy1 - oy + 3) / 4 : 0;
