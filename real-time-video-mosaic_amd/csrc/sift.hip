@@ -230,6 +230,37 @@ __global__ __launch_bounds__(256) void k_sift_blur_cols(const SiftFrame* __restr
         (y >= half && y + half < h) ? col_taps(t, src + (size_t)y * w + x, w) : col_taps_border(t, src + x, y, h, w);
 }
 
+// 16-byte LDS reads by hand.  lds_offset: the LDS address of a __shared__ object (the low half of
+// its generic address); lds_read16: ds_read_b128 at addr + OFF, the result is valid after lds_wait on
+// the registers it went to (the compiler does not track reads it did not issue itself).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_offset(const void* p) { return (uint32_t)(uintptr_t)p; }
+__device__ __forceinline__ f32x4 lds_read16(uint32_t addr, int off) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off) : "memory");
+    return v;
+}
+template <int K>
+__device__ __forceinline__ void lds_wait(f32x4 (&u)[K]) {
+    static_assert(K >= 1 && K <= 12, "one operand per register group");
+    // every register group is an in/out operand, so that no use of it can move above the wait
+    if constexpr (K == 5)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4])::"memory");
+    else if constexpr (K == 6)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5])::"memory");
+    else if constexpr (K == 7)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6])::"memory");
+    else if constexpr (K == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7])::"memory");
+    else if constexpr (K == 9)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]), "+v"(u[8])::"memory");
+    else
+        static_assert(K == 5, "add the operand list for this window length");
+}
+
 // Both passes of one blur for a tile of SBT_W x SBT_H outputs, compiled per kernel length N (11,
 // 13, 17, 21, 27 for sigma = 1.6 and three layers per octave): the row-passed values of the tile's
 // rows and of the N - 1 rows around them stay in LDS, so the plane between the passes never
@@ -243,13 +274,23 @@ __global__ __launch_bounds__(256) void k_sift_blur_cols(const SiftFrame* __restr
 //     row-passed values in registers (centre first, then the symmetric pairs outwards) and writes
 //     the layer.
 constexpr int SBT_W = 128, SBT_H = 32, SB_R = 8, SB_C = 16, SBT_STAGE = SBT_W + 32;
+// The row pass reads its windows as 16-byte words at a lane stride of 32 bytes, four rows of 16 lanes
+// per wave.  A 16-byte read is served in four groups of 16 lanes that mix two rows (lanes 0-3, 12-15
+// and 20-27 first): with rows 160 floats apart the lanes of a group meet on the same banks.  A row
+// stride of 164 floats (36 banks on) puts the second row's lanes on the banks the first leaves idle.
+constexpr int SBT_STAGE_PAD = SBT_STAGE + 4;
+__device__ __forceinline__ int sb_pad(int e) { return e; }
+// The row-passed tile is written as 16-byte words at the same lane stride (eight consecutive lanes per
+// group, banks counted modulo 32): columns with bit 5 set keep their two 16-byte words in swapped
+// order (column c lives at c ^ 4 there), which costs no space.
+__device__ __forceinline__ int rp_col(int c) { return c ^ ((c >> 3) & 4); }
 
 template <int N>
 __global__ __launch_bounds__(256) void k_sift_blur(const SiftFrame* __restrict__ F, int src_id, int dst_id, int h, int w, Taps t) {
     constexpr int half = N / 2, RB = SBT_H + N - 1, NIN = SBT_W + N - 1, WIN4 = (SB_R + N - 1 + 3) / 4;
     static_assert(N % 2 == 1 && NIN <= SBT_STAGE && (SBT_W - SB_R) + 4 * WIN4 <= SBT_STAGE, "windows fit the staged row");
     static_assert(SBT_W == 16 * SB_R && SBT_H == 2 * SB_C, "thread mapping of the two passes");
-    __shared__ __align__(16) float s_in[4][4][SBT_STAGE];
+    __shared__ __align__(16) float s_in[4][4][SBT_STAGE_PAD];
     __shared__ __align__(16) float s_rp[RB][SBT_W];
     const SiftFrame& f = F[blockIdx.z];
     const auto src = as_global(plane(f, src_id));
@@ -282,7 +323,7 @@ __global__ __launch_bounds__(256) void k_sift_blur(const SiftFrame* __restrict__
 #pragma unroll
             for (int k = 0; k < NK; k++) {
                 const int i = lane + 64 * k;
-                if (i < SBT_STAGE) s_in[wv][qq][i] = pre[qq][k];
+                if (i < SBT_STAGE) s_in[wv][qq][sb_pad(i)] = pre[qq][k];
             }
         }
         if (rb + 16 < RB) request(rb + 16);
@@ -291,12 +332,16 @@ __global__ __launch_bounds__(256) void k_sift_blur(const SiftFrame* __restrict__
         __builtin_amdgcn_wave_barrier();
         const int r = rb + q;
         if (r < RB) {
+            // the window as WIN4 16-byte reads, spelled out: left to itself the compiler cuts the window
+            // into some forty 4- and 8-byte reads (half the LDS rate, banks counted modulo 32)
+            f32x4 u[WIN4];
+            const uint32_t wa = lds_offset(&s_in[wv][q][sb_pad(seg * SB_R)]);
+#pragma unroll
+            for (int i = 0; i < WIN4; i++) u[i] = lds_read16(wa, 16 * i);
+            lds_wait(u);
             float v[4 * WIN4];
 #pragma unroll
-            for (int i = 0; i < WIN4; i++) {
-                const float4 u = *reinterpret_cast<const float4*>(&s_in[wv][q][seg * SB_R + 4 * i]);
-                v[4 * i] = u.x, v[4 * i + 1] = u.y, v[4 * i + 2] = u.z, v[4 * i + 3] = u.w;
-            }
+            for (int i = 0; i < WIN4; i++) v[4 * i] = u[i].x, v[4 * i + 1] = u[i].y, v[4 * i + 2] = u[i].z, v[4 * i + 3] = u[i].w;
             float a[SB_R];
 #pragma unroll
             for (int o = 0; o < SB_R; o++) a[o] = t.k[0] * v[o];
@@ -305,8 +350,8 @@ __global__ __launch_bounds__(256) void k_sift_blur(const SiftFrame* __restrict__
 #pragma unroll
                 for (int o = 0; o < SB_R; o++) a[o] = __builtin_fmaf(v[o + k], t.k[k], a[o]);
             }
-            *reinterpret_cast<float4*>(&s_rp[r][seg * SB_R]) = make_float4(a[0], a[1], a[2], a[3]);
-            *reinterpret_cast<float4*>(&s_rp[r][seg * SB_R + 4]) = make_float4(a[4], a[5], a[6], a[7]);
+            *reinterpret_cast<float4*>(&s_rp[r][rp_col(seg * SB_R)]) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float4*>(&s_rp[r][rp_col(seg * SB_R + 4)]) = make_float4(a[4], a[5], a[6], a[7]);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -317,7 +362,7 @@ __global__ __launch_bounds__(256) void k_sift_blur(const SiftFrame* __restrict__
     if (x >= w || yo >= h) return;
     float v[SB_C + N - 1];
 #pragma unroll
-    for (int i = 0; i < SB_C + N - 1; i++) v[i] = s_rp[ry + i][cx];
+    for (int i = 0; i < SB_C + N - 1; i++) v[i] = s_rp[ry + i][rp_col(cx)];
     float a[SB_C];
 #pragma unroll
     for (int o = 0; o < SB_C; o++) a[o] = t.c[0] * v[o + half];

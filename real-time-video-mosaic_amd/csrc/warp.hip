@@ -364,11 +364,13 @@ __global__ __launch_bounds__(256) void k_pred_bits(const uint32_t* __restrict__ 
 // window of 34 staged pairs; a workgroup takes 4 rows; blockIdx.z = frame of the batch.
 // outputs per lane in the row pass of the blur: a wave takes BR_TILE consecutive pixels of a row
 constexpr int BR_OUT = 4, BR_TILE = 64 * BR_OUT, BR_STAGE = BR_TILE + 32, BR_LOADS = (BR_TILE + 30 + 63) / 64;
-// The staged pairs are read back as 16-byte words at a lane stride of 32 bytes: without padding lanes l
-// and l + 8 of a group of 16 meet in the same four banks while every other group of four banks idles.
-// Two pairs (16 bytes) of padding after every 32 pairs shift lanes 8..15 into the idle banks.
-constexpr int BR_STAGE_PAD = BR_STAGE + 2 * ((BR_STAGE + 31) / 32);
-__device__ __forceinline__ int br_pad(int e) { return e + 2 * (e >> 5); }
+// The staged pairs are read back as 16-byte words at a lane stride of 32 bytes (four pairs).  A 16-byte
+// read is served in four groups of 16 lanes (lanes 0-3, 12-15 and 20-27 first), 64 banks of four
+// bytes: in pair order the lanes of a group meet two by two on the same banks.  Pairs whose index has
+// bit 5 set keep their two 16-byte words in swapped order (pair e lives at e ^ 2 there): every group
+// then covers all banks once.
+constexpr int BR_STAGE_PAD = BR_STAGE;
+__device__ __forceinline__ int br_pad(int e) { return e ^ ((e >> 4) & 2); }
 
 __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
                                                const SideDev& side, int cw, int bx, int by, f32x2 (*s_w)[BR_STAGE_PAD]) {
