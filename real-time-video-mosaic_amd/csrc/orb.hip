@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void k_blur7(OrbDev P, const FrameSlot* __rest
     const uint8_t* __restrict__ img = pyr + P.off[l];
     // pixels: rows ty0-3 .. ty0+34, columns tx0-4 .. tx0+67 (LDS column = x - tx0 + 4)
     __shared__ __align__(16) uint8_t s[38][72];
-    __shared__ uint32_t r[38][32];
+    __shared__ __align__(16) uint32_t r[19][64];
     const int tid = threadIdx.x;
     if (tx0 >= 4 && tx0 + 68 <= W && ty0 >= 3 && ty0 + 35 <= H) {
         for (int i = tid; i < 38 * 18; i += 256) {
@@ -559,57 +559,74 @@ __global__ __launch_bounds__(256) void k_blur7(OrbDev P, const FrameSlot* __rest
         }
     }
     __syncthreads();
-    // row pass: 4 consecutive outputs per task from 12 staged bytes (3 aligned words);
-    // the sums fit 16 bits (the taps add up to 257: at most 65535) and are stored two per word
-    for (int i = tid; i < 38 * 16; i += 256) {
-        const int rr = i >> 4, g = i & 15;
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(&s[rr][4 * g]);
-        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-        uint32_t px[12];
+    // The sums are dot products of byte and 16-bit vectors (exact in 32 bits):
+    //   row pass   7 taps on 7 consecutive bytes = two v_dot4_u32_u8 (the eighth tap is zero); a task takes
+    //              4 outputs of 2 rows from 12 staged bytes per row and stores, per column, the pair
+    //              {row 2p, row 2p + 1} of row sums as one word (a row sum is at most 255 * 257 = 65535)
+    //   column pass  7 taps on 7 consecutive rows = four v_dot2_u32_u16 on four such pairs (again with a zero
+    //              tap: at the end for an even output row, in front for an odd one); a thread takes 4 columns
+    //              x 2 rows from four 16-byte reads and stores one word per row
+    const uint32_t k0 = P.gk7[0], k1 = P.gk7[1], k2 = P.gk7[2], k3 = P.gk7[3], k4 = P.gk7[4], k5 = P.gk7[5], k6 = P.gk7[6];
+    const uint32_t tlo = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), thi = k4 | (k5 << 8) | (k6 << 16);
+    for (int i = tid; i < 19 * 16; i += 256) {
+        const int pr = i >> 4, g = i & 15;
+        uint32_t a[2][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            px[k] = (w0 >> (8 * k)) & 255u;
-            px[4 + k] = (w1 >> (8 * k)) & 255u;
-            px[8 + k] = (w2 >> (8 * k)) & 255u;
+        for (int h = 0; h < 2; h++) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&s[2 * pr + h][4 * g]);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            // output o: bytes o + 1 .. o + 7 of the twelve
+            a[h][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), thi,
+                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), tlo, 0u, false), false);
+            a[h][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), thi,
+                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), tlo, 0u, false), false);
+            a[h][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), thi,
+                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), tlo, 0u, false), false);
+            a[h][3] = __builtin_amdgcn_udot4(w2, thi, __builtin_amdgcn_udot4(w1, tlo, 0u, false), false);
         }
-        uint32_t a[4];
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            a[o] = 0;
-#pragma unroll
-            for (int k = 0; k < 7; k++) a[o] += __umul24((uint32_t)P.gk7[k], px[o + 1 + k]);  // 9 x 8 bits
-        }
-        r[rr][2 * g] = a[0] | (a[1] << 16);
-        r[rr][2 * g + 1] = a[2] | (a[3] << 16);
+        *reinterpret_cast<uint4*>(&r[pr][4 * g]) = make_uint4(a[0][0] | (a[1][0] << 16), a[0][1] | (a[1][1] << 16),
+                                                              a[0][2] | (a[1][2] << 16), a[0][3] | (a[1][3] << 16));
     }
     __syncthreads();
-    // column pass: 2 adjacent columns x 4 rows per thread from 10 packed words
-    const int cp = tid & 31, rg = tid >> 5;
-    const int x = tx0 + 2 * cp;
-    if (x >= W) return;
-    uint32_t v[10];
+    const int cg = tid & 15, q = tid >> 4;
+    const int x = tx0 + 4 * cg, y = ty0 + 2 * q;
+    if (x >= W || y >= H) return;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    // output row 2q: rows 2q .. 2q + 6 of the tile's 38; output row 2q + 1: rows 2q + 1 .. 2q + 7
+    const us2 e0 = {(unsigned short)k0, (unsigned short)k1}, e1 = {(unsigned short)k2, (unsigned short)k3},
+              e2 = {(unsigned short)k4, (unsigned short)k5}, e3 = {(unsigned short)k6, 0};
+    const us2 o0 = {0, (unsigned short)k0}, o1 = {(unsigned short)k1, (unsigned short)k2},
+              o2 = {(unsigned short)k3, (unsigned short)k4}, o3 = {(unsigned short)k5, (unsigned short)k6};
+    uint32_t v[4][4];
 #pragma unroll
-    for (int j = 0; j < 10; j++) v[j] = r[4 * rg + j][cp];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int y = ty0 + 4 * rg + i;
-        if (y >= H) break;
-        uint32_t a0 = 0, a1 = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-            a0 += __umul24((uint32_t)P.gk7[k], v[i + k] & 0xFFFFu);  // 9 x 16 bits
-            a1 += __umul24((uint32_t)P.gk7[k], v[i + k] >> 16);
-        }
-        uint32_t q0 = a0 >> 16, q1 = a1 >> 16;
-        const uint32_t m0 = a0 & 0xFFFFu, m1 = a1 & 0xFFFFu;
-        if (m0 > 32768u || (m0 == 32768u && (q0 & 1u))) q0++;
-        if (m1 > 32768u || (m1 == 32768u && (q1 & 1u))) q1++;
-        q0 = q0 > 255u ? 255u : q0;
-        q1 = q1 > 255u ? 255u : q1;
-        // x is even and the pitch a multiple of 64: the pair is 2-byte aligned; a column past
-        // the level's width lands in the row padding
-        *reinterpret_cast<uint16_t*>(out + P.off[l] + (size_t)y * pitch + x) = (uint16_t)(q0 | (q1 << 8));
+    for (int j = 0; j < 4; j++) {
+        const uint4 u = *reinterpret_cast<const uint4*>(&r[q + j][4 * cg]);
+        v[j][0] = u.x, v[j][1] = u.y, v[j][2] = u.z, v[j][3] = u.w;
     }
+    uint32_t oute = 0, outo = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const us2 p0 = __builtin_bit_cast(us2, v[0][c]), p1 = __builtin_bit_cast(us2, v[1][c]),
+                  p2 = __builtin_bit_cast(us2, v[2][c]), p3 = __builtin_bit_cast(us2, v[3][c]);
+        uint32_t ae = __builtin_amdgcn_udot2(p0, e0, 0u, false);
+        ae = __builtin_amdgcn_udot2(p1, e1, ae, false);
+        ae = __builtin_amdgcn_udot2(p2, e2, ae, false);
+        ae = __builtin_amdgcn_udot2(p3, e3, ae, false);
+        uint32_t ao = __builtin_amdgcn_udot2(p0, o0, 0u, false);
+        ao = __builtin_amdgcn_udot2(p1, o1, ao, false);
+        ao = __builtin_amdgcn_udot2(p2, o2, ao, false);
+        ao = __builtin_amdgcn_udot2(p3, o3, ao, false);
+        // sum / 65536 rounded half to even, saturated
+        const uint32_t qe = min((ae + 0x7FFFu + ((ae >> 16) & 1u)) >> 16, 255u);
+        const uint32_t qo = min((ao + 0x7FFFu + ((ao >> 16) & 1u)) >> 16, 255u);
+        oute |= qe << (8 * c);
+        outo |= qo << (8 * c);
+    }
+    // x is a multiple of 4 and the pitch a multiple of 64: aligned words; columns past the level's width
+    // land in the row padding
+    uint8_t* op = out + P.off[l] + (size_t)y * pitch + x;
+    *reinterpret_cast<uint32_t*>(op) = oute;
+    if (y + 1 < H) *reinterpret_cast<uint32_t*>(op + pitch) = outo;
 }
 
 // ------------------------------------------------------------------ describe
