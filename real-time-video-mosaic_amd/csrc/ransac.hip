@@ -99,7 +99,7 @@ __device__ __forceinline__ void first_max_step(double& val, int& bi) {
 // eigenvectors; W: eigenvalues, descending).  The pivot choice, the rotation
 // formulas and the bookkeeping of the per-row / per-column maxima follow the
 // sequential algorithm exactly; lanes only share out independent element updates.
-__device__ void jacobi_wave(double* A, double* W, double* V, int* indR, int* indC, int* perm, int n) {
+__device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int* indR, int* indC, int* perm, int n) {
     const int lane = threadIdx.x & 63;
     const double eps = DBL_EPSILON;
     for (int e = lane; e < n * n; e += 64) V[e] = (e / n == e % n) ? 1. : 0.;
@@ -211,26 +211,37 @@ __device__ void jacobi_wave(double* A, double* W, double* V, int* indR, int* ind
             __syncthreads();
         }
     __syncthreads();
-    // selection sort (descending) with row swaps: lane 0 finds the permutation,
-    // every lane then moves its share of V through registers
-    if (lane == 0) {
-        double w[9];
-        int pr[9];
-        for (int i = 0; i < n; i++) w[i] = W[i], pr[i] = i;
-        for (int k = 0; k < n - 1; k++) {
-            int m = k;
-            for (int i = k + 1; i < n; i++)
-                if (w[m] < w[i]) m = i;
-            if (k != m) {
-                const double tw = w[m];
-                w[m] = w[k];
-                w[k] = tw;
-                const int tp = pr[m];
-                pr[m] = pr[k];
-                pr[k] = tp;
-            }
+    // selection sort (descending) with row swaps: the permutation is found with compile-time indices
+    // only (values and positions stay in registers; arrays indexed at run time would live in scratch
+    // memory, a chain of dependent loads and stores), by every lane alike; every lane then moves its
+    // share of V through registers
+    {
+        constexpr int NM = 9;
+        double w[NM];
+        int pr[NM];
+#pragma unroll
+        for (int i = 0; i < NM; i++) w[i] = i < n ? W[i] : 0., pr[i] = i;
+#pragma unroll
+        for (int k = 0; k < NM - 1; k++) {
+            if (k >= n - 1) break;
+            // first largest of w[k..n-1]
+            double wm = w[k];
+            int m = k, pm = pr[k];
+#pragma unroll
+            for (int i = k + 1; i < NM; i++)
+                if (i < n && wm < w[i]) wm = w[i], m = i, pm = pr[i];
+            // swap positions k and m
+#pragma unroll
+            for (int i = k + 1; i < NM; i++)
+                if (i == m) w[i] = w[k], pr[i] = pr[k];
+            w[k] = wm;
+            pr[k] = pm;
         }
-        for (int i = 0; i < n; i++) W[i] = w[i], perm[i] = pr[i];
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NM; i++)
+                if (i < n) W[i] = w[i], perm[i] = pr[i];
+        }
     }
     __syncthreads();
     double v0 = 0, v1 = 0;
