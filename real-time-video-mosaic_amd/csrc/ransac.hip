@@ -74,12 +74,25 @@ __device__ __forceinline__ double row_shr_f64(double v, double fill) {
     const int hi = row_shr_i32<N>(__double2hiint(v), __double2hiint(fill));
     return __hiloint2double(hi, lo);
 }
-// largest value of lanes 0..15, the same in every lane of the wave (values >= 0 or -1)
+// v_max_f64 as it is (fmax() spends two more of them on quieting signalling NaNs first)
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// the same shift with +0.0 for lanes without a source (no registers to preset)
+template <int N>
+__device__ __forceinline__ double row_shr_f64_zero(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + N, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + N, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// largest value of lanes 0..15, the same in every lane of the wave (values >= 0 or -1, at least one >= 0)
 __device__ __forceinline__ double row0_max(double v) {
-    v = fmax(v, row_shr_f64<1>(v, -1.));
-    v = fmax(v, row_shr_f64<2>(v, -1.));
-    v = fmax(v, row_shr_f64<4>(v, -1.));
-    v = fmax(v, row_shr_f64<8>(v, -1.));
+    v = max_f64(v, row_shr_f64_zero<1>(v));
+    v = max_f64(v, row_shr_f64_zero<2>(v));
+    v = max_f64(v, row_shr_f64_zero<4>(v));
+    v = max_f64(v, row_shr_f64_zero<8>(v));
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 15), hi = __builtin_amdgcn_readlane(__double2hiint(v), 15);
     return __hiloint2double(hi, lo);
 }
@@ -91,7 +104,11 @@ template <int N>
 __device__ __forceinline__ void first_max_step(double& val, int& bi) {
     const double ov = row_shr_f64<N>(val, -2.);
     const int oi = row_shr_i32<N>(bi, 1 << 20);
-    if (ov > val || (ov == val && oi < bi)) val = ov, bi = oi;
+    // as selects on the register halves (a branch here costs more than the three moves it would skip)
+    const bool take = (ov > val) | ((ov == val) & (oi < bi));
+    const int lo = take ? __double2loint(ov) : __double2loint(val), hi = take ? __double2hiint(ov) : __double2hiint(val);
+    val = __hiloint2double(hi, lo);
+    bi = take ? oi : bi;
 }
 
 // cv::JacobiImpl_<double> executed by one full wave on LDS-resident matrices
@@ -467,7 +484,10 @@ __global__ __launch_bounds__(64) void k_rs_subsets(const FrameSlot* __restrict__
     }
 }
 
-// One wave per hypothesis: solve the 4-point homography, count the inliers.
+// One wave per hypothesis: solve the 4-point homography, count the inliers.  Workgroup x of a problem
+// takes iterations h0 + x, h0 + x + gridDim.x, ... below h1 and below the problem's budget: a late stage,
+// whose budget has almost always dropped below h0 already, is a small grid that exits at once instead of
+// one workgroup for every iteration it might have had to run.
 __global__ __launch_bounds__(64) void k_rs_hyp(const FrameSlot* __restrict__ slots, int sb, int h0, int h1,
                                                float thr) {
     const FrameSlot& S = slots[sb + blockIdx.y];
@@ -478,38 +498,40 @@ __global__ __launch_bounds__(64) void k_rs_hyp(const FrameSlot* __restrict__ slo
     const int* __restrict__ idx = S.rs_idx;
     int* __restrict__ good = S.rs_good;
     double* __restrict__ hypH = S.rs_hypH;
-    const int h = h0 + blockIdx.x;
     const int count = *count_p;
-    if (h >= h1 || count <= 4 || st->done) return;
-    if (st->fail_at >= 0 && h >= st->fail_at) return;
-    if (h >= st->niters) return;
+    if (count <= 4 || st->done) return;
+    int hend = min(h1, st->niters);
+    if (st->fail_at >= 0) hend = min(hend, st->fail_at);
     __shared__ JacobiLds L;
     __shared__ float ms1[8], ms2[8];
     const int lane = threadIdx.x;
-    if (lane < 4) {
-        const int v = idx[4 * h + lane];
-        ms1[2 * lane] = src[2 * v];
-        ms1[2 * lane + 1] = src[2 * v + 1];
-        ms2[2 * lane] = dst[2 * v];
-        ms2[2 * lane + 1] = dst[2 * v + 1];
+    for (int h = h0 + blockIdx.x; h < hend; h += gridDim.x) {
+        __syncthreads();  // the points of the iteration before are no longer read
+        if (lane < 4) {
+            const int v = idx[4 * h + lane];
+            ms1[2 * lane] = src[2 * v];
+            ms1[2 * lane + 1] = src[2 * v + 1];
+            ms2[2 * lane] = dst[2 * v];
+            ms2[2 * lane + 1] = dst[2 * v + 1];
+        }
+        __syncthreads();
+        double H[9];
+        if (!run_kernel_wave(ms1, ms2, 4, &L, H)) {
+            if (lane == 0) good[h] = -1;
+            continue;
+        }
+        float Hf[8];
+        for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
+        int g = 0;
+        for (int i0 = 0; i0 < count; i0 += 64) {
+            const int i = i0 + lane;
+            bool in = false;
+            if (i < count) in = is_inlier(Hf, src[2 * i], src[2 * i + 1], dst[2 * i], dst[2 * i + 1], thr);
+            g += __popcll(__ballot(in));
+        }
+        if (lane == 0) good[h] = g;
+        if (lane < 9) hypH[9 * h + lane] = H[lane];
     }
-    __syncthreads();
-    double H[9];
-    if (!run_kernel_wave(ms1, ms2, 4, &L, H)) {
-        if (lane == 0) good[h] = -1;
-        return;
-    }
-    float Hf[8];
-    for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
-    int g = 0;
-    for (int i0 = 0; i0 < count; i0 += 64) {
-        const int i = i0 + lane;
-        bool in = false;
-        if (i < count) in = is_inlier(Hf, src[2 * i], src[2 * i + 1], dst[2 * i], dst[2 * i + 1], thr);
-        g += __popcll(__ballot(in));
-    }
-    if (lane == 0) good[h] = g;
-    if (lane < 9) hypH[9 * h + lane] = H[lane];
 }
 
 __device__ int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
@@ -834,7 +856,7 @@ int rtvm_launch_ransac_search(rtvm_ctx* c, int sb, int nb, double thresh, int ma
         if (h1 <= h0) continue;
         RTVM_LAUNCH(c, k_rs_subsets, dim3(nb), dim3(64), 0, sl, sb, c->d_rs_raw, c->rs_raw_n, h0, h1, confidence,
                     max_iters, h0 == 0 ? 1 : 0);
-        RTVM_LAUNCH(c, k_rs_hyp, dim3(h1 - h0, nb), dim3(64), 0, sl, sb, h0, h1, thr);
+        RTVM_LAUNCH(c, k_rs_hyp, dim3(h1 - h0 < 256 ? h1 - h0 : 256, nb), dim3(64), 0, sl, sb, h0, h1, thr);
         RTVM_LAUNCH(c, k_rs_replay, dim3(nb), dim3(64), 0, sl, sb, h0, h1, confidence, h1 >= max_iters ? 1 : 0);
         h0 = h1;
     }

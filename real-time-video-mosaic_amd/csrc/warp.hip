@@ -409,7 +409,10 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
             if (i < BR_STAGE) s_w[wv][br_pad(i)] = f32x2{wn, wo};
         }
     }
-    __syncthreads();
+    // a wave reads back only what it staged itself: LDS keeps a wave's accesses in order, no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!row_ok) return;
     const int x = bx + BR_OUT * lane;
     if (x + BR_OUT <= rx0 || x >= rx1) return;
@@ -459,7 +462,9 @@ __global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict_
     }
     for (int t = blockIdx.x; t < T; t += G) {  // a region larger than the grid was sized for
         blur_rows_tile(wp, gk, side, cw, ox + BR_TILE * (t % ntx), oy + 4 * (t / ntx), s_w);
-        __syncthreads();  // the staging area is reused by the next tile
+        // the wave's staging row is reused by its next tile
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
