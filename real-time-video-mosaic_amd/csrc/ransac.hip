@@ -120,6 +120,11 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
     const int lane = threadIdx.x & 63;
     const double eps = DBL_EPSILON;
     for (int e = lane; e < n * n; e += 64) V[e] = (e / n == e % n) ? 1. : 0.;
+    // One index array for both kinds of maxima, so that the pivot search reads its 2n - 2 candidates
+    // with one address per lane: ind[r] = column of the largest |a| of row r right of the diagonal
+    // (rows 0..n-2), ind[n - 2 + c] = row of the largest |a| of column c above it (columns 1..n-1).
+    int* ind = indR;  // 16 entries are enough for n <= 9
+    (void)indC;
     if (lane < n) {
         const int k = lane;
         W[k] = A[(n + 1) * k];
@@ -130,7 +135,7 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
                 const double val = fabs(A[n * k + i]);
                 if (mv < val) mv = val, m = i;
             }
-            indR[k] = m;
+            ind[k] = m;
         }
         if (k > 0) {
             int m = 0;
@@ -139,24 +144,22 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
                 const double val = fabs(A[n * i + k]);
                 if (mv < val) mv = val, m = i;
             }
-            indC[k] = m;
+            ind[n - 2 + k] = m;
         }
     }
     __syncthreads();
     const int maxIters = n * n * 30;
+    const bool is_row = lane < n - 1, is_cand = lane < 2 * n - 2;
+    const int voff = (int)(V - A);  // V addressed from A: one base for the rotation's loads and stores
     if (n > 1)
         for (int iters = 0; iters < maxIters; iters++) {
-            // pivot: first maximum over rows 0..n-2 (through indR), then columns 1..n-1 (through indC)
+            // pivot: first maximum over rows 0..n-2, then columns 1..n-1
             double val = -1., sval = 0., wck = 0., wcl = 0.;
             int ck = 0, cl = 0;
-            if (lane < n - 1) {
-                ck = lane;
-                cl = indR[lane];
-            } else if (lane < 2 * n - 2) {
-                cl = lane - (n - 1) + 1;
-                ck = indC[cl];
-            }
-            if (lane < 2 * n - 2) {  // the candidate element and the two eigenvalue estimates it would touch
+            if (is_cand) {  // the candidate element and the two eigenvalue estimates it would touch
+                const int ix = ind[lane];
+                ck = is_row ? lane : ix;
+                cl = is_row ? ix : lane - (n - 2);
                 sval = A[n * ck + cl];
                 wck = W[ck];
                 wcl = W[cl];
@@ -168,62 +171,52 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
             const int k = __builtin_amdgcn_readlane(ck, win), l = __builtin_amdgcn_readlane(cl, win);
             const double p = readlane_f64(sval, win);
             if (fabs(p) <= eps) break;
-            const double y = (readlane_f64(wcl, win) - readlane_f64(wck, win)) * 0.5;
+            const double wk = readlane_f64(wck, win), wl = readlane_f64(wcl, win);
+            // lanes 0..n-1 rotate the pair of A that row / column i = lane shares with k and l (none for
+            // i = k, l), lanes 16..16+n-1 the pair of V of column i = lane - 16: one sequence for both.
+            // The pairs are requested now (only k and l are needed to find them) and arrive while the
+            // divisions and square roots of the rotation's coefficients run.
+            const bool isA = lane < n;
+            const int ri = isA ? lane : lane - 16;
+            const bool act = isA ? (ri != k && ri != l) : (lane >= 16 && lane < 16 + n);
+            const int e0 = isA ? (ri < k ? n * ri + k : n * k + ri) : voff + n * k + ri;
+            const int e1 = isA ? (ri < l ? n * ri + l : n * l + ri) : voff + n * l + ri;
+            double a0 = 0, b0 = 0;
+            if (act) a0 = A[e0], b0 = A[e1];
+            const double y = (wl - wk) * 0.5;
             double t = fabs(y) + cv_hypot(p, y);
             double s = cv_hypot(p, t);
             const double c = t / s;
             s = p / s;
             t = (p / t) * p;
             if (y < 0) s = -s, t = -t;
-            __syncthreads();
+            __syncthreads();  // every lane has read its candidate and its pair
             if (lane == 0) {
                 A[n * k + l] = 0;
-                W[k] -= t;
-                W[l] += t;
+                W[k] = wk - t;  // W[k] -= t, W[l] += t on the values the pivot search already holds
+                W[l] = wl + t;
             }
-            if (lane < n) {
-                const int i = lane;
-                if (i != k && i != l) {
-                    double *p0, *p1;
-                    if (i < k) {
-                        p0 = &A[n * i + k];
-                        p1 = &A[n * i + l];
-                    } else if (i < l) {
-                        p0 = &A[n * k + i];
-                        p1 = &A[n * i + l];
-                    } else {
-                        p0 = &A[n * k + i];
-                        p1 = &A[n * l + i];
-                    }
-                    const double a0 = *p0, b0 = *p1;
-                    *p0 = a0 * c - b0 * s;
-                    *p1 = a0 * s + b0 * c;
-                }
-            } else if (lane >= 16 && lane < 16 + n) {
-                const int i = lane - 16;
-                const double a0 = V[n * k + i], b0 = V[n * l + i];
-                V[n * k + i] = a0 * c - b0 * s;
-                V[n * l + i] = a0 * s + b0 * c;
+            if (act) {
+                A[e0] = a0 * c - b0 * s;
+                A[e1] = a0 * s + b0 * c;
             }
             __syncthreads();
-            // indR[k], indC[k], indR[l], indC[l] again: the sequential scans "first largest |a| of row
-            // idx right of the diagonal" / "... of column idx above it", each by one group of 16 lanes
-            // (lane i looks at element i, then a first-maximum reduction inside the group)
+            // the maxima of row k, column k, row l, column l again: the sequential scans "first largest
+            // |a| of row idx right of the diagonal" / "... of column idx above it", each by one group of
+            // 16 lanes (lane i looks at element i, then a first-maximum reduction inside the group)
             {
                 const int g = lane >> 4, i = lane & 15;
                 const int idx = (g & 2) ? l : k;
+                const bool col = (g & 1) != 0;
+                const bool has = col ? (idx > 0 && i < idx) : (idx < n - 1 && i > idx && i < n);
                 double val = -1.;
-                if ((g & 1) == 0) {
-                    if (idx < n - 1 && i > idx && i < n) val = fabs(A[n * idx + i]);
-                } else {
-                    if (idx > 0 && i < idx) val = fabs(A[n * i + idx]);
-                }
+                if (has) val = fabs(A[col ? n * i + idx : n * idx + i]);
                 int bi = i;
                 first_max_step<1>(val, bi);
                 first_max_step<2>(val, bi);
                 first_max_step<4>(val, bi);
                 first_max_step<8>(val, bi);  // lane 15 of the group now holds the group's result
-                if (i == 15 && val >= 0.) ((g & 1) ? indC : indR)[idx] = bi;
+                if (i == 15 && val >= 0.) ind[col ? n - 2 + idx : idx] = bi;
             }
             __syncthreads();
         }
