@@ -36,16 +36,31 @@ struct RsState {
 };
 
 // ------------------------------------------------------------------ helpers
+// sqrt(x) for 1 <= x <= 2: the refinement sqrt() itself runs (reciprocal square root, then
+// Goldschmidt steps and two corrections on fused multiply-adds), without its scaling of very small
+// arguments and its handling of zero, infinity and NaN, none of which 1 + q*q with q <= 1 can be.
+__device__ __forceinline__ double sqrt_1to2(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = r * 0.5;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, e, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
 __device__ __forceinline__ double cv_hypot(double a, double b) {
     a = fabs(a);
     b = fabs(b);
     if (a > b) {
         b /= a;
-        return a * sqrt(1 + b * b);
+        return a * sqrt_1to2(1 + b * b);
     }
     if (b > 0) {
         a /= b;
-        return b * sqrt(1 + a * a);
+        return b * sqrt_1to2(1 + a * a);
     }
     return 0;
 }
