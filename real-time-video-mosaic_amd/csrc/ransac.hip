@@ -598,6 +598,9 @@ struct RefineLds {
     double A[64], Ap[64], v[8], d[8], D[8], x[8], xd[8], diag[8];
 };
 
+// position of JtJ[a][b], a <= b, in the row-major list of the upper triangle of an 8x8
+__device__ constexpr int acc_index(int a, int b) { return a * 8 - a * (a - 1) / 2 + (b - a); }
+
 // residuals at parameters h over the compacted inliers: returns |r|^2; when
 // with_J, also JtJ -> S->A (8x8), Jt r -> S->v, and max |r| -> *rinf
 __device__ double lm_compute_wave(const float* __restrict__ M, const float* __restrict__ m, int count,
@@ -617,15 +620,35 @@ __device__ double lm_compute_wave(const float* __restrict__ M, const float* __re
         ss += ex * ex + ey * ey;
         rmax = fmax(rmax, fmax(fabs(ex), fabs(ey)));
         if (with_J) {
-            const double Jx[8] = {Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi};
-            const double Jy[8] = {0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi};
-            int e = 0;
+            // Jx = {Mx ww, My ww, ww, 0, 0, 0, -Mx ww xi, -My ww xi}, Jy = {0, 0, 0, Mx ww, My ww, ww, -Mx ww yi,
+            // -My ww yi}; JtJ[a][b] += Jx[a] Jx[b] + Jy[a] Jy[b], Jt r[a] += Jx[a] ex + Jy[a] ey.  A product with
+            // one of the zeros is +-0 (the entries are finite: ww is guarded above), and adding +-0 changes
+            // neither the other product nor a sum that started at +0: the products of the zeros are left out,
+            // and the nine entries between parameters 0..2 and 3..5 stay +0.
+            const double j0 = Mx * ww, j1 = My * ww, j2 = ww;
+            const double x6 = -Mx * ww * xi, x7 = -My * ww * xi, y6 = -Mx * ww * yi, y7 = -My * ww * yi;
+            const double J3[3] = {j0, j1, j2};
 #pragma unroll
-            for (int a = 0; a < 8; a++)
+            for (int a = 0; a < 3; a++)
 #pragma unroll
-                for (int b = a; b < 8; b++) acc[e++] += Jx[a] * Jx[b] + Jy[a] * Jy[b];
+                for (int b = a; b < 3; b++) {
+                    acc[acc_index(a, b)] += J3[a] * J3[b];          // Jx Jx
+                    acc[acc_index(a + 3, b + 3)] += J3[a] * J3[b];  // Jy Jy: the same value, its own sum
+                }
 #pragma unroll
-            for (int a = 0; a < 8; a++) acc[36 + a] += Jx[a] * ex + Jy[a] * ey;
+            for (int a = 0; a < 3; a++) {
+                acc[acc_index(a, 6)] += J3[a] * x6;
+                acc[acc_index(a, 7)] += J3[a] * x7;
+                acc[acc_index(a + 3, 6)] += J3[a] * y6;
+                acc[acc_index(a + 3, 7)] += J3[a] * y7;
+                acc[36 + a] += J3[a] * ex;
+                acc[36 + a + 3] += J3[a] * ey;
+            }
+            acc[acc_index(6, 6)] += x6 * x6 + y6 * y6;
+            acc[acc_index(6, 7)] += x6 * x7 + y6 * y7;
+            acc[acc_index(7, 7)] += x7 * x7 + y7 * y7;
+            acc[36 + 6] += x6 * ex + y6 * ey;
+            acc[36 + 7] += x7 * ex + y7 * ey;
         }
     }
     if (with_J) {
@@ -635,7 +658,9 @@ __device__ double lm_compute_wave(const float* __restrict__ M, const float* __re
         for (int a = 0; a < 8; a++)
 #pragma unroll
             for (int b = a; b < 8; b++) {
-                const double v = wave_sum(acc[e++]);
+                const bool zero = a < 3 && b >= 3 && b < 6;  // never touched: a sum of +0 terms
+                const double v = zero ? 0. : wave_sum(acc[e]);
+                e++;
                 if (lane == 0) {
                     S->A[a * 8 + b] = v;
                     S->A[b * 8 + a] = v;
