@@ -179,6 +179,28 @@ def test_hip_dt_wide_and_tall_images():
 
 
 @pytest.mark.gpu
+def test_hip_dt_tile_borders():
+    """Image sizes around the scan kernels' tile (32 rows x 64 columns): a single zero in every corner
+    and in the middle of a tile border, so that every distance arrives through the summaries of other
+    tiles, along rows, along columns and along both."""
+    rng = np.random.default_rng(9)
+    c = rtvm.Context(48, 64, 140, 280)
+    try:
+        for h in (31, 32, 33, 64, 65, 97):
+            for w in (63, 64, 65, 127, 128, 129, 200):
+                spots = [(0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1), (min(31, h - 1), min(63, w - 1)),
+                         (min(32, h - 1), min(64, w - 1)), (h // 2, w // 2)]
+                for (y, x) in spots:
+                    m = np.full((h, w), 255, np.uint8)
+                    m[y, x] = 0
+                    assert np.array_equal(c.distance_transform(m), orc.distance_transform(m)), (h, w, y, x)
+                m = (rng.random((h, w)) >= 0.004).astype(np.uint8) * 255
+                assert np.array_equal(c.distance_transform(m), orc.distance_transform(m)), (h, w, "sparse")
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fixed", [0, 1])
 @pytest.mark.parametrize("name", sorted(HS))
 def test_hip_warp_perspective_exact(ctxs, fixed, name):
