@@ -231,8 +231,10 @@ __global__ __launch_bounds__(256) void k_sift_blur_cols(const SiftFrame* __restr
 }
 
 // 16-byte LDS reads by hand.  lds_offset: the LDS address of a __shared__ object (the low half of
-// its generic address); lds_read16: ds_read_b128 at addr + OFF, the result is valid after lds_wait on
-// the registers it went to (the compiler does not track reads it did not issue itself).
+// its generic address); lds_read16: ds_read_b128 at addr + OFF; lds_arrived<LATER>: its result is
+// valid once all but the LATER reads issued after it have returned (LDS answers a wave in order;
+// the compiler does not track reads it did not issue itself, so the registers are an in/out operand
+// of the wait and no use of them can move above it).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t lds_offset(const void* p) { return (uint32_t)(uintptr_t)p; }
 __device__ __forceinline__ f32x4 lds_read16(uint32_t addr, int off) {
@@ -240,25 +242,18 @@ __device__ __forceinline__ f32x4 lds_read16(uint32_t addr, int off) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off) : "memory");
     return v;
 }
-template <int K>
-__device__ __forceinline__ void lds_wait(f32x4 (&u)[K]) {
-    static_assert(K >= 1 && K <= 12, "one operand per register group");
-    // every register group is an in/out operand, so that no use of it can move above the wait
-    if constexpr (K == 5)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4])::"memory");
-    else if constexpr (K == 6)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5])::"memory");
-    else if constexpr (K == 7)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6])::"memory");
-    else if constexpr (K == 8)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7])::"memory");
-    else if constexpr (K == 9)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]), "+v"(u[8])::"memory");
-    else
-        static_assert(K == 5, "add the operand list for this window length");
+template <int LATER>
+__device__ __forceinline__ void lds_arrived(f32x4& u) {
+    static_assert(LATER >= 0 && LATER <= 15, "the counter has four bits");
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(u) : "n"(LATER) : "memory");
+}
+// u[0..K) were read in this order and nothing else since
+template <int K, int I = 0>
+__device__ __forceinline__ void lds_arrived_all(f32x4 (&u)[K]) {
+    if constexpr (I < K) {
+        lds_arrived<(K - 1 - I < 15 ? K - 1 - I : 15)>(u[I]);
+        lds_arrived_all<K, I + 1>(u);
+    }
 }
 
 // Both passes of one blur for a tile of SBT_W x SBT_H outputs, compiled per kernel length N (11,
@@ -338,7 +333,7 @@ __global__ __launch_bounds__(256) void k_sift_blur(const SiftFrame* __restrict__
             const uint32_t wa = lds_offset(&s_in[wv][q][sb_pad(seg * SB_R)]);
 #pragma unroll
             for (int i = 0; i < WIN4; i++) u[i] = lds_read16(wa, 16 * i);
-            lds_wait(u);
+            lds_arrived_all(u);
             float v[4 * WIN4];
 #pragma unroll
             for (int i = 0; i < WIN4; i++) v[4 * i] = u[i].x, v[4 * i + 1] = u[i].y, v[4 * i + 2] = u[i].z, v[4 * i + 3] = u[i].w;
