@@ -51,18 +51,16 @@ __device__ __forceinline__ double sqrt_1to2(double x) {
     return __builtin_fma(d, h, g);
 }
 
+// cv::hypot as Jacobi uses it (the larger magnitude times sqrt(1 + q*q), q the ratio of the smaller to
+// the larger; 0 when both are 0), as selects: one copy of the division and the root, no branches
 __device__ __forceinline__ double cv_hypot(double a, double b) {
     a = fabs(a);
     b = fabs(b);
-    if (a > b) {
-        b /= a;
-        return a * sqrt_1to2(1 + b * b);
-    }
-    if (b > 0) {
-        a /= b;
-        return b * sqrt_1to2(1 + a * a);
-    }
-    return 0;
+    const bool ab = a > b;
+    const double hi = ab ? a : b, lo = ab ? b : a;
+    const double q = lo / hi;  // hi is 0 only where the result is 0 whatever q is
+    const double r = hi * sqrt_1to2(1 + q * q);
+    return (ab || b > 0) ? r : 0.;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -114,16 +112,28 @@ __device__ __forceinline__ double row0_max(double v) {
 __device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane: the same in every lane
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-// one step of the first-maximum reduction: (value, index) of this lane against those N lanes down the row
-template <int N>
-__device__ __forceinline__ void first_max_step(double& val, int& bi) {
-    const double ov = row_shr_f64<N>(val, -2.);
-    const int oi = row_shr_i32<N>(bi, 1 << 20);
-    // as selects on the register halves (a branch here costs more than the three moves it would skip)
-    const bool take = (ov > val) | ((ov == val) & (oi < bi));
-    const int lo = take ? __double2loint(ov) : __double2loint(val), hi = take ? __double2hiint(ov) : __double2hiint(val);
-    val = __hiloint2double(hi, lo);
-    bi = take ? oi : bi;
+// every lane of a row of 16 lanes receives the largest value of the row: four exchanges (lane ^ 1,
+// lane ^ 2, then the mirror images inside 8 and 16 lanes, which meet lanes ^ 4 and ^ 8 of equal halves)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    // (every lane has a source under these patterns; "zero without one" only spares presetting the target)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_all_max(double v) {
+    v = max_f64(v, dpp_f64<0xB1>(v));   // quad_perm:[1,0,3,2]
+    v = max_f64(v, dpp_f64<0x4E>(v));   // quad_perm:[2,3,0,1]
+    v = max_f64(v, dpp_f64<0x141>(v));  // row_half_mirror
+    v = max_f64(v, dpp_f64<0x140>(v));  // row_mirror
+    return v;
+}
+// LDS serves the accesses of one wave in order: between the phases of a one-wave workgroup only the
+// compiler has to be kept from moving them
+__device__ __forceinline__ void wave_lds_phase() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // cv::JacobiImpl_<double> executed by one full wave on LDS-resident matrices
@@ -166,6 +176,25 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
     const int maxIters = n * n * 30;
     const bool is_row = lane < n - 1, is_cand = lane < 2 * n - 2;
     const int voff = (int)(V - A);  // V addressed from A: one base for the rotation's loads and stores
+    // What the lanes' parts in a rotation do not depend on the pivot for, arranged so that the pivot enters
+    // by arithmetic only (choices between differently computed addresses compile to branches on the
+    // execution mask, a dozen per rotation).
+    // Rotation: lanes 0..n-1 take the pair of A that row / column lane shares with k and l (none for
+    // lane = k, l): elements n * min(lane, k) + max(lane, k) and the same with l; lanes 16..16+n-1 take the
+    // pair of V of column lane - 16: elements voff + n * k + lane - 16 and the same with l, which is the same
+    // formula for an index rr = lane - 16 + 64 beyond every k and a base 64 lower.
+    const bool isA = lane < n, live = isA || (lane >= 16 && lane < 16 + n);
+    const int rr = isA ? lane : lane + 48, rbase = isA ? 0 : voff - 64;
+    // Scans: the four groups of 16 lanes take row k, column k, row l, column l; lane i16 of a group looks at
+    // element i16: of a row idx that is A[n * idx + i16] for idx < i16 < n, of a column A[n * i16 + idx] for
+    // i16 < idx.
+    const int i16 = lane & 15;
+    const bool col = (lane & 16) != 0;
+    const int of_l = (lane >> 5) & 1;                               // idx = k + of_l * (l - k)
+    const int scan_a = col ? n * i16 : i16, scan_b = col ? 1 : n;   // the element: scan_a + scan_b * idx
+    const int side_i = col ? -i16 : i16, side_s = col ? -1 : 1;     // it exists iff side_i - side_s * idx > 0 ...
+    const bool in_n = col || i16 < n;                               // ... and i16 < n
+    const int slot_off = col ? n - 2 : 0;
     if (n > 1)
         for (int iters = 0; iters < maxIters; iters++) {
             // pivot: first maximum over rows 0..n-2, then columns 1..n-1
@@ -187,15 +216,11 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
             const double p = readlane_f64(sval, win);
             if (fabs(p) <= eps) break;
             const double wk = readlane_f64(wck, win), wl = readlane_f64(wcl, win);
-            // lanes 0..n-1 rotate the pair of A that row / column i = lane shares with k and l (none for
-            // i = k, l), lanes 16..16+n-1 the pair of V of column i = lane - 16: one sequence for both.
             // The pairs are requested now (only k and l are needed to find them) and arrive while the
             // divisions and square roots of the rotation's coefficients run.
-            const bool isA = lane < n;
-            const int ri = isA ? lane : lane - 16;
-            const bool act = isA ? (ri != k && ri != l) : (lane >= 16 && lane < 16 + n);
-            const int e0 = isA ? (ri < k ? n * ri + k : n * k + ri) : voff + n * k + ri;
-            const int e1 = isA ? (ri < l ? n * ri + l : n * l + ri) : voff + n * l + ri;
+            const bool act = live && rr != k && rr != l;
+            const int e0 = rbase + n * min(rr, k) + max(rr, k);
+            const int e1 = rbase + n * min(rr, l) + max(rr, l);
             double a0 = 0, b0 = 0;
             if (act) a0 = A[e0], b0 = A[e1];
             const double y = (wl - wk) * 0.5;
@@ -205,35 +230,38 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
             s = p / s;
             t = (p / t) * p;
             if (y < 0) s = -s, t = -t;
-            __syncthreads();  // every lane has read its candidate and its pair
+            // W[k] -= t, W[l] += t on the values the pivot search already holds
+            double wk_new = wk - t, wl_new = wl + t, a1 = a0 * c - b0 * s, b1 = a0 * s + b0 * c;
+            // All of that in every lane and in one piece: left to itself the compiler moves the division by t
+            // under "lane 0" and the rest under "lanes with a pair", one chain of dependent operations after
+            // the other, where side by side each fills the other's waits.
+            asm volatile("" : "+v"(wk_new), "+v"(wl_new), "+v"(a1), "+v"(b1));
+            wave_lds_phase();  // every lane has read its candidate and its pair
             if (lane == 0) {
                 A[n * k + l] = 0;
-                W[k] = wk - t;  // W[k] -= t, W[l] += t on the values the pivot search already holds
-                W[l] = wl + t;
+                W[k] = wk_new;
+                W[l] = wl_new;
             }
             if (act) {
-                A[e0] = a0 * c - b0 * s;
-                A[e1] = a0 * s + b0 * c;
+                A[e0] = a1;
+                A[e1] = b1;
             }
-            __syncthreads();
+            wave_lds_phase();
             // the maxima of row k, column k, row l, column l again: the sequential scans "first largest
             // |a| of row idx right of the diagonal" / "... of column idx above it", each by one group of
-            // 16 lanes (lane i looks at element i, then a first-maximum reduction inside the group)
+            // 16 lanes: lane i16 looks at element i16, the group's largest value reaches all its lanes, and
+            // the first lane that holds it is the scan's answer
             {
-                const int g = lane >> 4, i = lane & 15;
-                const int idx = (g & 2) ? l : k;
-                const bool col = (g & 1) != 0;
-                const bool has = col ? (idx > 0 && i < idx) : (idx < n - 1 && i > idx && i < n);
-                double val = -1.;
-                if (has) val = fabs(A[col ? n * i + idx : n * idx + i]);
-                int bi = i;
-                first_max_step<1>(val, bi);
-                first_max_step<2>(val, bi);
-                first_max_step<4>(val, bi);
-                first_max_step<8>(val, bi);  // lane 15 of the group now holds the group's result
-                if (i == 15 && val >= 0.) ind[col ? n - 2 + idx : idx] = bi;
+                const int idx = k + of_l * (l - k);
+                const bool has = in_n && side_i - side_s * idx > 0;
+                double v = -1.;
+                if (has) v = fabs(A[scan_a + scan_b * idx]);
+                const double gm = row_all_max(v);
+                const unsigned long long eq = __ballot(v == gm);
+                const int first = __ffs((unsigned)(eq >> (lane & 48)) & 0xFFFFu) - 1;
+                if (i16 == 15 && gm >= 0.) ind[slot_off + idx] = first;
             }
-            __syncthreads();
+            wave_lds_phase();
         }
     __syncthreads();
     // selection sort (descending) with row swaps: the permutation is found with compile-time indices
