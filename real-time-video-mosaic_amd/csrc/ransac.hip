@@ -52,15 +52,15 @@ __device__ __forceinline__ double sqrt_1to2(double x) {
 }
 
 // cv::hypot as Jacobi uses it (the larger magnitude times sqrt(1 + q*q), q the ratio of the smaller to
-// the larger; 0 when both are 0), as selects: one copy of the division and the root, no branches
-__device__ __forceinline__ double cv_hypot(double a, double b) {
+// the larger; 0 when both are 0) for a != 0, as every pivot is: the larger magnitude is then not 0 and the
+// zero case cannot occur.  As selects: one copy of the division and the root, no branches.
+__device__ __forceinline__ double cv_hypot_nz(double a, double b) {
     a = fabs(a);
     b = fabs(b);
     const bool ab = a > b;
     const double hi = ab ? a : b, lo = ab ? b : a;
-    const double q = lo / hi;  // hi is 0 only where the result is 0 whatever q is
-    const double r = hi * sqrt_1to2(1 + q * q);
-    return (ab || b > 0) ? r : 0.;
+    const double q = lo / hi;
+    return hi * sqrt_1to2(1 + q * q);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -150,6 +150,8 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
     // (rows 0..n-2), ind[n - 2 + c] = row of the largest |a| of column c above it (columns 1..n-1).
     int* ind = indR;  // 16 entries are enough for n <= 9
     (void)indC;
+    if (lane < 16) ind[lane] = 0;  // every lane reads an entry, the candidates' are set below
+    wave_lds_phase();
     if (lane < n) {
         const int k = lane;
         W[k] = A[(n + 1) * k];
@@ -198,20 +200,19 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
     if (n > 1)
         for (int iters = 0; iters < maxIters; iters++) {
             // pivot: first maximum over rows 0..n-2, then columns 1..n-1
-            double val = -1., sval = 0., wck = 0., wcl = 0.;
-            int ck = 0, cl = 0;
-            if (is_cand) {  // the candidate element and the two eigenvalue estimates it would touch
-                const int ix = ind[lane];
-                ck = is_row ? lane : ix;
-                cl = is_row ? ix : lane - (n - 2);
-                sval = A[n * ck + cl];
-                wck = W[ck];
-                wcl = W[cl];
-                val = fabs(sval);
-            }
+            // the candidate element and the two eigenvalue estimates it would touch (lanes that are no
+            // candidates read element (0, 0) and never win)
+            const int ix = ind[lane & 15];
+            const int ck = is_row ? lane : is_cand ? ix : 0;
+            const int cl = is_row ? ix : is_cand ? lane - (n - 2) : 0;
+            double sval = A[n * ck + cl], wck = W[ck], wcl = W[cl];
+            // (all three requested here, in one round trip: the estimates are not needed to recognise the
+            // end of the iteration, and the compiler would fetch them after that test, in a trip of their own)
+            asm volatile("" : "+v"(sval), "+v"(wck), "+v"(wcl));
+            const double val = is_cand ? fabs(sval) : -1.;
             const double mx = row0_max(val);  // the 2n-2 <= 16 candidates sit in lanes 0..15
             const unsigned long long hit = __ballot(val == mx);
-            const int win = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+            const int win = __builtin_ctzll(hit);  // some lane holds the maximum
             const int k = __builtin_amdgcn_readlane(ck, win), l = __builtin_amdgcn_readlane(cl, win);
             const double p = readlane_f64(sval, win);
             if (fabs(p) <= eps) break;
@@ -224,11 +225,15 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
             double a0 = 0, b0 = 0;
             if (act) a0 = A[e0], b0 = A[e1];
             const double y = (wl - wk) * 0.5;
-            double t = fabs(y) + cv_hypot(p, y);
-            double s = cv_hypot(p, t);
+            double t = fabs(y) + cv_hypot_nz(p, y);  // |p| > eps
+            // hypot(p, t): t >= hypot(p, y) >= |p|, so t is the larger magnitude (for t = |p| both orders give
+            // the same), and its ratio q = |p| / t is, but for the sign of p, the quotient p / t of the next
+            // line of the sequential code: (p / t) * p = q * |p| bit for bit.  One division less.
+            const double q = fabs(p) / t;
+            double s = t * sqrt_1to2(1 + q * q);
             const double c = t / s;
             s = p / s;
-            t = (p / t) * p;
+            t = q * fabs(p);
             if (y < 0) s = -s, t = -t;
             // W[k] -= t, W[l] += t on the values the pivot search already holds
             double wk_new = wk - t, wl_new = wl + t, a1 = a0 * c - b0 * s, b1 = a0 * s + b0 * c;
@@ -254,8 +259,9 @@ __device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int
             {
                 const int idx = k + of_l * (l - k);
                 const bool has = in_n && side_i - side_s * idx > 0;
-                double v = -1.;
-                if (has) v = fabs(A[scan_a + scan_b * idx]);
+                // (lanes without an element read some other entry of A or V and discard it)
+                const double av = fabs(A[scan_a + scan_b * idx]);
+                const double v = has ? av : -1.;
                 const double gm = row_all_max(v);
                 const unsigned long long eq = __ballot(v == gm);
                 const int first = __ffs((unsigned)(eq >> (lane & 48)) & 0xFFFFu) - 1;
