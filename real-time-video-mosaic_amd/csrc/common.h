@@ -174,6 +174,15 @@ struct DtJobG {
           zpitch(j.zpitch), cpitch(j.cpitch), ng(j.ng), rpitch(j.rpitch) {}
 };
 
+// Between two phases of a workgroup that is ONE wave.  LDS serves the accesses of a wave in order, so only
+// the compiler has to be kept from moving them across; __syncthreads() would also wait for every global store
+// of the wave to complete.
+__device__ __forceinline__ void wave_lds_phase() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Two floats handled as one packed operand (v_pk_fma_f32 and friends).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

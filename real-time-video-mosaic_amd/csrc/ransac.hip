@@ -128,14 +128,6 @@ __device__ __forceinline__ double row_all_max(double v) {
     v = max_f64(v, dpp_f64<0x140>(v));  // row_mirror
     return v;
 }
-// LDS serves the accesses of one wave in order: between the phases of a one-wave workgroup only the
-// compiler has to be kept from moving them
-__device__ __forceinline__ void wave_lds_phase() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // cv::JacobiImpl_<double> executed by one full wave on LDS-resident matrices
 // (A: n x n, only the upper triangle is used and it is destroyed; V: rows are the
 // eigenvectors; W: eigenvalues, descending).  The pivot choice, the rotation

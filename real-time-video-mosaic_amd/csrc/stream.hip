@@ -82,7 +82,8 @@ __global__ void k_validate(const double* __restrict__ H, double trans_thr, doubl
 // validate, smooth (weighted mean of at most five relative homographies),
 // H = H_old @ H_smoothed, H_old = H.  Writes the absolute homography and the
 // "do not stitch" flag of every frame, and a copy of the state after every frame.
-// One wave: the state and the per-frame inputs are brought into LDS by all lanes; lane e < 9
+// One wave (the phases are separated for the compiler only, see wave_lds_phase): the state and the
+// per-frame inputs are brought into LDS by all lanes; lane e < 9
 // carries element e of the 3x3 matrices through the chain (the decisions are taken by all
 // lanes alike), lane 0 keeps the scalars, all lanes copy the snapshots out.
 __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__ slots, int sb, int n,
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
         s_valid[lane] = validate_h(Hr, trans_thr, scale_thr) ? 1 : 0;
     }
     if (lane < 30) s_w[lane] = wtab[lane];
-    __syncthreads();
+    wave_lds_phase();
     StreamState* st = &S;
     int n_done = 0, last_good = -1;
     // 0 = go on; 1 = a mispredicted canvas mask upstream (detection results stand);
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
                 double h[5];
                 for (int a = 0; a < 5; a++) h[a] = st->hist[a][e];
                 const double Ho0 = st->H_old[(e / 3) * 3], Ho1 = st->H_old[(e / 3) * 3 + 1], Ho2 = st->H_old[(e / 3) * 3 + 2];
-                __syncthreads();  // everything read before anything of this frame is written
+                wave_lds_phase();  // everything read before anything of this frame is written
                 if (k == 5) {
                     for (int a = 0; a < 4; a++) h[a] = h[a + 1];
                     k = 4;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
                         if (a < k) st->hist[a][e] = h[a];
                     s_Hs[e] = Hs_e;
                 }
-                __syncthreads();
+                wave_lds_phase();
                 // self.H = np.matmul(self.H_old, H_relative_smoothed)
                 const int c2 = e % 3;
                 const double H_e = (Ho0 * s_Hs[c2] + Ho1 * s_Hs[3 + c2]) + Ho2 * s_Hs[6 + c2];
@@ -198,13 +199,13 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
             }
             if (lane == 0) st->last_good = last_good;
         }
-        __syncthreads();
+        wave_lds_phase();
         if (snapshot) {  // the state to return to when a later frame of the batch cannot be stitched
             const uint32_t* l = reinterpret_cast<const uint32_t*>(&S);
             uint32_t* g = reinterpret_cast<uint32_t*>(snap + j);
             for (int i = lane; i < WORDS; i += 64) g[i] = l[i];
         }
-        __syncthreads();
+        wave_lds_phase();
     }
     if (lane == 0) {
         st->abort = abort;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
         // did the last frame that was consumed advance the state?  (unchanged by a void batch)
         if (n_done > 0) st->tail_ok = (!abort && last_good == n - 1) ? 1 : 0;
     }
-    __syncthreads();
+    wave_lds_phase();
     {
         const uint32_t* l = reinterpret_cast<const uint32_t*>(&S);
         uint32_t* g = reinterpret_cast<uint32_t*>(st_g);

@@ -136,15 +136,26 @@ __device__ void warp_prep_frame(int j, const double* Hp, WarpParams* wp, DtJob* 
 // the non-zero pixels, which is the safe side); frame j also counts the frames before it in the
 // batch.  One block; thread j = frame j.
 __device__ void old_rects(const WarpParams* wp, DtJob* jobs_old, int n, int* cbox, int ch, int cw) {
+    // the regions of interest of the batch's frames side by side in LDS (x0, y0, x1, y1; an empty one as
+    // the neutral element of the joins below): every lane walks the frames before its own
+    __shared__ int4 s_roi[RTVM_MAX_BATCH];
     const int j = threadIdx.x;
     int x0 = cbox[0], y0 = cbox[1], x1 = cbox[2], y1 = cbox[3];
-    __syncthreads();
-    if (j < n && wp[j].rx1 > wp[j].rx0) {
-        for (int i = 0; i < j; i++)
-            if (wp[i].rx1 > wp[i].rx0) {
-                x0 = min(x0, wp[i].rx0), y0 = min(y0, wp[i].ry0);
-                x1 = max(x1, wp[i].rx1), y1 = max(y1, wp[i].ry1);
-            }
+    int4 own = make_int4(0x7FFFFFFF, 0x7FFFFFFF, 0, 0);
+    bool drawn = false;
+    if (j < n) {
+        const int4 r = make_int4(wp[j].rx0, wp[j].ry0, wp[j].rx1, wp[j].ry1);
+        drawn = r.z > r.x;
+        if (drawn) own = r;
+        s_roi[j] = own;
+    }
+    __syncthreads();  // cbox is read by every lane before lane 0 replaces it
+    if (drawn) {
+        for (int i = 0; i < j; i++) {
+            const int4 r = s_roi[i];
+            x0 = min(x0, r.x), y0 = min(y0, r.y);
+            x1 = max(x1, r.z), y1 = max(y1, r.w);
+        }
         // the ring of zeros around the box, then the window of this frame
         x0 = min(max(x0 - 1, 0), wp[j].wx0), y0 = min(max(y0 - 1, 0), wp[j].wy0);
         x1 = max(min(x1 + 1, cw), wp[j].wx1), y1 = max(min(y1 + 1, ch), wp[j].wy1);
@@ -154,19 +165,14 @@ __device__ void old_rects(const WarpParams* wp, DtJob* jobs_old, int n, int* cbo
         jobs_old[j].y1 = y1;
     }
     if (j == 0) {
-        int b[4] = {cbox[0], cbox[1], cbox[2], cbox[3]};
-        for (int i = 0; i < n; i++)
-            if (wp[i].rx1 > wp[i].rx0) {
-                b[0] = min(b[0], wp[i].rx0), b[1] = min(b[1], wp[i].ry0);
-                b[2] = max(b[2], wp[i].rx1), b[3] = max(b[3], wp[i].ry1);
-            }
         // cbox[4..7]: the box of this batch alone (the commit kernel leaves everything outside it alone)
         int u[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0, 0};
-        for (int i = 0; i < n; i++)
-            if (wp[i].rx1 > wp[i].rx0) {
-                u[0] = min(u[0], wp[i].rx0), u[1] = min(u[1], wp[i].ry0);
-                u[2] = max(u[2], wp[i].rx1), u[3] = max(u[3], wp[i].ry1);
-            }
+        for (int i = 0; i < n; i++) {
+            const int4 r = s_roi[i];
+            u[0] = min(u[0], r.x), u[1] = min(u[1], r.y);
+            u[2] = max(u[2], r.z), u[3] = max(u[3], r.w);
+        }
+        const int b[4] = {min(cbox[0], u[0]), min(cbox[1], u[1]), max(cbox[2], u[2]), max(cbox[3], u[3])};
         for (int k = 0; k < 4; k++) cbox[k] = b[k], cbox[4 + k] = u[k];
     }
 }
