@@ -314,6 +314,206 @@ __device__ __forceinline__ void warp_tile(const uint8_t* __restrict__ src, const
     }
 }
 
+// Where canvas pixel (x, y) lies in the frame: the top-left tap (ix, iy), clamped to [-2, fw + 1] x
+// [-2, fh + 1] so that it is an integer whatever the arithmetic produced, and the interpolation fractions
+// (FIXED: 0..31 as integers; else the float fractions as bit patterns).  Returns whether the pixel takes
+// taps at all (warp_tile's test); then the clamps changed nothing.
+template <bool FIXED>
+__device__ __forceinline__ bool warp_pos(const WarpParams* __restrict__ wp, int x, int y, int fh, int fw, int& ix, int& iy,
+                                         int& qa, int& qb) {
+    if (FIXED) {
+        const double* M = wp->M;
+        const int bw0 = wp->bw0;
+        const int xb = (x / bw0) * bw0, x1 = x - xb;
+        const double X0 = M[0] * xb + M[1] * y + M[2];
+        const double Y0 = M[3] * xb + M[4] * y + M[5];
+        const double W0 = M[6] * xb + M[7] * y + M[8];
+        double W = W0 + M[6] * x1;
+        W = W ? 32. / W : 0;
+        const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + M[0] * x1) * W));
+        const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + M[3] * x1) * W));
+        const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
+        int sx = X >> 5, sy = Y >> 5;
+        sx = sx < -32768 ? -32768 : sx > 32767 ? 32767 : sx;
+        sy = sy < -32768 ? -32768 : sy > 32767 ? 32767 : sy;
+        qa = X & 31;
+        qb = Y & 31;
+        ix = min(max(sx, -2), fw + 1);
+        iy = min(max(sy, -2), fh + 1);
+        return sx >= -1 && sx < fw && sy >= -1 && sy < fh;
+    } else {
+        const float* Mf = wp->Mf;
+        const float fx = (float)x, fy = (float)y;
+        const float w = (Mf[6] * fx + Mf[7] * fy) + Mf[8];
+        const float sx = ((Mf[0] * fx + Mf[1] * fy) + Mf[2]) / w;
+        const float sy = ((Mf[3] * fx + Mf[4] * fy) + Mf[5]) / w;
+        const float flx = floorf(sx), fly = floorf(sy);
+        qa = __float_as_int(sx - flx);
+        qb = __float_as_int(sy - fly);
+        ix = (int)fminf(fmaxf(flx, -2.f), (float)(fw + 1));  // a NaN becomes -2
+        iy = (int)fminf(fmaxf(fly, -2.f), (float)(fh + 1));
+        return sx > -1.f && sx < (float)fw && sy > -1.f && sy < (float)fh;
+    }
+}
+
+// The interpolated pixel from its four taps, each a word B | G << 8 | R << 16: warp_tile's arithmetic.
+template <bool FIXED>
+__device__ __forceinline__ uint32_t warp_interp(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, int qa, int qb) {
+    uint32_t out = 0;
+    if (FIXED) {
+        const int ax = qa, ay = qb;
+        const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32;
+        const int w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int s = w00 * (int)((p00 >> (8 * c)) & 255) + w01 * (int)((p01 >> (8 * c)) & 255) +
+                          w10 * (int)((p10 >> (8 * c)) & 255) + w11 * (int)((p11 >> (8 * c)) & 255);
+            out |= (uint32_t)((s + 16384) >> 15) << (8 * c);
+        }
+    } else {
+        const float a = __int_as_float(qa), b = __int_as_float(qb);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float f00 = (float)((p00 >> (8 * c)) & 255), f01 = (float)((p01 >> (8 * c)) & 255);
+            const float f10 = (float)((p10 >> (8 * c)) & 255), f11 = (float)((p11 >> (8 * c)) & 255);
+            const float v0 = f00 + (f01 - f00) * a;
+            const float v1 = f10 + (f11 - f10) * a;
+            const float r = v0 + (v1 - v0) * b;
+            const int q = __float2int_rn(r);
+            out |= (uint32_t)(q < 0 ? 0 : q > 255 ? 255 : q) << (8 * c);
+        }
+    }
+    return out;
+}
+
+constexpr int WT_ROWS = 16;      // canvas rows of a staged tile (64 columns: a wave is 64 pixels of a row)
+constexpr int WT_WORDS = 4096;   // frame pixels staged per tile, one word each (16 KB)
+
+struct WarpLds {
+    uint32_t px[WT_WORDS];   // the frame's rectangle under the tile, B | G << 8 | R << 16 per pixel, 0 outside the frame
+    int corner[8];           // (ix, iy) of the tile's four corner pixels
+    int bad[2];              // by tile parity: a pixel's taps lie outside the staged rectangle
+};
+
+// One tile of 64 x 16 canvas pixels at (bx, by), four pixels per thread (column bx + lane, rows by + wave + 4 r).
+// The frame's rectangle under the tile (from the tile's corners: a homography is monotone along every
+// row and column of a tile on which its denominator keeps its sign) goes into LDS by 12-byte loads of four
+// pixels, zero outside the frame (BORDER_CONSTANT), and the taps are two LDS reads of two words.  Every
+// pixel checks that its taps are inside the rectangle; if one is not, or the rectangle is too large (strong
+// minification), the tile is done by warp_tile's gathers from global memory.  `tile` counts the tiles of
+// this workgroup.  Same results as warp_tile.
+template <bool FIXED>
+__device__ __forceinline__ void warp_tile_staged(const uint8_t* __restrict__ src, const WarpParams* __restrict__ wp,
+                                                 gptr<uint8_t> out3, gptr<uint32_t> out4, const DtJob* __restrict__ job_new,
+                                                 int fh, int fw, int cw, int bx, int by, WarpLds& s, int tile) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rx0 = wp->rx0, ry0 = wp->ry0, rx1 = wp->rx1, ry1 = wp->ry1;
+    const int x = bx + lane;
+    const bool incol = x >= rx0 && x < rx1;
+    int ix[4], iy[4], qa[4], qb[4];
+    bool ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = by + wv + 4 * r;
+        ok[r] = warp_pos<FIXED>(wp, x, y, fh, fw, ix[r], iy[r], qa[r], qb[r]) && incol && y >= ry0 && y < ry1;
+    }
+    if ((lane == 0 || lane == 63) && (wv == 0 || wv == 3)) {
+        const int k = 2 * (lane & 1) + 4 * (wv & 1);
+        s.corner[k] = wv ? ix[3] : ix[0];
+        s.corner[k + 1] = wv ? iy[3] : iy[0];
+    }
+    __syncthreads();
+    // the next tile's flag (every thread has read it for the tile before this one); this tile's was cleared a tile ago
+    if (threadIdx.x == 0) s.bad[(tile + 1) & 1] = 0;
+    // the rectangle of taps: the corners' taps and a pixel more on every side, inside [-1, fw] x [-1, fh]
+    const int c0x = s.corner[0], c0y = s.corner[1], c1x = s.corner[2], c1y = s.corner[3];
+    const int c2x = s.corner[4], c2y = s.corner[5], c3x = s.corner[6], c3y = s.corner[7];
+    const int sx0 = max(min(min(c0x, c1x), min(c2x, c3x)) - 1, -1), sx1 = min(max(max(c0x, c1x), max(c2x, c3x)) + 2, fw);
+    const int sy0 = max(min(min(c0y, c1y), min(c2y, c3y)) - 1, -1), sy1 = min(max(max(c0y, c1y), max(c2y, c3y)) + 2, fh);
+    const int bw = sx1 - sx0 + 1, bh = sy1 - sy0 + 1;
+    const int gpr = (bw + 3) >> 2, pw = 4 * gpr;   // groups of four pixels per staged row, words per staged row
+    const bool stage = bw > 1 && bh > 1 && pw * bh <= WT_WORDS;
+    int at[4];
+    bool miss = false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int dx = ix[r] - sx0, dy = iy[r] - sy0;
+        const bool in = stage && (unsigned)dx < (unsigned)(bw - 1) && (unsigned)dy < (unsigned)(bh - 1);
+        miss |= ok[r] && !in;
+        at[r] = dy * pw + dx;
+    }
+    if (miss) s.bad[tile & 1] = 1;
+    if (stage) {
+        const int ng = gpr * bh;
+        const float inv = __builtin_amdgcn_rcpf((float)gpr);
+        for (int g = threadIdx.x; g < ng; g += 256) {
+            // g / gpr: the quotient is below 1024 / gpr and (g + 0.5) / gpr at least 0.5 / gpr away from an integer
+            const int row = (int)(((float)g + 0.5f) * inv), gi = g - row * gpr;
+            const int yy = sy0 + row, xx = sx0 + 4 * gi;
+            uint4 p = make_uint4(0u, 0u, 0u, 0u);
+            if ((unsigned)yy < (unsigned)fh) {
+                const uint32_t off = (__umul24((uint32_t)yy, (uint32_t)fw) + (uint32_t)xx) * 3u;  // of pixel xx when it exists
+                if (xx >= 0 && xx + 3 < fw) {
+                    uint32_t d[3];
+                    __builtin_memcpy(d, src + off, 12);
+                    p.x = d[0];
+                    p.y = __builtin_amdgcn_alignbit(d[1], d[0], 24);
+                    p.z = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+                    p.w = d[2] >> 8;
+                } else {
+                    uint32_t q[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        q[k] = 0;
+                        if ((unsigned)(xx + k) < (unsigned)fw) {
+                            const uint8_t* b = src + (off + 3u * (uint32_t)k);
+                            q[k] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+                        }
+                    }
+                    p = make_uint4(q[0], q[1], q[2], q[3]);
+                }
+            }
+            *reinterpret_cast<uint4*>(&s.px[row * pw + 4 * gi]) = p;
+        }
+    }
+    __syncthreads();
+    if (s.bad[tile & 1]) {  // the same for all threads
+#pragma unroll 1
+        for (int k = 0; k < WT_ROWS; k += 4) warp_tile<FIXED>(src, wp, out3, out4, job_new, fh, fw, cw, bx, by + k);
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = by + wv + 4 * r;
+        if (y < ry0 || y >= ry1) continue;  // the same for the wave
+        uint32_t v = 0;
+        if (ok[r]) {
+            const int i = at[r];
+            v = warp_interp<FIXED>(s.px[i], s.px[i + 1], s.px[i + pw], s.px[i + pw + 1], qa[r], qb[r]) & 0xFFFFFFu;
+        }
+        const bool zero = v == 0;
+        if (incol) {
+            const size_t p = (size_t)y * cw + x;
+            if (out4) {  // the pixel and its mask byte (main.py:878-879) in one word
+                out4[p] = v | (zero ? 0u : 0xFF000000u);
+            } else {
+                out3[3 * p] = (uint8_t)v;
+                out3[3 * p + 1] = (uint8_t)(v >> 8);
+                out3[3 * p + 2] = (uint8_t)(v >> 16);
+            }
+        }
+        if (job_new) {
+            // zero bit rows of the new mask for the distance transform (zero pixels of the ROI)
+            const unsigned long long bal = __ballot(incol && zero);
+            if (lane == 0) {
+                const auto B = as_global(job_new->B) + (size_t)y * job_new->wpitch + (bx >> 5);
+                B[0] = (uint32_t)bal;
+                B[1] = (uint32_t)(bal >> 32);
+            }
+        }
+    }
+}
+
 // blockIdx.z = frame of the batch: source srcs.p[z], parameters wp[z], output planes
 // sides[z] (or `out_only`, 3 bytes per pixel, for the stage entry point), bit rows of jobs_new[z].
 // The grid is sized for a region of interest of about the frame's size and walks the
@@ -322,18 +522,21 @@ template <bool FIXED>
 __global__ __launch_bounds__(256) void k_warp(BatchPtrs srcs, const WarpParams* __restrict__ wps,
                                               const SideDev* __restrict__ sides, uint8_t* __restrict__ out_only,
                                               const DtJob* __restrict__ jobs_new, int fh, int fw, int ch, int cw) {
+    __shared__ __align__(16) WarpLds s;
     const uint8_t* __restrict__ src = srcs.p[blockIdx.z];
     const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const gptr<uint8_t> out3 = as_global(out_only);
     const gptr<uint32_t> out4 = out_only ? nullptr : as_global(sides[blockIdx.z].warped);
     const DtJob* __restrict__ job_new = jobs_new ? jobs_new + blockIdx.z : nullptr;
     const int rx1 = wp->rx1, ry1 = wp->ry1;
-    const int ox = wp->rx0 & ~63, oy = wp->ry0 & ~3;
+    const int ox = wp->rx0 & ~63, oy = wp->ry0;
+    if (threadIdx.x == 0) s.bad[0] = 0;
+    int tile = 0;
 #pragma unroll 1
-    for (int by = oy + 4 * (int)blockIdx.y; by < ry1; by += 4 * (int)gridDim.y)
+    for (int by = oy + WT_ROWS * (int)blockIdx.y; by < ry1; by += WT_ROWS * (int)gridDim.y)
 #pragma unroll 1
         for (int bx = ox + 64 * (int)blockIdx.x; bx < rx1; bx += 64 * (int)gridDim.x)
-            warp_tile<FIXED>(src, wp, out3, out4, job_new, fh, fw, cw, bx, by);
+            warp_tile_staged<FIXED>(src, wp, out3, out4, job_new, fh, fw, cw, bx, by, s, tile++);
 }
 
 // The canvas mask each frame of a batch will meet, as zero bit rows, assuming that a pixel
@@ -734,7 +937,7 @@ int rtvm_launch_warp_only(rtvm_ctx* c, const uint8_t* d_bgr, const double* d_H, 
     BatchPtrs bp;
     memset(&bp, 0, sizeof(bp));
     bp.p[0] = d_bgr;
-    const dim3 grid((c->cw + 63) / 64, (c->ch + 3) / 4, 1);
+    const dim3 grid((c->cw + 63) / 64, (c->ch + WT_ROWS - 1) / WT_ROWS, 1);
     if (c->flags & RTVM_FLAG_WARP_FIXED)
         RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, bp, c->d_wp, (const SideDev*)nullptr, d_out,
                     (const DtJob*)nullptr, c->fh, c->fw, c->ch, c->cw);
@@ -760,7 +963,7 @@ int rtvm_launch_sides(rtvm_ctx* c, const uint8_t* const* d_bgr, int n) {
     BatchPtrs bp;
     memset(&bp, 0, sizeof(bp));
     for (int j = 0; j < n; j++) bp.p[j] = d_bgr[j];
-    const dim3 grid(roi_tiles(c->cw, c->fw + c->fh / 2, 64), roi_tiles(c->ch, c->fh + c->fw / 2, 4), n);
+    const dim3 grid(roi_tiles(c->cw, c->fw + c->fh / 2, 64), roi_tiles(c->ch, c->fh + c->fw / 2, WT_ROWS), n);
     if (c->flags & RTVM_FLAG_WARP_FIXED)
         RTVM_LAUNCH(c, k_warp<true>, grid, dim3(256), 0, bp, c->d_wp, c->d_side, (uint8_t*)nullptr, c->d_jobs, c->fh,
                     c->fw, c->ch, c->cw);
