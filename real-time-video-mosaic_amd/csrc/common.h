@@ -322,6 +322,7 @@ struct rtvm_ctx {
     OrbDev orb;
     size_t orb_pyr_bytes;
     int orb_cand_total, orb_sel_total, orb_xtab_total, orb_ytab_total;
+    int orb_chain;         // the pyramid's levels are resized in two chained launches (else one launch per level)
     uint8_t* d_bgr;        // staging frame fh*fw*3
     uint16_t* d_xofs;      // resize tables
     uint16_t* d_xw;

@@ -138,6 +138,142 @@ __global__ __launch_bounds__(256) void k_resize(const FrameSlot* __restrict__ sl
     }
 }
 
+// ---- several levels per launch
+// The rectangle of a level a chain workgroup computes (x0, y0, w, h; x0 and w multiples of 4) and the part
+// of it the workgroup writes to memory (columns ox0..ox1, rows oy0..oy1, exclusive ends).
+struct RcRegion {
+    int x0, y0, w, h, ox0, oy0, ox1, oy1;
+};
+
+constexpr int RC_TW = 64, RC_TH = 16;  // tile of the chain's last level
+constexpr int RC_MAXN = 4;             // levels per chain
+constexpr int RC_BUF = 12288;          // bytes per staging buffer (two: the levels alternate between them)
+
+// Rectangles of levels a .. a+n (R[0] .. R[n]) for tile (tx0, ty0) of level a+n.  Level j+1 reads level j
+// through the tables xofs/yofs (+ tab_off[j+1]): a workgroup computes of every level what its next level
+// reads, and owns (writes) the pixels between the first sources of its own tile and of the next tile:
+// those ranges partition every level, so that each pixel is written once, by the workgroup that has it
+// anyway.  Column boundaries are rounded down to 4 (words are stored); the last tile of a row or column
+// takes the level's remainder.  Host and device run the same code on the same tables.
+__host__ __device__ inline void rc_regions(const OrbDev& P, int a, int n, int tx0, int ty0, const uint16_t* xofs,
+                                           const uint16_t* yofs, RcRegion* R) {
+    const int b = a + n;
+    const int w4b = (P.w[b] + 3) & ~3;
+    R[n].ox0 = tx0;
+    R[n].oy0 = ty0;
+    R[n].ox1 = tx0 + RC_TW < P.w[b] ? tx0 + RC_TW : w4b;
+    R[n].oy1 = ty0 + RC_TH < P.h[b] ? ty0 + RC_TH : P.h[b];
+    R[n].x0 = R[n].ox0;
+    R[n].y0 = R[n].oy0;
+    R[n].w = R[n].ox1 - R[n].ox0;
+    R[n].h = R[n].oy1 - R[n].oy0;
+    for (int k = n - 1; k >= 0; k--) {
+        const int j = a + k;  // this level; level j+1 is R[k+1]
+        const uint16_t* xo = xofs + P.xtab_off[j + 1];
+        const uint16_t* yo = yofs + P.ytab_off[j + 1];
+        const RcRegion& U = R[k + 1];
+        const int uw = P.w[j + 1], uh = P.h[j + 1];
+        const int lastx = U.x0 + U.w - 1 < uw - 1 ? U.x0 + U.w - 1 : uw - 1;
+        const int lasty = U.y0 + U.h - 1 < uh - 1 ? U.y0 + U.h - 1 : uh - 1;
+        // taps of the upper rectangle: first source .. last source + 1 (inside the level)
+        int nx0 = xo[U.x0 < uw - 1 ? U.x0 : uw - 1], nx1 = (int)xo[lastx] + 2;   // exclusive
+        int ny0 = yo[U.y0 < uh - 1 ? U.y0 : uh - 1], ny1 = (int)yo[lasty] + 2;
+        const int w4 = (P.w[j] + 3) & ~3;
+        if (nx1 > w4) nx1 = w4;
+        if (ny1 > P.h[j]) ny1 = P.h[j];
+        RcRegion& T = R[k];
+        T.ox0 = U.ox0 == 0 ? 0 : (int)xo[U.ox0] & ~3;
+        T.oy0 = U.oy0 == 0 ? 0 : (int)yo[U.oy0];
+        T.ox1 = U.ox1 >= uw ? w4 : (int)xo[U.ox1] & ~3;
+        T.oy1 = U.oy1 >= uh ? P.h[j] : (int)yo[U.oy1];
+        const int x0 = (nx0 & ~3) < T.ox0 ? (nx0 & ~3) : T.ox0, x1 = ((nx1 + 3) & ~3) > T.ox1 ? ((nx1 + 3) & ~3) : T.ox1;
+        const int y0 = ny0 < T.oy0 ? ny0 : T.oy0, y1 = ny1 > T.oy1 ? ny1 : T.oy1;
+        T.x0 = x0;
+        T.y0 = y0;
+        T.w = x1 - x0;
+        T.h = y1 - y0;
+    }
+}
+
+// Levels a+1 .. a+N of the pyramid in one launch: one workgroup per 64 x 16 tile of level a+N stages the
+// rectangle of level a under it in LDS and resizes level by level from LDS to LDS (k_resize's arithmetic),
+// four pixels of a row per thread, storing the pixels it owns as words.  What neighbouring workgroups both
+// need of a level both compute (about a third more pixels than the levels have); no level is read back
+// from memory and no launch waits for another.  The host has checked that every rectangle fits RC_BUF.
+template <int N>
+__global__ __launch_bounds__(256) void k_resize_chain(const OrbDev P, const FrameSlot* __restrict__ slots, int sb, int a,
+                                                      const uint16_t* __restrict__ xofs, const uint16_t* __restrict__ xw,
+                                                      const uint16_t* __restrict__ yofs, const uint16_t* __restrict__ yw) {
+    __shared__ __align__(16) uint8_t s_buf[2][RC_BUF];
+    __shared__ RcRegion s_reg[N + 1];
+    const FrameSlot& S = slots[sb + blockIdx.z];
+    const int b = a + N;
+    const int tiles_x = (P.w[b] + RC_TW - 1) / RC_TW;
+    const int tile = xcd_tile(blockIdx.x, tiles_x * ((P.h[b] + RC_TH - 1) / RC_TH));
+    if (tile < 0) return;
+    const int tid = threadIdx.x;
+    if (tid == 0) rc_regions(P, a, N, (tile % tiles_x) * RC_TW, (tile / tiles_x) * RC_TH, xofs, yofs, s_reg);
+    __syncthreads();
+    {   // level a: the rectangle from memory, aligned words, clamped to the plane
+        const RcRegion R = s_reg[0];
+        const uint8_t* __restrict__ src = S.pyr + P.off[a];
+        const int sp = P.pitch[a], sh = P.h[a];
+        const int qw = R.w >> 2, nq = qw * R.h;
+        const float inv = __builtin_amdgcn_rcpf((float)qw);
+        for (int i = tid; i < nq; i += 256) {
+            const int r = (int)(((float)i + 0.5f) * inv), q = i - r * qw;   // i / qw: exact for these sizes
+            const int y = min(R.y0 + r, sh - 1), x = min(R.x0 + 4 * q, sp - 4);
+            *reinterpret_cast<uint32_t*>(&s_buf[0][r * R.w + 4 * q]) = *reinterpret_cast<const uint32_t*>(src + (unsigned)(y * sp + x));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k <= N; k++) {
+        const int j = a + k;
+        const RcRegion R = s_reg[k], U = s_reg[k - 1];   // this level, the level it reads
+        const uint8_t* __restrict__ sbuf = s_buf[(k - 1) & 1];
+        uint8_t* __restrict__ dbuf = s_buf[k & 1];
+        uint8_t* __restrict__ dst = S.pyr + P.off[j];
+        const uint16_t* __restrict__ xo_t = xofs + P.xtab_off[j];
+        const uint16_t* __restrict__ xw_t = xw + P.xtab_off[j];
+        const uint16_t* __restrict__ yo_t = yofs + P.ytab_off[j];
+        const uint16_t* __restrict__ yw_t = yw + P.ytab_off[j];
+        const int dp = P.pitch[j], dh = P.h[j];
+        const int qw = R.w >> 2, nq = qw * R.h;
+        const float inv = __builtin_amdgcn_rcpf((float)qw);
+        for (int i = tid; i < nq; i += 256) {
+            const int r = (int)(((float)i + 0.5f) * inv), q = i - r * qw;
+            const int x = R.x0 + 4 * q, y = R.y0 + r;   // x < w4: the tables are padded to there
+            const int yc = min(y, dh - 1);
+            const int yo = yo_t[yc];
+            const unsigned cyr = yw_t[yc];
+            const unsigned cy = cyr == 0xFFFFu ? 0u : cyr;
+            const int r0 = (yo - U.y0) * U.w - U.x0, r1 = cyr == 0xFFFFu ? r0 : r0 + U.w;
+            const uint2 xo4 = *reinterpret_cast<const uint2*>(xo_t + x), xw4 = *reinterpret_cast<const uint2*>(xw_t + x);
+            uint32_t word = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const unsigned xo = ((e < 2 ? xo4.x : xo4.y) >> (16 * (e & 1))) & 0xFFFFu;
+                const unsigned cxr = ((e < 2 ? xw4.x : xw4.y) >> (16 * (e & 1))) & 0xFFFFu;
+                const unsigned cx = cxr == 0xFFFFu ? 0u : cxr;
+                const unsigned xo1 = cxr == 0xFFFFu ? xo : xo + 1;
+                const unsigned a00 = sbuf[r0 + (int)xo], a01 = sbuf[r0 + (int)xo1];
+                const unsigned a10 = sbuf[r1 + (int)xo], a11 = sbuf[r1 + (int)xo1];
+                // 9-bit weights, 8- and 16-bit values: 24-bit multiplies
+                const unsigned h0 = __umul24(256u - cx, a00) + __umul24(cx, a01);
+                const unsigned h1 = __umul24(256u - cx, a10) + __umul24(cx, a11);
+                unsigned v = __umul24(256u - cy, h0) + __umul24(cy, h1);
+                v = (v + 32768u) >> 16;
+                word |= (v > 255u ? 255u : v) << (8 * e);
+            }
+            if (k < N) *reinterpret_cast<uint32_t*>(&dbuf[r * R.w + 4 * q]) = word;
+            if (x >= R.ox0 && x < R.ox1 && y >= R.oy0 && y < R.oy1)
+                *reinterpret_cast<uint32_t*>(dst + (unsigned)(y * dp + x)) = word;
+        }
+        if (k < N) __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ FAST
 __device__ __forceinline__ int tile_level(const OrbDev& P, int tile, int* local) {
     int l = 0;
@@ -775,7 +911,7 @@ int rtvm_orb_plan(rtvm_ctx* c) {
         cand += P.cand_cap[l];
         P.xtab_off[l] = xt;
         P.ytab_off[l] = yt;
-        xt += P.w[l];
+        xt += ((P.w[l] + 3) & ~3) + 4;   // entries up to the next multiple of 4 exist (the last one repeated)
         yt += P.h[l];
         P.tile_off[l] = tiles;
         if (P.w[l] > 2 * EDGE && P.h[l] > 2 * EDGE)
@@ -838,12 +974,33 @@ int rtvm_orb_setup(rtvm_ctx* c) {
         yw(c->orb_ytab_total + 1);
     for (int l = 1; l < RTVM_NLEVELS; l++) {
         lin_coeffs(P.w[l - 1], P.w[l], &xo[P.xtab_off[l]], &xw[P.xtab_off[l]]);
+        for (int v = P.w[l]; v < ((P.w[l] + 3) & ~3) + 4; v++) {
+            xo[P.xtab_off[l] + v] = xo[P.xtab_off[l] + P.w[l] - 1];
+            xw[P.xtab_off[l] + v] = xw[P.xtab_off[l] + P.w[l] - 1];
+        }
         lin_coeffs(P.h[l - 1], P.h[l], &yo[P.ytab_off[l]], &yw[P.ytab_off[l]]);
     }
     HIP_TRY(c, hipMemcpy(c->d_xofs, xo.data(), xo.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_xw, xw.data(), xw.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_yofs, yo.data(), yo.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_yw, yw.data(), yw.size() * 2, hipMemcpyHostToDevice));
+    // Levels 1-3 and 4-7 as two chained launches when every rectangle of every tile fits the staging
+    // buffers (any frame size the pyramid factor 1.2 leaves above a few pixels); else level by level.
+    c->orb_chain = 1;
+    const int chain_a[2] = {0, 3}, chain_n[2] = {3, 4};
+    for (int g = 0; g < 2 && c->orb_chain; g++) {
+        const int a = chain_a[g], n = chain_n[g], b = a + n;
+        if (P.w[b] < 8 || P.h[b] < 8) c->orb_chain = 0;
+        for (int ty = 0; ty < P.h[b] && c->orb_chain; ty += RC_TH)
+            for (int tx = 0; tx < P.w[b] && c->orb_chain; tx += RC_TW) {
+                RcRegion R[RC_MAXN + 1];
+                rc_regions(P, a, n, tx, ty, xo.data(), yo.data(), R);
+                for (int k = 0; k <= n; k++)
+                    if (R[k].w <= 0 || R[k].h <= 0 || R[k].w * R[k].h > RC_BUF || R[k].x0 < 0 || R[k].y0 < 0 ||
+                        R[k].x0 + R[k].w > P.pitch[a + k] || R[k].w * R[k].h / 4 >= 4096)
+                        c->orb_chain = 0;
+            }
+    }
     return RTVM_OK;
 }
 
@@ -853,6 +1010,13 @@ int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
     const FrameSlot* sl = c->d_slots;
     RTVM_LAUNCH(c, k_gray, dim3((P.w[0] + 1023) / 1024, P.h[0], nb), dim3(256), 0, sl, sb, P.off[0], P.w[0], P.h[0],
                 P.pitch[0], rtvm_gray_coef(c));
+    if (c->orb_chain) {
+        static_assert(RTVM_NLEVELS == 8, "the chains cover levels 1-3 and 4-7");
+        RTVM_LAUNCH(c, k_resize_chain<3>, dim3(xcd_grid(((P.w[3] + RC_TW - 1) / RC_TW) * ((P.h[3] + RC_TH - 1) / RC_TH)), 1, nb),
+                    dim3(256), 0, P, sl, sb, 0, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw);
+        RTVM_LAUNCH(c, k_resize_chain<4>, dim3(xcd_grid(((P.w[7] + RC_TW - 1) / RC_TW) * ((P.h[7] + RC_TH - 1) / RC_TH)), 1, nb),
+                    dim3(256), 0, P, sl, sb, 3, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw);
+    } else
     for (int l = 1; l < RTVM_NLEVELS; l++)
         RTVM_LAUNCH(c, k_resize, dim3(xcd_grid(((P.w[l] + 63) / 64) * ((P.h[l] + 15) / 16)), 1, nb), dim3(256), 0, sl, sb, P.off[l - 1],
                     P.pitch[l - 1], P.h[l - 1], P.off[l], P.w[l], P.h[l], P.pitch[l], c->d_xofs + P.xtab_off[l],

@@ -633,19 +633,30 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
         v[2 * q + 1] = f32x2{a.z, a.w};
     }
     const auto outp = as_global(side.rb) + row + x;
-    // the sums of the lane advance tap by tap side by side: no packed operation waits for the one before it
+    // The sums of the lane advance tap by tap side by side, so that no packed operation waits for the one
+    // before it.  Spelled out as assembly: the scheduler strings the taps of each sum into one chain of
+    // dependent packed operations, every one a wait state (s_nop) behind its predecessor, whatever order
+    // the source gives them.  The wait state before the first group and after the last covers the
+    // neighbouring compiler-generated instructions, whose hazards the compiler cannot see into the assembly.
+    static_assert(BR_OUT == 4, "the groups below take four sums");
     f32x2 a[BR_OUT];
     {
         const float k0 = gk[0];
 #pragma unroll
         for (int o = 0; o < BR_OUT; o++) a[o] = f32x2{k0, k0} * v[o];
+        asm("s_nop 0" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
     }
 #pragma unroll
     for (int i = 1; i < 31; i++) {
         const float ki = gk[i];
-#pragma unroll
-        for (int o = 0; o < BR_OUT; o++) a[o] = __builtin_elementwise_fma(v[o + i], f32x2{ki, ki}, a[o]);
+        asm("v_pk_fma_f32 %0, %4, %8, %0\n\t"
+            "v_pk_fma_f32 %1, %5, %8, %1\n\t"
+            "v_pk_fma_f32 %2, %6, %8, %2\n\t"
+            "v_pk_fma_f32 %3, %7, %8, %3"
+            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+            : "v"(v[i]), "v"(v[i + 1]), "v"(v[i + 2]), "v"(v[i + 3]), "s"(f32x2{ki, ki}));
     }
+    asm("s_nop 0" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
 #pragma unroll
     for (int o = 0; o < BR_OUT; o++)
         if (x + o >= rx0 && x + o < rx1) outp[o] = a[o];
