@@ -374,6 +374,8 @@ void free_all(rtvm_ctx* c) {
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
     free(c->recs);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+    if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
+    if (c->ev_blur7) (void)hipEventDestroy(c->ev_blur7);
 }
 
 }  // namespace

@@ -297,6 +297,7 @@ struct rtvm_ctx {
     int rs_alone = 0;   // at most a batch's worth of frames in flight: latency is what counts (ransac.hip)
     hipEvent_t ev_done[RTVM_REPORTS];  // batch number (seq % RTVM_REPORTS) is complete
     hipEvent_t ev_main;
+    hipEvent_t ev_pyr, ev_blur7;   // ORB detection: the pyramid is complete / the blurred pyramid is (k_blur7 on a second stream)
     int back_rec[RTVM_NSETS];  // ev_back[k] has been recorded
     int set_next;              // slot set of the next pipelined batch
     int spec_tail;             // slot of the last frame of the batch queued before, -1 = none:

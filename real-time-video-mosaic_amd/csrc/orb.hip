@@ -1024,8 +1024,31 @@ int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
     if (P.tile_off[RTVM_NLEVELS] > 0) {
         RTVM_LAUNCH(c, k_fast, dim3(xcd_grid_runs(P.tile_off[RTVM_NLEVELS]), nb), dim3(256), 0, P, sl, sb);
     }
+    // The blurred pyramid needs the pyramid only.  On a context with several streams it is computed on the
+    // RANSAC search stream beside the selection (k_orb_select is one workgroup per level and frame: latency,
+    // not work; beside k_fast, which fills the device, it would gain nothing), and the descriptors wait for
+    // both.  That stream's order stays what the data flow is anyway: the hypothesis search of these frames is
+    // queued after their matching.
+    const bool fork = c->stream_rs && c->stream_rs != c->stream;
+    if (fork) {
+        if (!c->ev_pyr) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming));
+        if (!c->ev_blur7) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_blur7, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->ev_pyr, c->stream));
+        hipStream_t back = c->stream;
+        c->stream = c->stream_rs;
+        hipError_t e = hipStreamWaitEvent(c->stream, c->ev_pyr, 0);
+        if (e == hipSuccess) {
+            RTVM_LAUNCH(c, k_blur7, dim3(xcd_grid(P.btile_off[RTVM_NLEVELS]), nb), dim3(256), 0, P, sl, sb);
+            e = hipEventRecord(c->ev_blur7, c->stream);
+        }
+        c->stream = back;
+        HIP_TRY(c, e);
+    }
     RTVM_LAUNCH(c, k_orb_select, dim3(RTVM_NLEVELS, nb), dim3(1024), 0, P, sl, sb);
-    RTVM_LAUNCH(c, k_blur7, dim3(xcd_grid(P.btile_off[RTVM_NLEVELS]), nb), dim3(256), 0, P, sl, sb);
+    if (fork)
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_blur7, 0));
+    else
+        RTVM_LAUNCH(c, k_blur7, dim3(xcd_grid(P.btile_off[RTVM_NLEVELS]), nb), dim3(256), 0, P, sl, sb);
     RTVM_LAUNCH(c, k_orb_describe, dim3(P.max_kp, nb), dim3(64), 0, P, sl, sb);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
