@@ -812,15 +812,39 @@ __global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* 
     const int x0 = sel_lxy[2 * (P.sel_off[l] + idx)], y0 = sel_lxy[2 * (P.sel_off[l] + idx) + 1];
     const int pitch = P.pitch[l];
     const uint8_t* img = pyr + P.off[l];
+    // The two patches the keypoint reads, as a few 16-byte loads into LDS instead of a byte gather per sample (a
+    // gather of 64 bytes from 64 rows touches 64 cache lines: the kernel was bound by that): 31 rows x 32 bytes of
+    // the level around (x0, y0) for the moments, DESC_R rows and columns on every side of the blurred level for the
+    // tests (the pattern's points lie within 18.4 pixels of the centre).  Keypoints keep 31 pixels from the border.
+    constexpr int DESC_R = 19, DESC_ROWS = 2 * DESC_R + 1, DESC_PITCH = 48;
+    __shared__ __align__(16) uint8_t s_img[31][32];
+    __shared__ __align__(16) uint8_t s_blur[DESC_ROWS][DESC_PITCH];
+    {
+        typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+        if (lane < 62) {
+            const int r = lane >> 1, hf = lane & 1;
+            const uint8_t* g = img + (size_t)(y0 - 15 + r) * pitch + (x0 - 15 + 16 * hf);
+            *reinterpret_cast<u32x4*>(&s_img[r][16 * hf]) = *reinterpret_cast<const u32x4u*>(g);
+        }
+        const uint8_t* bl = blur + P.off[l];
+#pragma unroll
+        for (int i = lane; i < 3 * DESC_ROWS; i += 64) {
+            const int r = i / 3, sg = i - 3 * r;
+            const uint8_t* g = bl + (size_t)(y0 - DESC_R + r) * pitch + (x0 - DESC_R + 16 * sg);
+            *reinterpret_cast<u32x4*>(&s_blur[r][16 * sg]) = *reinterpret_cast<const u32x4u*>(g);
+        }
+    }
+    wave_lds_phase();
     // moments over the disc of radius 15: lane v+15 handles row v
     int m10 = 0, m01 = 0;
     if (lane < 31) {
         const int v = lane - 15;
         const int d = P.umax[v < 0 ? -v : v];
-        const uint8_t* row = img + (size_t)(y0 + v) * pitch + x0;
         int sum = 0;
-        for (int u = -d; u <= d; u++) {
-            const int val = row[u];
+#pragma unroll
+        for (int u = -15; u <= 15; u++) {
+            const int raw = s_img[lane][15 + u];   // read unconditionally: no branch per sample
+            const int val = (u < 0 ? -u : u) <= d ? raw : 0;
             m10 += u * val;
             sum += val;
         }
@@ -846,7 +870,6 @@ __global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* 
     float ang = angle;
     ang *= (float)(M_PI / 180.f);
     const float a = (float)cos((double)ang), b = (float)sin((double)ang);
-    const uint8_t* bimg = blur + P.off[l] + (size_t)y0 * pitch + x0;
     unsigned nib = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -854,8 +877,11 @@ __global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* 
         const float px1 = (float)p[0], py1 = (float)p[1], px2 = (float)p[2], py2 = (float)p[3];
         const float x1 = px1 * a - py1 * b, y1 = px1 * b + py1 * a;
         const float x2 = px2 * a - py2 * b, y2 = px2 * b + py2 * a;
-        const int t0 = bimg[(ptrdiff_t)__float2int_rn(y1) * pitch + __float2int_rn(x1)];
-        const int t1 = bimg[(ptrdiff_t)__float2int_rn(y2) * pitch + __float2int_rn(x2)];
+        // (the clamps never bind: they keep an index inside the patch whatever the arithmetic does)
+        const int ix1 = min(max(__float2int_rn(x1), -DESC_R), DESC_R), iy1 = min(max(__float2int_rn(y1), -DESC_R), DESC_R);
+        const int ix2 = min(max(__float2int_rn(x2), -DESC_R), DESC_R), iy2 = min(max(__float2int_rn(y2), -DESC_R), DESC_R);
+        const int t0 = s_blur[iy1 + DESC_R][ix1 + DESC_R];
+        const int t1 = s_blur[iy2 + DESC_R][ix2 + DESC_R];
         nib |= (unsigned)(t0 < t1) << t;
     }
     const unsigned hi = __shfl_down(nib, 1);
