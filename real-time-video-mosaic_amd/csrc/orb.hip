@@ -513,16 +513,23 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P, const FrameSlot* __restr
 }
 
 // ------------------------------------------------------------------ selection
+// The 9 x 9 pixels around the point as nine 12-byte loads (a byte load per sample would touch a cache line
+// per lane and sample: 189 of them per point), the sums from registers with compile-time byte positions.
 __device__ float harris_response(const uint8_t* __restrict__ img, int pitch, int x0, int y0) {
+    uint32_t w[9][3];   // byte k of row r = pixel (x0 - 4 + k, y0 - 4 + r)
+    const uint8_t* base = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
+#pragma unroll
+    for (int r = 0; r < 9; r++) __builtin_memcpy(w[r], base + (size_t)r * pitch, 12);
+    auto px = [&](int r, int k) { return (int)((w[r][k >> 2] >> (8 * (k & 3))) & 255u); };
     int a = 0, b = 0, c = 0;
+#pragma unroll
     for (int i = -3; i <= 3; i++) {
-        const uint8_t* r0 = img + (size_t)(y0 + i - 1) * pitch + x0;
-        const uint8_t* r1 = r0 + pitch;
-        const uint8_t* r2 = r1 + pitch;
+        const int r1 = i + 4, r0 = r1 - 1, r2 = r1 + 1;
 #pragma unroll
         for (int j = -3; j <= 3; j++) {
-            const int Ix = (r1[j + 1] - r1[j - 1]) * 2 + (r0[j + 1] - r0[j - 1]) + (r2[j + 1] - r2[j - 1]);
-            const int Iy = (r2[j] - r0[j]) * 2 + (r2[j - 1] - r0[j - 1]) + (r2[j + 1] - r0[j + 1]);
+            const int k = j + 4;
+            const int Ix = (px(r1, k + 1) - px(r1, k - 1)) * 2 + (px(r0, k + 1) - px(r0, k - 1)) + (px(r2, k + 1) - px(r2, k - 1));
+            const int Iy = (px(r2, k) - px(r0, k)) * 2 + (px(r2, k - 1) - px(r0, k - 1)) + (px(r2, k + 1) - px(r0, k + 1));
             a += Ix * Ix;
             b += Iy * Iy;
             c += Ix * Iy;
