@@ -714,13 +714,32 @@ __device__ __forceinline__ void blur_cols_window(const WarpParams* __restrict__ 
 #pragma unroll
         for (int i = 0; i < BC_ROWS; i++) a[i] = f32x2{k0, k0} * v[15 + i];
     }
+    // Groups of four sums as assembly, the four additions before the four multiply-adds, for the reason given
+    // in the row pass: left to the scheduler every sum becomes one chain of add, wait state, multiply-add.
+    static_assert(BC_ROWS % 4 == 0, "the groups below take four sums");
+#pragma unroll
+    for (int i = 0; i < BC_ROWS; i += 4) asm("s_nop 0" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
 #pragma unroll
     for (int t = 1; t <= 15; t++) {
         const float kt = gk[15 + t];
 #pragma unroll
-        for (int i = 0; i < BC_ROWS; i++)
-            a[i] = __builtin_elementwise_fma(v[15 + i + t] + v[15 + i - t], f32x2{kt, kt}, a[i]);
+        for (int i = 0; i < BC_ROWS; i += 4) {
+            f32x2 t0, t1, t2, t3;
+            asm("v_pk_add_f32 %4, %8, %12\n\t"
+                "v_pk_add_f32 %5, %9, %13\n\t"
+                "v_pk_add_f32 %6, %10, %14\n\t"
+                "v_pk_add_f32 %7, %11, %15\n\t"
+                "v_pk_fma_f32 %0, %4, %16, %0\n\t"
+                "v_pk_fma_f32 %1, %5, %16, %1\n\t"
+                "v_pk_fma_f32 %2, %6, %16, %2\n\t"
+                "v_pk_fma_f32 %3, %7, %16, %3"
+                : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                : "v"(v[15 + i + t]), "v"(v[16 + i + t]), "v"(v[17 + i + t]), "v"(v[18 + i + t]), "v"(v[15 + i - t]),
+                  "v"(v[16 + i - t]), "v"(v[17 + i - t]), "v"(v[18 + i - t]), "s"(f32x2{kt, kt}));
+        }
     }
+#pragma unroll
+    for (int i = 0; i < BC_ROWS; i += 4) asm("s_nop 0" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
 #pragma unroll
     for (int i = 0; i < BC_ROWS; i++)
         if (need[i]) {
