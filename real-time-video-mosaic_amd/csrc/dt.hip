@@ -117,6 +117,26 @@ __device__ __forceinline__ LineGeom line_geom(const DtJobG& jb) {
 // 32x32 bit matrix (w_r).  Each half-wave does one such block: lane r loads its window (two words),
 // 32 ballots transpose it.  (Small workgroups on purpose: a workgroup of 16 waves waits for half a
 // compute unit to be free at once, which rarely happens while the other streams keep the GPU busy.)
+// Transpose of the 32 x 32 bit matrix held by each half of the wave (lane r of a half holds row r): afterwards bit i
+// of lane r's word is bit r of what lane i held.  Five exchange steps with the lane 16, 8, 4, 2, 1 away (a swizzle
+// inside each half): a lane keeps the bits of the block it shares with its partner's row and takes the rest from the
+// partner's word, rotated by the distance; tm = the bits kept, tsh = the rotation (both per lane and step).
+// Three instructions per step where a ballot per bit and a select took four per bit and two wait states.
+__device__ __forceinline__ uint32_t transpose32(uint32_t a, const uint32_t (&tm)[5], const uint32_t (&tsh)[5]) {
+#define RTVM_T32_STEP(st, J)                                                                               \
+    {                                                                                                      \
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_swizzle((int)a, ((J) << 10) | 0x1F);               \
+        a = (a & tm[st]) | (__builtin_amdgcn_alignbit(b, b, tsh[st]) & ~tm[st]);                           \
+    }
+    RTVM_T32_STEP(0, 16)
+    RTVM_T32_STEP(1, 8)
+    RTVM_T32_STEP(2, 4)
+    RTVM_T32_STEP(3, 2)
+    RTVM_T32_STEP(4, 1)
+#undef RTVM_T32_STEP
+    return a;
+}
+
 __global__ __launch_bounds__(256) void k_dt_diag_a(const DtJob* __restrict__ jobs, int n_first, int second) {
     const DtJobG jb(jobs[job_index(blockIdx.z >> 1, n_first, second)]);
     const int orient = blockIdx.z & 1;
@@ -152,18 +172,21 @@ __global__ __launch_bounds__(256) void k_dt_diag_a(const DtJob* __restrict__ job
             w[k] = v;
         }
     }
+    // the lane's constants of the five exchange steps of the bit-matrix transpose (distance 16 >> s)
+    uint32_t tm[5], tsh[5];
+#pragma unroll
+    for (int st = 0; st < 5; st++) {
+        const int j = 16 >> st;
+        const uint32_t m = st == 0 ? 0x0000FFFFu : st == 1 ? 0x00FF00FFu : st == 2 ? 0x0F0F0F0Fu : st == 3 ? 0x33333333u : 0x55555555u;
+        tm[st] = (r & j) ? ~m : m;
+        tsh[st] = (r & j) ? j : 32 - j;
+    }
     uint32_t any = 0;
 #pragma unroll
     for (int k = 0; k < GR / 4; k++) {
         const int c = blockIdx.y * GR + wave * (GR / 4) + k;
         if (c >= g.nch) break;  // wave-uniform
-        uint32_t z = 0;
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const unsigned long long b = __ballot((w[k] >> j) & 1u);
-            const uint32_t half = grp ? (uint32_t)(b >> 32) : (uint32_t)b;
-            if (r == j) z = half;
-        }
+        const uint32_t z = transpose32(w[k], tm, tsh);
         if (line < g.nlines) jb.Z[((size_t)orient * jb.znch + c) * jb.zpitch + line] = z;
         any |= (z != 0 ? 1u : 0u) << (wave * (GR / 4) + k);
     }
