@@ -371,8 +371,11 @@ __device__ __forceinline__ void load_tile_e(const DtJobG& jb, int x, int ya, uin
         const int y = min(ya + r, jb.y1 - 1);
         s[r] = jb.S[(size_t)y * jb.pitch + xc];
     }
+    // rows of the lane that lie inside the rectangle, as a per-lane number: tests against it are selects.  (A test
+    // on the wave-uniform row limit becomes a branch per row, and every such branch copies all of E.)
+    const int rows_in = col_in ? jb.y1 - ya : 0;
 #pragma unroll
-    for (int r = 0; r < CH; r++) E[r] = (col_in && ya + r < jb.y1) ? e_soft(s[r]) : BIG;
+    for (int r = 0; r < CH; r++) E[r] = r < rows_in ? e_soft(s[r]) : BIG;
 }
 
 // Summaries of the tiles: per (column, chunk) what leaves the chunk downwards (value at its last
