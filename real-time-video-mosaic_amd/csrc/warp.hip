@@ -657,6 +657,12 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
             : "v"(v[i]), "v"(v[i + 1]), "v"(v[i + 2]), "v"(v[i + 3]), "s"(f32x2{ki, ki}));
     }
     asm("s_nop 0" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+    if (x >= rx0 && x + BR_OUT <= rx1) {   // all but the lanes on the region's edges: two 16-byte stores
+        typedef float f32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+        *reinterpret_cast<gptr<f32x4a8>>(outp) = f32x4a8{a[0].x, a[0].y, a[1].x, a[1].y};
+        *reinterpret_cast<gptr<f32x4a8>>(outp + 2) = f32x4a8{a[2].x, a[2].y, a[3].x, a[3].y};
+        return;
+    }
 #pragma unroll
     for (int o = 0; o < BR_OUT; o++)
         if (x + o >= rx0 && x + o < rx1) outp[o] = a[o];
