@@ -59,10 +59,16 @@ def pyramid_pixels(fh, fw):
     return tot
 
 
+def pyramid_level_pixels(fh, fw, l):
+    s = np.float32(np.float64(np.float32(1.2)) ** l)
+    inv = np.float32(1.0) / s
+    return int(np.rint(fw * inv)) * int(np.rint(fh * inv))
+
+
 def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
     """Compulsory HBM bytes per frame of all launches of a kernel: every input read once, every
-    output written once.  Every kernel is launched once (k_resize: seven times) per batch and
-    serves all frames of the batch.
+    output written once.  Every kernel is launched once per batch (the per-level k_resize seven times)
+    and serves all frames of the batch.
 
     The distance transform runs two jobs per frame: the new mask on the frame's region of the
     canvas (roi_px pixels) and the (predicted) old mask on the canvas content's bounding box, whose
@@ -79,6 +85,8 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
         "k_fast": S,                           # level pixels in (candidates out are a few KB)
         "k_blur7": S + S,
         "k_resize": (S - P) * (1.44 + 1),      # levels 1..7: previous level in, level out
+        "k_resize_chain<3>": P + sum(pyramid_level_pixels(fh, fw, l) for l in (1, 2, 3)),   # level 0 in, levels 1-3 out
+        "k_resize_chain<4>": sum(pyramid_level_pixels(fh, fw, l) for l in (3, 4, 5, 6, 7)),     # level 3 in, levels 4-7 out
         "k_warp<false>": 3 * P + 4 * roi_px + roi_px / 8,   # frame in, warped u8x3 + mask + zero bits out
         "k_warp<true>": 3 * P + 4 * roi_px + roi_px / 8,
         "k_dt_diag_a": A / 8 + A / 4,          # zero bit rows in, one bit per pixel and orientation out
@@ -90,6 +98,7 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
         "k_blur_cols": 8 * win + roi_px + 8 * roi_px,       # row-blurred weights + mask in, final weights out
         # per frame: mask + warped + two weights in; per batch: canvas + mask in/out and their snapshot
         "k_commit<false>": 12 * roi_px + 12 * roi_px / batch,
+        "k_commit4<false>": 12 * roi_px + 12 * roi_px / batch,
         "k_hamming_argmin": 2 * nkp * 32 * 2,
         "k_rs_refine": nkp * 16,               # matched point pairs in (latency bound: fp64 solver chains)
     }
