@@ -379,8 +379,8 @@ __device__ __forceinline__ uint32_t warp_interp(uint32_t p00, uint32_t p01, uint
             const float v0 = f00 + (f01 - f00) * a;
             const float v1 = f10 + (f11 - f10) * a;
             const float r = v0 + (v1 - v0) * b;
-            const int q = __float2int_rn(r);
-            out |= (uint32_t)(q < 0 ? 0 : q > 255 ? 255 : q) << (8 * c);
+            // round to nearest even, clamp to 0..255 and place the byte: one instruction (v_cvt_pk_u8_f32)
+            out = __builtin_amdgcn_cvt_pk_u8_f32(r, c, out);
         }
     }
     return out;
@@ -482,6 +482,12 @@ __device__ __forceinline__ void warp_tile_staged(const uint8_t* __restrict__ src
         for (int k = 0; k < WT_ROWS; k += 4) warp_tile<FIXED>(src, wp, out3, out4, job_new, fh, fw, cw, bx, by + k);
         return;
     }
+    gptr<uint32_t> bits = nullptr;   // the tile's words of the bit rows: row y at bits + y * bpitch
+    uint32_t bpitch = 0;
+    if (job_new) {
+        bits = as_global(job_new->B) + (bx >> 5);
+        bpitch = (uint32_t)job_new->wpitch;
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int y = by + wv + 4 * r;
@@ -493,7 +499,7 @@ __device__ __forceinline__ void warp_tile_staged(const uint8_t* __restrict__ src
         }
         const bool zero = v == 0;
         if (incol) {
-            const size_t p = (size_t)y * cw + x;
+            const uint32_t p = (uint32_t)y * (uint32_t)cw + (uint32_t)x;   // a canvas is far below 2^30 pixels
             if (out4) {  // the pixel and its mask byte (main.py:878-879) in one word
                 out4[p] = v | (zero ? 0u : 0xFF000000u);
             } else {
@@ -506,7 +512,7 @@ __device__ __forceinline__ void warp_tile_staged(const uint8_t* __restrict__ src
             // zero bit rows of the new mask for the distance transform (zero pixels of the ROI)
             const unsigned long long bal = __ballot(incol && zero);
             if (lane == 0) {
-                const auto B = as_global(job_new->B) + (size_t)y * job_new->wpitch + (bx >> 5);
+                const auto B = bits + (uint32_t)y * bpitch;
                 B[0] = (uint32_t)bal;
                 B[1] = (uint32_t)(bal >> 32);
             }
@@ -519,7 +525,7 @@ __device__ __forceinline__ void warp_tile_staged(const uint8_t* __restrict__ src
 // The grid is sized for a region of interest of about the frame's size and walks the
 // tiles of the actual one (tile (0,0) holds the ROI's first pixel).
 template <bool FIXED>
-__global__ __launch_bounds__(256) void k_warp(BatchPtrs srcs, const WarpParams* __restrict__ wps,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_warp(BatchPtrs srcs, const WarpParams* __restrict__ wps,
                                               const SideDev* __restrict__ sides, uint8_t* __restrict__ out_only,
                                               const DtJob* __restrict__ jobs_new, int fh, int fw, int ch, int cw) {
     __shared__ __align__(16) WarpLds s;
