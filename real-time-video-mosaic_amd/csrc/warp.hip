@@ -678,7 +678,7 @@ __device__ __forceinline__ void blur_rows_tile(const WarpParams* __restrict__ wp
 // the blend window, columns of the ROI), tile (0,0) holding the region's first pixel.  The grid
 // (a multiple of 8 workgroups) is sized for a region of about the frame's size: one tile per
 // workgroup; a larger region (normally none) is walked with the grid as stride.
-__global__ __launch_bounds__(256) void k_blur_rows(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k_blur_rows(const WarpParams* __restrict__ wps, const float* __restrict__ gk,
                                                    const SideDev* __restrict__ sides, int cw) {
     const WarpParams* __restrict__ wp = wps + blockIdx.z;
     const SideDev side = sides[blockIdx.z];
