@@ -39,6 +39,7 @@ constexpr int CH = 32;                         // rows per chunk
 constexpr int GR = 16;                         // chunks per summary group
 constexpr int TW = 192;                        // columns per tile of k_dt_diag_b: TW + 31 lines fit 256 threads
 constexpr int DB_THREADS = 256;
+constexpr int TPAD = 8, TP = TW + 2 * TPAD;    // a tile row in LDS: TPAD spare columns on either side (rows stay 16-byte aligned)
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t v, uint32_t k) {
     return v > INF32 - k ? INF32 : v + k;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void k_dt_diag_a(const DtJob* __restrict__ job
 // Steps to the nearest zero along one line for the 32 rows of chunk c, written into the LDS tile
 // of the line's orientation.
 __device__ __forceinline__ void diag_steps(const DtJobG& jb, const LineGeom& g, int orient, int c, int line, int col0,
-                                           int dcol, uint16_t (*T)[TW]) {
+                                           int dcol, uint16_t (*T)[TP]) {
     const auto Z = jb.Z + (size_t)orient * jb.znch * jb.zpitch + line;
     const auto Z16 = jb.Z16 + (size_t)orient * jb.zg * jb.zpitch + line;
     const uint32_t z = Z[(size_t)c * jb.zpitch];
@@ -250,9 +251,9 @@ __device__ __forceinline__ void diag_steps(const DtJobG& jb, const LineGeom& g, 
 #pragma unroll
     for (int r = 0; r < CH; r++) {
         run = (run + 1) & __builtin_amdgcn_sbfe(nz, r, 1);
-        const int col = col0 + dcol * r;
-        if (col < 0 || col >= TW) continue;
-        T[r][col] = (uint16_t)min(min(run, e[r]), 0xFFFF);
+        // a column outside the tile goes to one of the two pad columns beside it: a store per row, no branch
+        const int col = min(max(col0 + dcol * r, -1), TW);
+        T[r][TPAD + col] = (uint16_t)min(min(run, e[r]), 0xFFFF);
     }
 }
 
@@ -272,10 +273,10 @@ __global__ __launch_bounds__(DB_THREADS) void k_dt_diag_b(const DtJob* __restric
     if (!rows_needed && !cols_needed) return;
     // one tile per orientation; a pixel of the rectangle lies on exactly one line of each family,
     // pixels outside it keep "no zero" and are never stored
-    __shared__ __align__(16) uint16_t T[2][CH][TW];
+    __shared__ __align__(16) uint16_t T[2][CH][TP];
     const int i = threadIdx.x;
     if (jb.x0 > X || jb.x1 < X + TW) {
-        for (int e = i; e < 2 * CH * TW / 8; e += DB_THREADS) reinterpret_cast<uint4*>(&T[0][0][0])[e] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int e = i; e < 2 * CH * TP / 8; e += DB_THREADS) reinterpret_cast<uint4*>(&T[0][0][0])[e] = make_uint4(~0u, ~0u, ~0u, ~0u);
         __syncthreads();
     }
     if (i < TW + CH - 1) {
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(DB_THREADS) void k_dt_diag_b(const DtJob* __restric
             const int r = e / (TW / 8), q = e % (TW / 8);
             const int x = X + q * 8;
             if (x + 8 <= jb.x0 || x >= jb.x1) continue;
-            const uint4 a = *reinterpret_cast<const uint4*>(&T[0][r][q * 8]), b = *reinterpret_cast<const uint4*>(&T[1][r][q * 8]);
+            const uint4 a = *reinterpret_cast<const uint4*>(&T[0][r][TPAD + q * 8]), b = *reinterpret_cast<const uint4*>(&T[1][r][TPAD + q * 8]);
             store_u4(jb.S + (size_t)(ya + r) * jb.pitch + x, make_uint4(pk_min_u16(a.x, b.x), pk_min_u16(a.y, b.y),
                                                                       pk_min_u16(a.z, b.z), pk_min_u16(a.w, b.w)));
         }
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(DB_THREADS) void k_dt_diag_b(const DtJob* __restric
         for (int e = i; e < nrows * TW; e += DB_THREADS) {
             const int r = e / TW, x = X + e % TW;
             if (x < jb.x0 || x >= jb.x1) continue;
-            jb.S[(size_t)(ya + r) * jb.pitch + x] = min(T[0][r][e % TW], T[1][r][e % TW]);
+            jb.S[(size_t)(ya + r) * jb.pitch + x] = min(T[0][r][TPAD + e % TW], T[1][r][TPAD + e % TW]);
         }
     }
 }
