@@ -73,7 +73,6 @@ void carve_slot(rtvm_ctx* c, Carver& k, FrameSlot& S, int cap, int kind) {
     }
     if (kind == 1) {
         S.pyr = k.take<uint8_t>(c->orb_pyr_bytes);
-        S.pyr_blur = k.take<uint8_t>(c->orb_pyr_bytes);
         S.score = k.take<uint8_t>(c->orb_pyr_bytes);
         S.cand = k.take<uint32_t>(c->orb_cand_total);
         S.cand_count = k.take<int>(RTVM_NLEVELS + RTVM_NLEVELS * 256);
@@ -374,8 +373,6 @@ void free_all(rtvm_ctx* c) {
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
     free(c->recs);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
-    if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
-    if (c->ev_blur7) (void)hipEventDestroy(c->ev_blur7);
 }
 
 }  // namespace

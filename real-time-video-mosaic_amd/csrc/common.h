@@ -49,7 +49,6 @@ struct FeatSet {
 struct FrameSlot {
     const uint8_t* bgr;    // frame pixels (device)
     uint8_t* pyr;          // pyramid (un-blurred)
-    uint8_t* pyr_blur;     // pyramid after the 7x7 blur
     uint8_t* score;        // FAST score planes, same layout
     uint32_t* cand;        // candidates: packed (score << 24 | y << 12 | x)
     int* cand_count;       // RTVM_NLEVELS counters + RTVM_NLEVELS*256 histogram
@@ -297,7 +296,6 @@ struct rtvm_ctx {
     int rs_alone = 0;   // at most a batch's worth of frames in flight: latency is what counts (ransac.hip)
     hipEvent_t ev_done[RTVM_REPORTS];  // batch number (seq % RTVM_REPORTS) is complete
     hipEvent_t ev_main;
-    hipEvent_t ev_pyr, ev_blur7;   // ORB detection: the pyramid is complete / the blurred pyramid is (k_blur7 on a second stream)
     int back_rec[RTVM_NSETS];  // ev_back[k] has been recorded
     int set_next;              // slot set of the next pipelined batch
     int spec_tail;             // slot of the last frame of the batch queued before, -1 = none:

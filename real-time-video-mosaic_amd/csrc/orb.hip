@@ -10,8 +10,8 @@
 //                 of candidates + per-level score histogram
 //   k_orb_select  one workgroup per level: retainBest(2n) from the histogram, raster
 //                 sort (bitonic, LDS), Harris response, retainBest(n) by rank counting
-//   k_blur7       7x7 Gaussian (integer, exact), all levels in one launch
-//   k_orb_describe one wave per keypoint: intensity-centroid angle, steered BRIEF-256
+//   k_orb_describe one wave per keypoint: intensity-centroid angle, steered BRIEF-256 on the 7x7
+//                 Gaussian (integer, exact) of the level, evaluated at the points the tests read
 // All integer stages are exact; the float stages (Harris response, angle, pattern
 // rotation) follow OpenCV's operation order without fused multiply-add.
 #include "common.h"
@@ -665,113 +665,6 @@ __global__ __launch_bounds__(1024) void k_orb_select(OrbDev P, const FrameSlot* 
     if (tid == 0) sel_count[l] = min(s_base, out_cap);
 }
 
-// ------------------------------------------------------------------ blur
-// GaussianBlur(7x7, sigma 2) as ORB runs it on each level: integer taps
-// cvRound(k * 256), exact row and column sums, round half to even, saturate.
-// One workgroup per tile of 64 x 32 pixels.
-__global__ __launch_bounds__(256) void k_blur7(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
-    const FrameSlot& SL = slots[sb + blockIdx.y];
-    const uint8_t* __restrict__ pyr = SL.pyr;
-    uint8_t* __restrict__ out = SL.pyr_blur;
-    const int lin = xcd_tile(blockIdx.x, P.btile_off[RTVM_NLEVELS]);
-    if (lin < 0) return;
-    int l = 0;
-#pragma unroll
-    for (int k = 1; k < RTVM_NLEVELS; k++)
-        if (lin >= P.btile_off[k]) l = k;
-    const int local = lin - P.btile_off[l];
-    const int W = P.w[l], H = P.h[l], pitch = P.pitch[l];
-    const int tiles_x = (W + 63) / 64;
-    const int tx0 = (local % tiles_x) * 64, ty0 = (local / tiles_x) * 32;
-    const uint8_t* __restrict__ img = pyr + P.off[l];
-    // pixels: rows ty0-3 .. ty0+34, columns tx0-4 .. tx0+67 (LDS column = x - tx0 + 4)
-    __shared__ __align__(16) uint8_t s[38][72];
-    __shared__ __align__(16) uint32_t r[19][64];
-    const int tid = threadIdx.x;
-    if (tx0 >= 4 && tx0 + 68 <= W && ty0 >= 3 && ty0 + 35 <= H) {
-        for (int i = tid; i < 38 * 18; i += 256) {
-            const int rr = i / 18, q = i % 18;
-            *reinterpret_cast<uint32_t*>(&s[rr][4 * q]) =
-                *reinterpret_cast<const uint32_t*>(img + (size_t)(ty0 - 3 + rr) * pitch + tx0 - 4 + 4 * q);
-        }
-    } else {
-        for (int i = tid; i < 38 * 70; i += 256) {
-            const int rr = i / 70, c = i % 70;
-            const int y = reflect101(ty0 - 3 + rr, H), x = reflect101(tx0 - 3 + c, W);
-            s[rr][c + 1] = img[(size_t)y * pitch + x];
-        }
-    }
-    __syncthreads();
-    // The sums are dot products of byte and 16-bit vectors (exact in 32 bits):
-    //   row pass   7 taps on 7 consecutive bytes = two v_dot4_u32_u8 (the eighth tap is zero); a task takes
-    //              4 outputs of 2 rows from 12 staged bytes per row and stores, per column, the pair
-    //              {row 2p, row 2p + 1} of row sums as one word (a row sum is at most 255 * 257 = 65535)
-    //   column pass  7 taps on 7 consecutive rows = four v_dot2_u32_u16 on four such pairs (again with a zero
-    //              tap: at the end for an even output row, in front for an odd one); a thread takes 4 columns
-    //              x 2 rows from four 16-byte reads and stores one word per row
-    const uint32_t k0 = P.gk7[0], k1 = P.gk7[1], k2 = P.gk7[2], k3 = P.gk7[3], k4 = P.gk7[4], k5 = P.gk7[5], k6 = P.gk7[6];
-    const uint32_t tlo = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), thi = k4 | (k5 << 8) | (k6 << 16);
-    for (int i = tid; i < 19 * 16; i += 256) {
-        const int pr = i >> 4, g = i & 15;
-        uint32_t a[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t* w = reinterpret_cast<const uint32_t*>(&s[2 * pr + h][4 * g]);
-            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-            // output o: bytes o + 1 .. o + 7 of the twelve
-            a[h][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), thi,
-                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), tlo, 0u, false), false);
-            a[h][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), thi,
-                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), tlo, 0u, false), false);
-            a[h][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), thi,
-                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), tlo, 0u, false), false);
-            a[h][3] = __builtin_amdgcn_udot4(w2, thi, __builtin_amdgcn_udot4(w1, tlo, 0u, false), false);
-        }
-        *reinterpret_cast<uint4*>(&r[pr][4 * g]) = make_uint4(a[0][0] | (a[1][0] << 16), a[0][1] | (a[1][1] << 16),
-                                                              a[0][2] | (a[1][2] << 16), a[0][3] | (a[1][3] << 16));
-    }
-    __syncthreads();
-    const int cg = tid & 15, q = tid >> 4;
-    const int x = tx0 + 4 * cg, y = ty0 + 2 * q;
-    if (x >= W || y >= H) return;
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    // output row 2q: rows 2q .. 2q + 6 of the tile's 38; output row 2q + 1: rows 2q + 1 .. 2q + 7
-    const us2 e0 = {(unsigned short)k0, (unsigned short)k1}, e1 = {(unsigned short)k2, (unsigned short)k3},
-              e2 = {(unsigned short)k4, (unsigned short)k5}, e3 = {(unsigned short)k6, 0};
-    const us2 o0 = {0, (unsigned short)k0}, o1 = {(unsigned short)k1, (unsigned short)k2},
-              o2 = {(unsigned short)k3, (unsigned short)k4}, o3 = {(unsigned short)k5, (unsigned short)k6};
-    uint32_t v[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint4 u = *reinterpret_cast<const uint4*>(&r[q + j][4 * cg]);
-        v[j][0] = u.x, v[j][1] = u.y, v[j][2] = u.z, v[j][3] = u.w;
-    }
-    uint32_t oute = 0, outo = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const us2 p0 = __builtin_bit_cast(us2, v[0][c]), p1 = __builtin_bit_cast(us2, v[1][c]),
-                  p2 = __builtin_bit_cast(us2, v[2][c]), p3 = __builtin_bit_cast(us2, v[3][c]);
-        uint32_t ae = __builtin_amdgcn_udot2(p0, e0, 0u, false);
-        ae = __builtin_amdgcn_udot2(p1, e1, ae, false);
-        ae = __builtin_amdgcn_udot2(p2, e2, ae, false);
-        ae = __builtin_amdgcn_udot2(p3, e3, ae, false);
-        uint32_t ao = __builtin_amdgcn_udot2(p0, o0, 0u, false);
-        ao = __builtin_amdgcn_udot2(p1, o1, ao, false);
-        ao = __builtin_amdgcn_udot2(p2, o2, ao, false);
-        ao = __builtin_amdgcn_udot2(p3, o3, ao, false);
-        // sum / 65536 rounded half to even, saturated
-        const uint32_t qe = min((ae + 0x7FFFu + ((ae >> 16) & 1u)) >> 16, 255u);
-        const uint32_t qo = min((ao + 0x7FFFu + ((ao >> 16) & 1u)) >> 16, 255u);
-        oute |= qe << (8 * c);
-        outo |= qo << (8 * c);
-    }
-    // x is a multiple of 4 and the pitch a multiple of 64: aligned words; columns past the level's width
-    // land in the row padding
-    uint8_t* op = out + P.off[l] + (size_t)y * pitch + x;
-    *reinterpret_cast<uint32_t*>(op) = oute;
-    if (y + 1 < H) *reinterpret_cast<uint32_t*>(op + pitch) = outo;
-}
-
 // ------------------------------------------------------------------ describe
 __device__ float fast_atan2(float y, float x) {
     const float p1 = 0.9997878412794807f * (float)(180 / M_PI), p3 = -0.3258083974640975f * (float)(180 / M_PI);
@@ -798,7 +691,6 @@ __device__ float fast_atan2(float y, float x) {
 __global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* __restrict__ slots, int sb) {
     const FrameSlot& SL = slots[sb + blockIdx.y];
     const uint8_t* __restrict__ pyr = SL.pyr;
-    const uint8_t* __restrict__ blur = SL.pyr_blur;
     const int* __restrict__ sel_count = SL.sel_count;
     const int32_t* __restrict__ sel_lxy = SL.sel_lxy;
     const float* __restrict__ sel_resp = SL.sel_resp;
@@ -819,26 +711,22 @@ __global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* 
     const int x0 = sel_lxy[2 * (P.sel_off[l] + idx)], y0 = sel_lxy[2 * (P.sel_off[l] + idx) + 1];
     const int pitch = P.pitch[l];
     const uint8_t* img = pyr + P.off[l];
-    // The two patches the keypoint reads, as a few 16-byte loads into LDS instead of a byte gather per sample (a
-    // gather of 64 bytes from 64 rows touches 64 cache lines: the kernel was bound by that): 31 rows x 32 bytes of
-    // the level around (x0, y0) for the moments, DESC_R rows and columns on every side of the blurred level for the
-    // tests (the pattern's points lie within 18.4 pixels of the centre).  Keypoints keep 31 pixels from the border.
-    constexpr int DESC_R = 19, DESC_ROWS = 2 * DESC_R + 1, DESC_PITCH = 48;
-    __shared__ __align__(16) uint8_t s_img[31][32];
-    __shared__ __align__(16) uint8_t s_blur[DESC_ROWS][DESC_PITCH];
+    // The patch of the level the keypoint reads, as 16-byte loads into LDS instead of a byte gather per sample (a
+    // gather of 64 bytes from 64 rows touches 64 cache lines: the kernel was bound by that): DESC_R + 3 rows and
+    // DESC_R + 5 columns on every side of (x0, y0) and more to the right (rows of 64 bytes).  It serves the moments
+    // (radius 15) and the tests: the pattern's points lie within 18.4 pixels of the centre, and the 7 x 7 Gaussian
+    // of cv::ORB's blurred image is evaluated at the 512 points the tests read, not on the whole pyramid.
+    // Keypoints keep 31 pixels from the border, so neither the patch nor a 7 x 7 window meets a mirrored pixel
+    // (bytes past a row's 45th column are staged but never used; the plane has a spare row behind its last one).
+    constexpr int DESC_R = 19, PATCH_Y = DESC_R + 3, PATCH_X = DESC_R + 5, PATCH_ROWS = 2 * PATCH_Y + 1, PATCH_PITCH = 64;
+    __shared__ __align__(16) uint8_t s_raw[PATCH_ROWS][PATCH_PITCH];
     {
         typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
-        if (lane < 62) {
-            const int r = lane >> 1, hf = lane & 1;
-            const uint8_t* g = img + (size_t)(y0 - 15 + r) * pitch + (x0 - 15 + 16 * hf);
-            *reinterpret_cast<u32x4*>(&s_img[r][16 * hf]) = *reinterpret_cast<const u32x4u*>(g);
-        }
-        const uint8_t* bl = blur + P.off[l];
 #pragma unroll
-        for (int i = lane; i < 3 * DESC_ROWS; i += 64) {
-            const int r = i / 3, sg = i - 3 * r;
-            const uint8_t* g = bl + (size_t)(y0 - DESC_R + r) * pitch + (x0 - DESC_R + 16 * sg);
-            *reinterpret_cast<u32x4*>(&s_blur[r][16 * sg]) = *reinterpret_cast<const u32x4u*>(g);
+        for (int i = lane; i < 4 * PATCH_ROWS; i += 64) {
+            const int r = i >> 2, sg = i & 3;
+            const uint8_t* g = img + (size_t)(y0 - PATCH_Y + r) * pitch + (x0 - PATCH_X + 16 * sg);
+            *reinterpret_cast<u32x4*>(&s_raw[r][16 * sg]) = *reinterpret_cast<const u32x4u*>(g);
         }
     }
     wave_lds_phase();
@@ -850,7 +738,7 @@ __global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* 
         int sum = 0;
 #pragma unroll
         for (int u = -15; u <= 15; u++) {
-            const int raw = s_img[lane][15 + u];   // read unconditionally: no branch per sample
+            const int raw = s_raw[PATCH_Y - 15 + lane][PATCH_X + u];   // read unconditionally: no branch per sample
             const int val = (u < 0 ? -u : u) <= d ? raw : 0;
             m10 += u * val;
             sum += val;
@@ -877,6 +765,26 @@ __global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* 
     float ang = angle;
     ang *= (float)(M_PI / 180.f);
     const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    // cv::GaussianBlur(7 x 7, sigma 2) of the level at patch position (ix, iy) relative to the keypoint: seven
+    // row sums of seven bytes (two v_dot4_u32_u8 on the bytes cut from three aligned words), their weighted sum,
+    // divided by 65536 with halves rounded to even and saturated - k_blur7's arithmetic at one point.
+    const uint32_t k0 = P.gk7[0], k1 = P.gk7[1], k2 = P.gk7[2], k3 = P.gk7[3], k4 = P.gk7[4], k5 = P.gk7[5], k6 = P.gk7[6];
+    const uint32_t tlo = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), thi = k4 | (k5 << 8) | (k6 << 16);
+    auto blurred = [&](int ix, int iy) -> int {
+        const int c = ix + PATCH_X - 3, r = iy + PATCH_Y - 3;   // first byte and first row of the window
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_raw[r][c & ~3]);
+        const uint32_t sh = (uint32_t)(c & 3);
+        const uint32_t kt[7] = {k0, k1, k2, k3, k4, k5, k6};
+        uint32_t acc = 0;
+#pragma unroll
+        for (int t = 0; t < 7; t++) {
+            const uint32_t w0 = w[t * (PATCH_PITCH / 4)], w1 = w[t * (PATCH_PITCH / 4) + 1], w2 = w[t * (PATCH_PITCH / 4) + 2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi4 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            const uint32_t rs = __builtin_amdgcn_udot4(hi4, thi, __builtin_amdgcn_udot4(lo, tlo, 0u, false), false);
+            acc += kt[t] * rs;
+        }
+        return (int)min((acc + 0x7FFFu + ((acc >> 16) & 1u)) >> 16, 255u);
+    };
     unsigned nib = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -887,8 +795,8 @@ __global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* 
         // (the clamps never bind: they keep an index inside the patch whatever the arithmetic does)
         const int ix1 = min(max(__float2int_rn(x1), -DESC_R), DESC_R), iy1 = min(max(__float2int_rn(y1), -DESC_R), DESC_R);
         const int ix2 = min(max(__float2int_rn(x2), -DESC_R), DESC_R), iy2 = min(max(__float2int_rn(y2), -DESC_R), DESC_R);
-        const int t0 = s_blur[iy1 + DESC_R][ix1 + DESC_R];
-        const int t1 = s_blur[iy2 + DESC_R][ix2 + DESC_R];
+        const int t0 = blurred(ix1, iy1);
+        const int t1 = blurred(ix2, iy2);
         nib |= (unsigned)(t0 < t1) << t;
     }
     const unsigned hi = __shfl_down(nib, 1);
@@ -1057,31 +965,7 @@ int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
     if (P.tile_off[RTVM_NLEVELS] > 0) {
         RTVM_LAUNCH(c, k_fast, dim3(xcd_grid_runs(P.tile_off[RTVM_NLEVELS]), nb), dim3(256), 0, P, sl, sb);
     }
-    // The blurred pyramid needs the pyramid only.  On a context with several streams it is computed on the
-    // RANSAC search stream beside the selection (k_orb_select is one workgroup per level and frame: latency,
-    // not work; beside k_fast, which fills the device, it would gain nothing), and the descriptors wait for
-    // both.  That stream's order stays what the data flow is anyway: the hypothesis search of these frames is
-    // queued after their matching.
-    const bool fork = c->stream_rs && c->stream_rs != c->stream;
-    if (fork) {
-        if (!c->ev_pyr) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming));
-        if (!c->ev_blur7) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_blur7, hipEventDisableTiming));
-        HIP_TRY(c, hipEventRecord(c->ev_pyr, c->stream));
-        hipStream_t back = c->stream;
-        c->stream = c->stream_rs;
-        hipError_t e = hipStreamWaitEvent(c->stream, c->ev_pyr, 0);
-        if (e == hipSuccess) {
-            RTVM_LAUNCH(c, k_blur7, dim3(xcd_grid(P.btile_off[RTVM_NLEVELS]), nb), dim3(256), 0, P, sl, sb);
-            e = hipEventRecord(c->ev_blur7, c->stream);
-        }
-        c->stream = back;
-        HIP_TRY(c, e);
-    }
     RTVM_LAUNCH(c, k_orb_select, dim3(RTVM_NLEVELS, nb), dim3(1024), 0, P, sl, sb);
-    if (fork)
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_blur7, 0));
-    else
-        RTVM_LAUNCH(c, k_blur7, dim3(xcd_grid(P.btile_off[RTVM_NLEVELS]), nb), dim3(256), 0, P, sl, sb);
     RTVM_LAUNCH(c, k_orb_describe, dim3(P.max_kp, nb), dim3(64), 0, P, sl, sb);
     HIP_TRY(c, hipGetLastError());
     return RTVM_OK;
