@@ -12,7 +12,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librtvm.so")
-# Canvas-half pieces Context.process_video keeps queued: the outcome of a piece is read while the next one runs.  A
+# Canvas-half pieces Context.process_video keeps queued for frames resident on the device (one more when the
+# frames come from host memory through the ingest ring): the outcome of a piece is read while the next one runs.  A
 # third one only adds a piece that did nothing (and its launches) to every mispredicted canvas mask: measured
 # 17 450 frames/s with three, 17 720 with two, 17 350 with four (720p ORB-1000).
 PIECES_IN_FLIGHT = 2
@@ -754,6 +755,8 @@ class Context:
         cb = max(1, min(batch, canvas_batch if canvas_batch else (batch + 1) // 2))
         # a frame source (HostFrameRing) hands out device addresses batch by batch; a list has them all
         acquire = getattr(bgr_dev_ptrs, "acquire", None) or (lambda first, k: bgr_dev_ptrs[first:first + k])
+        # a frame source copies host frames while pieces run: one piece more keeps the device busy meanwhile
+        in_flight = PIECES_IN_FLIGHT + 1 if getattr(bgr_dev_ptrs, "acquire", None) else PIECES_IN_FLIGHT
         status = np.zeros(n, np.int32)
         det = []     # detected batches, oldest first: [detect ticket, first frame, length, frames queued, frames consumed]
         inb = []     # canvas-half pieces in flight, oldest first: (batch entry, piece ticket, first frame of the batch, length)
@@ -789,7 +792,7 @@ class Context:
                 stats["batches_queued"] += 1
                 stats["frames_queued"] += k
                 nxt += k
-            while len(inb) < PIECES_IN_FLIGHT:
+            while len(inb) < in_flight:
                 e = next((r for r in det if r[3] < r[2]), None)
                 if e is None:
                     break
