@@ -42,18 +42,25 @@ __global__ __launch_bounds__(64) void k_hamming_argmin(const FrameSlot* __restri
     const uint4 a_lo = pa[0], a_hi = pa[1];
     const uint4 b_lo = pb[0], b_hi = pb[1];
     const int nb = min(64, nB - b0);
+    // the tile's 64 rows of B go through LDS: every lane reads row k as two 16-byte broadcast reads (eight
+    // v_readlane per row took three times as long as the instructions they feed)
+    __shared__ __align__(16) uint4 s_b[64][2];
+    s_b[lane][0] = b_lo;
+    s_b[lane][1] = b_hi;
+    wave_lds_phase();
     uint32_t best = 0xFFFFFFFFu;
 #pragma unroll 8
     for (int k = 0; k < 64; k++) {
+        const uint4 r_lo = s_b[k][0], r_hi = s_b[k][1];
         uint32_t d;
-        d = __popc(a_lo.x ^ (uint32_t)__builtin_amdgcn_readlane((int)b_lo.x, k));
-        d += __popc(a_lo.y ^ (uint32_t)__builtin_amdgcn_readlane((int)b_lo.y, k));
-        d += __popc(a_lo.z ^ (uint32_t)__builtin_amdgcn_readlane((int)b_lo.z, k));
-        d += __popc(a_lo.w ^ (uint32_t)__builtin_amdgcn_readlane((int)b_lo.w, k));
-        d += __popc(a_hi.x ^ (uint32_t)__builtin_amdgcn_readlane((int)b_hi.x, k));
-        d += __popc(a_hi.y ^ (uint32_t)__builtin_amdgcn_readlane((int)b_hi.y, k));
-        d += __popc(a_hi.z ^ (uint32_t)__builtin_amdgcn_readlane((int)b_hi.z, k));
-        d += __popc(a_hi.w ^ (uint32_t)__builtin_amdgcn_readlane((int)b_hi.w, k));
+        d = __popc(a_lo.x ^ r_lo.x);
+        d += __popc(a_lo.y ^ r_lo.y);
+        d += __popc(a_lo.z ^ r_lo.z);
+        d += __popc(a_lo.w ^ r_lo.w);
+        d += __popc(a_hi.x ^ r_hi.x);
+        d += __popc(a_hi.y ^ r_hi.y);
+        d += __popc(a_hi.z ^ r_hi.z);
+        d += __popc(a_hi.w ^ r_hi.w);
         // rows past the end of B were loaded clamped; keep them out of the minimum
         best = min(best, k < nb ? ((d << 16) | (uint32_t)(b0 + k)) : 0xFFFFFFFFu);
     }
