@@ -325,6 +325,8 @@ struct rtvm_ctx {
     uint8_t* d_bgr;        // staging frame fh*fw*3
     uint16_t* d_xofs;      // resize tables
     uint16_t* d_xw;
+    uint32_t* d_xsel;      // per output column: byte selector of its two taps within the eight bytes from its quad's first source
+    uint32_t* d_xwp;       // per output column: the two horizontal weights as 16-bit halves {256 - w, w}
     uint16_t* d_yofs;
     uint16_t* d_yw;
     FrameSlot* h_slots;    // host mirror of d_slots (RTVM_MAX_SLOTS + 1 entries)

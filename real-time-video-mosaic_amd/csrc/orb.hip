@@ -202,7 +202,8 @@ __host__ __device__ inline void rc_regions(const OrbDev& P, int a, int n, int tx
 // from memory and no launch waits for another.  The host has checked that every rectangle fits RC_BUF.
 template <int N>
 __global__ __launch_bounds__(256) void k_resize_chain(const OrbDev P, const FrameSlot* __restrict__ slots, int sb, int a,
-                                                      const uint16_t* __restrict__ xofs, const uint16_t* __restrict__ xw,
+                                                      const uint16_t* __restrict__ xofs, const uint32_t* __restrict__ xsel,
+                                                      const uint32_t* __restrict__ xwp,
                                                       const uint16_t* __restrict__ yofs, const uint16_t* __restrict__ yw) {
     __shared__ __align__(16) uint8_t s_buf[2][RC_BUF];
     __shared__ RcRegion s_reg[N + 1];
@@ -235,12 +236,14 @@ __global__ __launch_bounds__(256) void k_resize_chain(const OrbDev P, const Fram
         uint8_t* __restrict__ dbuf = s_buf[k & 1];
         uint8_t* __restrict__ dst = S.pyr + P.off[j];
         const uint16_t* __restrict__ xo_t = xofs + P.xtab_off[j];
-        const uint16_t* __restrict__ xw_t = xw + P.xtab_off[j];
+        const uint32_t* __restrict__ xs_t = xsel + P.xtab_off[j];
+        const uint32_t* __restrict__ xp_t = xwp + P.xtab_off[j];
         const uint16_t* __restrict__ yo_t = yofs + P.ytab_off[j];
         const uint16_t* __restrict__ yw_t = yw + P.ytab_off[j];
         const int dp = P.pitch[j], dh = P.h[j];
         const int qw = R.w >> 2, nq = qw * R.h;
         const float inv = __builtin_amdgcn_rcpf((float)qw);
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         for (int i = tid; i < nq; i += 256) {
             const int r = (int)(((float)i + 0.5f) * inv), q = i - r * qw;
             const int x = R.x0 + 4 * q, y = R.y0 + r;   // x < w4: the tables are padded to there
@@ -248,20 +251,25 @@ __global__ __launch_bounds__(256) void k_resize_chain(const OrbDev P, const Fram
             const int yo = yo_t[yc];
             const unsigned cyr = yw_t[yc];
             const unsigned cy = cyr == 0xFFFFu ? 0u : cyr;
-            const int r0 = (yo - U.y0) * U.w - U.x0, r1 = cyr == 0xFFFFu ? r0 : r0 + U.w;
-            const uint2 xo4 = *reinterpret_cast<const uint2*>(xo_t + x), xw4 = *reinterpret_cast<const uint2*>(xw_t + x);
+            // The four outputs read at most six consecutive bytes of a row, from the quad's first source on: the
+            // eight bytes from there are cut out of three aligned words, an output's two taps out of those by a
+            // byte selector from the table (as 16-bit halves), and the horizontal sum is one v_dot2_u32_u16 with
+            // the output's weight pair {256 - w, w} (a clamped single tap: the same byte twice, weights {256, 0}).
+            const int b0 = (yo - U.y0) * U.w - U.x0 + (int)xo_t[x], b1 = cyr == 0xFFFFu ? b0 : b0 + U.w;
+            const uint4 sel4 = *reinterpret_cast<const uint4*>(xs_t + x), wp4 = *reinterpret_cast<const uint4*>(xp_t + x);
+            const uint32_t* w0p = reinterpret_cast<const uint32_t*>(sbuf + (b0 & ~3));
+            const uint32_t* w1p = reinterpret_cast<const uint32_t*>(sbuf + (b1 & ~3));
+            const uint32_t sh = (uint32_t)(b0 & 3);   // the rows of a rectangle are a multiple of 4 bytes apart
+            const uint32_t lo0 = __builtin_amdgcn_alignbyte(w0p[1], w0p[0], sh), hi0 = __builtin_amdgcn_alignbyte(w0p[2], w0p[1], sh);
+            const uint32_t lo1 = __builtin_amdgcn_alignbyte(w1p[1], w1p[0], sh), hi1 = __builtin_amdgcn_alignbyte(w1p[2], w1p[1], sh);
+            const uint32_t sels[4] = {sel4.x, sel4.y, sel4.z, sel4.w}, wps[4] = {wp4.x, wp4.y, wp4.z, wp4.w};
             uint32_t word = 0;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const unsigned xo = ((e < 2 ? xo4.x : xo4.y) >> (16 * (e & 1))) & 0xFFFFu;
-                const unsigned cxr = ((e < 2 ? xw4.x : xw4.y) >> (16 * (e & 1))) & 0xFFFFu;
-                const unsigned cx = cxr == 0xFFFFu ? 0u : cxr;
-                const unsigned xo1 = cxr == 0xFFFFu ? xo : xo + 1;
-                const unsigned a00 = sbuf[r0 + (int)xo], a01 = sbuf[r0 + (int)xo1];
-                const unsigned a10 = sbuf[r1 + (int)xo], a11 = sbuf[r1 + (int)xo1];
-                // 9-bit weights, 8- and 16-bit values: 24-bit multiplies
-                const unsigned h0 = __umul24(256u - cx, a00) + __umul24(cx, a01);
-                const unsigned h1 = __umul24(256u - cx, a10) + __umul24(cx, a11);
+                const us2 wp = __builtin_bit_cast(us2, wps[e]);
+                const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi0, lo0, sels[e])), wp, 0u, false);
+                const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi1, lo1, sels[e])), wp, 0u, false);
+                // 9-bit weights, 16-bit sums: 24-bit multiplies
                 unsigned v = __umul24(256u - cy, h0) + __umul24(cy, h1);
                 v = (v + 32768u) >> 16;
                 word |= (v > 255u ? 255u : v) << (8 * e);
@@ -925,9 +933,25 @@ int rtvm_orb_setup(rtvm_ctx* c) {
     HIP_TRY(c, hipMemcpy(c->d_xw, xw.data(), xw.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_yofs, yo.data(), yo.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_yw, yw.data(), yw.size() * 2, hipMemcpyHostToDevice));
+    // The chained resize takes an output's taps out of the eight bytes that start at its quad's first source
+    bool sel_ok = true;
+    std::vector<uint32_t> xsel(c->orb_xtab_total + 4, 0u), xwp(c->orb_xtab_total + 4, 0u);
+    for (int l = 1; l < RTVM_NLEVELS; l++)
+        for (int v = 0; v < ((P.w[l] + 3) & ~3) + 4; v++) {
+            const int t = P.xtab_off[l] + v;
+            const int off = (int)xo[t] - (int)xo[P.xtab_off[l] + (v & ~3)];
+            const bool single = xw[t] == 0xFFFFu;
+            const int off1 = single ? off : off + 1;
+            if (off < 0 || off1 > 7) sel_ok = false;
+            xsel[t] = 0x0c000c00u | ((uint32_t)(off1 & 7) << 16) | (uint32_t)(off & 7);
+            const uint32_t cx = single ? 0u : xw[t];
+            xwp[t] = (256u - cx) | (cx << 16);
+        }
+    HIP_TRY(c, hipMemcpy(c->d_xsel, xsel.data(), xsel.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_xwp, xwp.data(), xwp.size() * 4, hipMemcpyHostToDevice));
     // Levels 1-3 and 4-7 as two chained launches when every rectangle of every tile fits the staging
     // buffers (any frame size the pyramid factor 1.2 leaves above a few pixels); else level by level.
-    c->orb_chain = 1;
+    c->orb_chain = sel_ok ? 1 : 0;
     const int chain_a[2] = {0, 3}, chain_n[2] = {3, 4};
     for (int g = 0; g < 2 && c->orb_chain; g++) {
         const int a = chain_a[g], n = chain_n[g], b = a + n;
@@ -937,7 +961,7 @@ int rtvm_orb_setup(rtvm_ctx* c) {
                 RcRegion R[RC_MAXN + 1];
                 rc_regions(P, a, n, tx, ty, xo.data(), yo.data(), R);
                 for (int k = 0; k <= n; k++)
-                    if (R[k].w <= 0 || R[k].h <= 0 || R[k].w * R[k].h > RC_BUF || R[k].x0 < 0 || R[k].y0 < 0 ||
+                    if (R[k].w <= 0 || R[k].h <= 0 || R[k].w * R[k].h + 16 > RC_BUF || R[k].x0 < 0 || R[k].y0 < 0 ||
                         R[k].x0 + R[k].w > P.pitch[a + k] || R[k].w * R[k].h / 4 >= 4096)
                         c->orb_chain = 0;
             }
@@ -954,9 +978,9 @@ int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
     if (c->orb_chain) {
         static_assert(RTVM_NLEVELS == 8, "the chains cover levels 1-3 and 4-7");
         RTVM_LAUNCH(c, k_resize_chain<3>, dim3(xcd_grid(((P.w[3] + RC_TW - 1) / RC_TW) * ((P.h[3] + RC_TH - 1) / RC_TH)), 1, nb),
-                    dim3(256), 0, P, sl, sb, 0, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw);
+                    dim3(256), 0, P, sl, sb, 0, c->d_xofs, c->d_xsel, c->d_xwp, c->d_yofs, c->d_yw);
         RTVM_LAUNCH(c, k_resize_chain<4>, dim3(xcd_grid(((P.w[7] + RC_TW - 1) / RC_TW) * ((P.h[7] + RC_TH - 1) / RC_TH)), 1, nb),
-                    dim3(256), 0, P, sl, sb, 3, c->d_xofs, c->d_xw, c->d_yofs, c->d_yw);
+                    dim3(256), 0, P, sl, sb, 3, c->d_xofs, c->d_xsel, c->d_xwp, c->d_yofs, c->d_yw);
     } else
     for (int l = 1; l < RTVM_NLEVELS; l++)
         RTVM_LAUNCH(c, k_resize, dim3(xcd_grid(((P.w[l] + 63) / 64) * ((P.h[l] + 15) / 16)), 1, nb), dim3(256), 0, sl, sb, P.off[l - 1],
