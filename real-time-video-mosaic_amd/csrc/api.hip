@@ -315,6 +315,10 @@ int alloc_all(rtvm_ctx* c) {
         ALLOC(c, d_xofs, c->orb_xtab_total + 1);
         ALLOC(c, d_xw, c->orb_xtab_total + 1);
         ALLOC(c, d_xsel, c->orb_xtab_total + 4);
+        {
+            int r_ = dev_alloc(c, (uint8_t**)&c->d_rc_regions, (size_t)(c->orb_rc_total + 1) * 32);
+            if (r_ != RTVM_OK) return r_;
+        }
         ALLOC(c, d_xwp, c->orb_xtab_total + 4);
         ALLOC(c, d_yofs, c->orb_ytab_total + 1);
         ALLOC(c, d_yw, c->orb_ytab_total + 1);
@@ -352,7 +356,7 @@ void free_all(rtvm_ctx* c) {
     c->ingest_slots = 0;
     void* ptrs[] = {c->d_slots, c->d_mq, c->d_mt, c->d_mcount, c->d_bgr, c->d_canvas,
                     c->d_mask_old, c->d_bold, c->d_snap_canvas, c->d_snap_mask, c->d_side, c->d_snap, c->d_gk, c->d_H,
-                    c->d_wp, c->d_cbox, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_work, c->d_xofs, c->d_xw, c->d_xsel, c->d_xwp, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
+                    c->d_wp, c->d_cbox, c->d_jobs, c->d_rs_raw, c->d_lq, c->d_lt, c->d_l_idx, c->d_l_dist, c->d_l_work, c->d_xofs, c->d_xw, c->d_xsel, c->d_xwp, c->d_rc_regions, c->d_yofs, c->d_yw, c->d_state, c->d_wtab,
                     c->d_skip};
     free_feat(&c->feat_prev);
     for (void* p : ptrs)

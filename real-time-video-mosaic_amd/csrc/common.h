@@ -325,6 +325,8 @@ struct rtvm_ctx {
     uint8_t* d_bgr;        // staging frame fh*fw*3
     uint16_t* d_xofs;      // resize tables
     uint16_t* d_xw;
+    void* d_rc_regions;    // the chained resize's rectangles per tile and level (RcRegion, orb.hip), both chains
+    int orb_rc_total;      // number of them
     uint32_t* d_xsel;      // per output column: byte selector of its two taps within the eight bytes from its quad's first source
     uint32_t* d_xwp;       // per output column: the two horizontal weights as 16-bit halves {256 - w, w}
     uint16_t* d_yofs;

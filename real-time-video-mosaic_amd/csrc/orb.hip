@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void k_resize(const FrameSlot* __restrict__ sl
 struct RcRegion {
     int x0, y0, w, h, ox0, oy0, ox1, oy1;
 };
+static_assert(sizeof(RcRegion) == 32, "the context reserves 32 bytes per rectangle");
 
 constexpr int RC_TW = 64, RC_TH = 16;  // tile of the chain's last level
 constexpr int RC_MAXN = 4;             // levels per chain
@@ -204,7 +205,8 @@ template <int N>
 __global__ __launch_bounds__(256) void k_resize_chain(const OrbDev P, const FrameSlot* __restrict__ slots, int sb, int a,
                                                       const uint16_t* __restrict__ xofs, const uint32_t* __restrict__ xsel,
                                                       const uint32_t* __restrict__ xwp,
-                                                      const uint16_t* __restrict__ yofs, const uint16_t* __restrict__ yw) {
+                                                      const uint16_t* __restrict__ yofs, const uint16_t* __restrict__ yw,
+                                                      const RcRegion* __restrict__ regions) {
     __shared__ __align__(16) uint8_t s_buf[2][RC_BUF];
     __shared__ RcRegion s_reg[N + 1];
     const FrameSlot& S = slots[sb + blockIdx.z];
@@ -213,7 +215,8 @@ __global__ __launch_bounds__(256) void k_resize_chain(const OrbDev P, const Fram
     const int tile = xcd_tile(blockIdx.x, tiles_x * ((P.h[b] + RC_TH - 1) / RC_TH));
     if (tile < 0) return;
     const int tid = threadIdx.x;
-    if (tid == 0) rc_regions(P, a, N, (tile % tiles_x) * RC_TW, (tile / tiles_x) * RC_TH, xofs, yofs, s_reg);
+    // the tile's rectangles, computed by the host at set-up with rc_regions (a chain of dependent table look-ups)
+    if (tid <= N) s_reg[tid] = regions[tile * (N + 1) + tid];
     __syncthreads();
     {   // level a: the rectangle from memory, aligned words, clamped to the plane
         const RcRegion R = s_reg[0];
@@ -871,6 +874,8 @@ int rtvm_orb_plan(rtvm_ctx* c) {
     P.tile_off[RTVM_NLEVELS] = tiles;
     P.btile_off[RTVM_NLEVELS] = btiles;
     c->orb_pyr_bytes = off;
+    c->orb_rc_total = ((P.w[3] + RC_TW - 1) / RC_TW) * ((P.h[3] + RC_TH - 1) / RC_TH) * 4 +
+                      ((P.w[7] + RC_TW - 1) / RC_TW) * ((P.h[7] + RC_TH - 1) / RC_TH) * 5;
     c->orb_cand_total = cand;
     c->orb_xtab_total = xt;
     c->orb_ytab_total = yt;
@@ -953,19 +958,25 @@ int rtvm_orb_setup(rtvm_ctx* c) {
     // buffers (any frame size the pyramid factor 1.2 leaves above a few pixels); else level by level.
     c->orb_chain = sel_ok ? 1 : 0;
     const int chain_a[2] = {0, 3}, chain_n[2] = {3, 4};
-    for (int g = 0; g < 2 && c->orb_chain; g++) {
+    std::vector<RcRegion> regs;
+    regs.reserve(c->orb_rc_total + 1);
+    for (int g = 0; g < 2; g++) {
         const int a = chain_a[g], n = chain_n[g], b = a + n;
         if (P.w[b] < 8 || P.h[b] < 8) c->orb_chain = 0;
-        for (int ty = 0; ty < P.h[b] && c->orb_chain; ty += RC_TH)
-            for (int tx = 0; tx < P.w[b] && c->orb_chain; tx += RC_TW) {
+        for (int ty = 0; ty < P.h[b]; ty += RC_TH)      // tiles in the kernel's order
+            for (int tx = 0; tx < P.w[b]; tx += RC_TW) {
                 RcRegion R[RC_MAXN + 1];
                 rc_regions(P, a, n, tx, ty, xo.data(), yo.data(), R);
-                for (int k = 0; k <= n; k++)
+                for (int k = 0; k <= n; k++) {
                     if (R[k].w <= 0 || R[k].h <= 0 || R[k].w * R[k].h + 16 > RC_BUF || R[k].x0 < 0 || R[k].y0 < 0 ||
                         R[k].x0 + R[k].w > P.pitch[a + k] || R[k].w * R[k].h / 4 >= 4096)
                         c->orb_chain = 0;
+                    regs.push_back(R[k]);
+                }
             }
     }
+    if ((int)regs.size() != c->orb_rc_total) RTVM_FAIL(c, RTVM_E_STATE, "resize chain: %d rectangles, %d planned", (int)regs.size(), c->orb_rc_total);
+    HIP_TRY(c, hipMemcpy(c->d_rc_regions, regs.data(), regs.size() * sizeof(RcRegion), hipMemcpyHostToDevice));
     return RTVM_OK;
 }
 
@@ -978,9 +989,10 @@ int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
     if (c->orb_chain) {
         static_assert(RTVM_NLEVELS == 8, "the chains cover levels 1-3 and 4-7");
         RTVM_LAUNCH(c, k_resize_chain<3>, dim3(xcd_grid(((P.w[3] + RC_TW - 1) / RC_TW) * ((P.h[3] + RC_TH - 1) / RC_TH)), 1, nb),
-                    dim3(256), 0, P, sl, sb, 0, c->d_xofs, c->d_xsel, c->d_xwp, c->d_yofs, c->d_yw);
+                    dim3(256), 0, P, sl, sb, 0, c->d_xofs, c->d_xsel, c->d_xwp, c->d_yofs, c->d_yw, (const RcRegion*)c->d_rc_regions);
         RTVM_LAUNCH(c, k_resize_chain<4>, dim3(xcd_grid(((P.w[7] + RC_TW - 1) / RC_TW) * ((P.h[7] + RC_TH - 1) / RC_TH)), 1, nb),
-                    dim3(256), 0, P, sl, sb, 3, c->d_xofs, c->d_xsel, c->d_xwp, c->d_yofs, c->d_yw);
+                    dim3(256), 0, P, sl, sb, 3, c->d_xofs, c->d_xsel, c->d_xwp, c->d_yofs, c->d_yw,
+                    (const RcRegion*)c->d_rc_regions + ((P.w[3] + RC_TW - 1) / RC_TW) * ((P.h[3] + RC_TH - 1) / RC_TH) * 4);
     } else
     for (int l = 1; l < RTVM_NLEVELS; l++)
         RTVM_LAUNCH(c, k_resize, dim3(xcd_grid(((P.w[l] + 63) / 64) * ((P.h[l] + 15) / 16)), 1, nb), dim3(256), 0, sl, sb, P.off[l - 1],
