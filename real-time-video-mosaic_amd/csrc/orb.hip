@@ -148,7 +148,10 @@ static_assert(sizeof(RcRegion) == 32, "the context reserves 32 bytes per rectang
 
 constexpr int RC_TW = 64, RC_TH = 16;  // tile of the chain's last level
 constexpr int RC_MAXN = 4;             // levels per chain
-constexpr int RC_BUF = 12288;          // bytes per staging buffer (two: the levels alternate between them)
+// bytes of the two staging buffers (the levels alternate between them; the chain's source level, the largest
+// rectangle, is in the first) of the chain of three levels and of the chain of four: sized for the pyramid factor
+// 1.2 with a margin, so that LDS does not limit the workgroups per CU; the host checks every tile against them
+constexpr int RC3_B0 = 6144, RC3_B1 = 4096, RC4_B0 = 9216, RC4_B1 = 6144;
 
 // Rectangles of levels a .. a+n (R[0] .. R[n]) for tile (tx0, ty0) of level a+n.  Level j+1 reads level j
 // through the tables xofs/yofs (+ tab_off[j+1]): a workgroup computes of every level what its next level
@@ -200,14 +203,16 @@ __host__ __device__ inline void rc_regions(const OrbDev& P, int a, int n, int tx
 // rectangle of level a under it in LDS and resizes level by level from LDS to LDS (k_resize's arithmetic),
 // four pixels of a row per thread, storing the pixels it owns as words.  What neighbouring workgroups both
 // need of a level both compute (about a third more pixels than the levels have); no level is read back
-// from memory and no launch waits for another.  The host has checked that every rectangle fits RC_BUF.
+// from memory and no launch waits for another.  The host has checked every rectangle against its staging buffer.
 template <int N>
 __global__ __launch_bounds__(256) void k_resize_chain(const OrbDev P, const FrameSlot* __restrict__ slots, int sb, int a,
                                                       const uint16_t* __restrict__ xofs, const uint32_t* __restrict__ xsel,
                                                       const uint32_t* __restrict__ xwp,
                                                       const uint16_t* __restrict__ yofs, const uint16_t* __restrict__ yw,
                                                       const RcRegion* __restrict__ regions) {
-    __shared__ __align__(16) uint8_t s_buf[2][RC_BUF];
+    constexpr int B0 = N == 3 ? RC3_B0 : RC4_B0, B1 = N == 3 ? RC3_B1 : RC4_B1;
+    static_assert(N == 3 || N == 4, "staging buffers exist for the chains of three and of four levels");
+    __shared__ __align__(16) uint8_t s_buf0[B0], s_buf1[B1];
     __shared__ RcRegion s_reg[N + 1];
     const FrameSlot& S = slots[sb + blockIdx.z];
     const int b = a + N;
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(256) void k_resize_chain(const OrbDev P, const Fram
         for (int i = tid; i < nq; i += 256) {
             const int r = (int)(((float)i + 0.5f) * inv), q = i - r * qw;   // i / qw: exact for these sizes
             const int y = min(R.y0 + r, sh - 1), x = min(R.x0 + 4 * q, sp - 4);
-            *reinterpret_cast<uint32_t*>(&s_buf[0][r * R.w + 4 * q]) = *reinterpret_cast<const uint32_t*>(src + (unsigned)(y * sp + x));
+            *reinterpret_cast<uint32_t*>(&s_buf0[r * R.w + 4 * q]) = *reinterpret_cast<const uint32_t*>(src + (unsigned)(y * sp + x));
         }
     }
     __syncthreads();
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(256) void k_resize_chain(const OrbDev P, const Fram
     for (int k = 1; k <= N; k++) {
         const int j = a + k;
         const RcRegion R = s_reg[k], U = s_reg[k - 1];   // this level, the level it reads
-        const uint8_t* __restrict__ sbuf = s_buf[(k - 1) & 1];
-        uint8_t* __restrict__ dbuf = s_buf[k & 1];
+        const uint8_t* __restrict__ sbuf = ((k - 1) & 1) ? s_buf1 : s_buf0;
+        uint8_t* __restrict__ dbuf = (k & 1) ? s_buf1 : s_buf0;
         uint8_t* __restrict__ dst = S.pyr + P.off[j];
         const uint16_t* __restrict__ xo_t = xofs + P.xtab_off[j];
         const uint32_t* __restrict__ xs_t = xsel + P.xtab_off[j];
@@ -968,7 +973,8 @@ int rtvm_orb_setup(rtvm_ctx* c) {
                 RcRegion R[RC_MAXN + 1];
                 rc_regions(P, a, n, tx, ty, xo.data(), yo.data(), R);
                 for (int k = 0; k <= n; k++) {
-                    if (R[k].w <= 0 || R[k].h <= 0 || R[k].w * R[k].h + 16 > RC_BUF || R[k].x0 < 0 || R[k].y0 < 0 ||
+                    const int room = (k & 1) ? (n == 3 ? RC3_B1 : RC4_B1) : (n == 3 ? RC3_B0 : RC4_B0);
+                    if (R[k].w <= 0 || R[k].h <= 0 || R[k].w * R[k].h + 16 > room || R[k].x0 < 0 || R[k].y0 < 0 ||
                         R[k].x0 + R[k].w > P.pitch[a + k] || R[k].w * R[k].h / 4 >= 4096)
                         c->orb_chain = 0;
                     regs.push_back(R[k]);
