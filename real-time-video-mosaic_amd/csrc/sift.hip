@@ -672,7 +672,7 @@ __device__ float orientation_hist(const SImg img, int px, int py, int radius, fl
 // (the host does not know the count yet).  Keypoints go to `list` in whatever order the waves
 // finish: the host sorts them (KeyPointsFilter::removeDuplicatedSorted), so the order of the
 // candidates and of the list does not reach the result.
-__global__ __launch_bounds__(64) void k_sift_refine(const SiftFrame* __restrict__ F, int cap, int list_cap) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_sift_refine(const SiftFrame* __restrict__ F, int cap, int list_cap) {
     const SiftFrame& f = F[blockIdx.y];
     const SPyr* __restrict__ P = &f.pyr;
     const unsigned long long* __restrict__ keys = f.keys;
