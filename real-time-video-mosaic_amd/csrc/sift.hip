@@ -895,61 +895,59 @@ __global__ __launch_bounds__(64) void k_sift_describe(const SiftFrame* __restric
     for (int i = lane; i < HLEN; i += 64) hist[i] = 0.f;
     const int side = 2 * radius + 1;
     const unsigned total = (unsigned)side * (unsigned)side;  // side <= 2 * 23170 + 1: fits 32 bits unsigned
-    for (unsigned base = 0; base < total; base += 64) {
-        const unsigned t = base + lane;
+    // About half of the scanned square lies inside the descriptor's rotated window, and a sample inside it costs
+    // some 700 instructions (exp and atan2 in double): the scan only tests (a few operations per position) and
+    // queues the positions inside, in scan order; whenever 64 are queued all lanes compute one sample each, and
+    // the eight shares of every sample are added to the bins in queue order, i.e. in scan order as before.
+    __shared__ unsigned s_q[128];
+    int nq = 0;   // queued positions (the same for all lanes)
+    auto inside = [&](unsigned t, float& c_rot, float& r_rot, float& rbin, float& cbin, int& r, int& c) {
+        const int i = (int)(t / (unsigned)side) - radius, j = (int)(t % (unsigned)side) - radius;
+        c_rot = j * cos_t - i * sin_t;
+        r_rot = j * sin_t + i * cos_t;
+        rbin = r_rot + d / 2 - 0.5f;
+        cbin = c_rot + d / 2 - 0.5f;
+        r = py + i, c = px + j;
+        return rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < img.h - 1 && c > 0 && c < img.w - 1;
+    };
+    auto flush = [&](int count) {   // the first count <= 64 queued samples
         int idx = -1;
-        float sh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (t < total) {
-            const int i = (int)(t / (unsigned)side) - radius, j = (int)(t % (unsigned)side) - radius;
-            const float c_rot = j * cos_t - i * sin_t;
-            const float r_rot = j * sin_t + i * cos_t;
-            float rbin = r_rot + d / 2 - 0.5f;
-            float cbin = c_rot + d / 2 - 0.5f;
-            const int r = py + i, c = px + j;
-            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < img.h - 1 && c > 0 && c < img.w - 1) {
-                const float dx = AT(img, r, c + 1) - AT(img, r, c - 1);
-                const float dy = AT(img, r - 1, c) - AT(img, r + 1, c);
-                const float W = (float)exp((double)((c_rot * c_rot + r_rot * r_rot) * exp_scale));
-                const float Ori = angle_deg(dy, dx);
-                const float Mag = sqrtf(dx * dx + dy * dy);
-                float obin = (Ori - ori) * bins_per_rad;
-                const float mag = Mag * W;
-                const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
-                int o0 = (int)floorf(obin);
-                rbin -= r0;
-                cbin -= c0;
-                obin -= o0;
-                if (o0 < 0) o0 += nb;
-                if (o0 >= nb) o0 -= nb;
-                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
-                const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-                const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
-                const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-                const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
-                const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-                idx = ((r0 + 1) * (d + 2) + c0 + 1) * (nb + 2) + o0;
-                sh[0] = v_rco000, sh[1] = v_rco001, sh[2] = v_rco010, sh[3] = v_rco011;
-                sh[4] = v_rco100, sh[5] = v_rco101, sh[6] = v_rco110, sh[7] = v_rco111;
-            }
+        if (lane < count) {
+            float c_rot, r_rot, rbin, cbin;
+            int r, c;
+            inside(s_q[lane], c_rot, r_rot, rbin, cbin, r, c);
+            const float dx = AT(img, r, c + 1) - AT(img, r, c - 1);
+            const float dy = AT(img, r - 1, c) - AT(img, r + 1, c);
+            const float W = (float)exp((double)((c_rot * c_rot + r_rot * r_rot) * exp_scale));
+            const float Ori = angle_deg(dy, dx);
+            const float Mag = sqrtf(dx * dx + dy * dy);
+            float obin = (Ori - ori) * bins_per_rad;
+            const float mag = Mag * W;
+            const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+            int o0 = (int)floorf(obin);
+            rbin -= r0;
+            cbin -= c0;
+            obin -= o0;
+            if (o0 < 0) o0 += nb;
+            if (o0 >= nb) o0 -= nb;
+            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+            const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+            const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+            const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+            idx = ((r0 + 1) * (d + 2) + c0 + 1) * (nb + 2) + o0;
+            s_v[lane][0] = v_rco000, s_v[lane][1] = v_rco001, s_v[lane][2] = v_rco010, s_v[lane][3] = v_rco011;
+            s_v[lane][4] = v_rco100, s_v[lane][5] = v_rco101, s_v[lane][6] = v_rco110, s_v[lane][7] = v_rco111;
         }
-        // the samples that fall into the descriptor's window (about half of the square that is scanned) move
-        // up to the front, in scan order
-        const unsigned long long hit = __ballot(idx >= 0);
-        const int n_hit = __popcll(hit);
-        s_idx[lane] = -1;
-        if (idx >= 0) {
-            const int pos = __popcll(hit & ((1ull << lane) - 1ull));
-            s_idx[pos] = idx;
-#pragma unroll
-            for (int e = 0; e < 8; e++) s_v[pos][e] = sh[e];
-        }
+        s_idx[lane] = idx;
         __syncthreads();
         // the eight shares of a sample go to eight different bins: lane e < 8 adds share e of every
         // sample, in sample order, so every bin still receives its terms in scan order
         if (lane < 8) {
             const int ofs = (lane & 1) + ((lane >> 1) & 1) * (nb + 2) + (lane >> 2) * (d + 2) * (nb + 2);
-            for (int l0 = 0; l0 < n_hit; l0 += 8) {
+            for (int l0 = 0; l0 < count; l0 += 8) {
                 // indices and shares of eight samples first, then the additions one after the other
                 const int4 ka = *reinterpret_cast<const int4*>(&s_idx[l0]);
                 const int4 kb = *reinterpret_cast<const int4*>(&s_idx[l0 + 4]);
@@ -963,7 +961,29 @@ __global__ __launch_bounds__(64) void k_sift_describe(const SiftFrame* __restric
             }
         }
         __syncthreads();
+    };
+    for (unsigned base = 0; base < total; base += 64) {
+        const unsigned t = base + lane;
+        bool in = false;
+        if (t < total) {
+            float c_rot, r_rot, rbin, cbin;
+            int r, c;
+            in = inside(t, c_rot, r_rot, rbin, cbin, r, c);
+        }
+        const unsigned long long hit = __ballot(in);
+        if (in) s_q[nq + __popcll(hit & ((1ull << lane) - 1ull))] = t;
+        nq += __popcll(hit);
+        __syncthreads();
+        if (nq >= 64) {
+            flush(64);
+            const unsigned keep = lane < nq - 64 ? s_q[64 + lane] : 0u;
+            __syncthreads();
+            s_q[lane] = keep;
+            nq -= 64;
+            __syncthreads();
+        }
     }
+    if (nq > 0) flush(nq);
     if (lane != 0) return;
     float* __restrict__ dst = desc + (size_t)q * 128;
     for (int i = 0; i < d; i++)
