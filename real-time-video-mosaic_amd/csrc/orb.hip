@@ -797,7 +797,7 @@ __global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* 
             const uint32_t w0 = w[t * (PATCH_PITCH / 4)], w1 = w[t * (PATCH_PITCH / 4) + 1], w2 = w[t * (PATCH_PITCH / 4) + 2];
             const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi4 = __builtin_amdgcn_alignbyte(w2, w1, sh);
             const uint32_t rs = __builtin_amdgcn_udot4(hi4, thi, __builtin_amdgcn_udot4(lo, tlo, 0u, false), false);
-            acc += kt[t] * rs;
+            acc += __umul24(kt[t], rs);   // an 8-bit tap and a 16-bit row sum: the full-rate multiply
         }
         return (int)min((acc + 0x7FFFu + ((acc >> 16) & 1u)) >> 16, 255u);
     };
