@@ -83,7 +83,6 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
     table = {
         "k_gray": 3 * P + P,
         "k_fast": S,                           # level pixels in (candidates out are a few KB)
-        "k_blur7": S + S,
         "k_resize": (S - P) * (1.44 + 1),      # levels 1..7: previous level in, level out
         "k_resize_chain<3>": P + sum(pyramid_level_pixels(fh, fw, l) for l in (1, 2, 3)),   # level 0 in, levels 1-3 out
         "k_resize_chain<4>": sum(pyramid_level_pixels(fh, fw, l) for l in (3, 4, 5, 6, 7)),     # level 3 in, levels 4-7 out

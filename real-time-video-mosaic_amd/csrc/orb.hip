@@ -4,10 +4,11 @@
 // Pipeline (every stage keeps its data in HBM planes of one pyramid buffer, one
 // u8 plane per level, pitch a multiple of 64):
 //   k_gray        BGR -> level 0
-//   k_resize      level l-1 -> level l, bit-exact fixed-point bilinear (7 launches)
-//   k_fast_score  FAST-9/16 corner score, LDS-staged 70x14 tiles, all levels in one launch
-//   k_fast_nms    3x3 non-maximum suppression, 31-pixel border, wave-aggregated append
-//                 of candidates + per-level score histogram
+//   k_resize_chain  levels 1-3 and 4-7, bit-exact fixed-point bilinear, level by level through LDS
+//                 (two launches; k_resize, one launch per level, for sizes the chains do not fit)
+//   k_fast        FAST-9/16 on 64x32 tiles in LDS, all levels in one launch: quick test, eight-pair
+//                 test and arc scores on compacted lists, 3x3 non-maximum suppression, 31-pixel
+//                 border, aggregated append of candidates + per-level score histogram
 //   k_orb_select  one workgroup per level: retainBest(2n) from the histogram, raster
 //                 sort (bitonic, LDS), Harris response, retainBest(n) by rank counting
 //   k_orb_describe one wave per keypoint: intensity-centroid angle, steered BRIEF-256 on the 7x7
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(64) void k_orb_describe(OrbDev P, const FrameSlot* 
     const float a = (float)cos((double)ang), b = (float)sin((double)ang);
     // cv::GaussianBlur(7 x 7, sigma 2) of the level at patch position (ix, iy) relative to the keypoint: seven
     // row sums of seven bytes (two v_dot4_u32_u8 on the bytes cut from three aligned words), their weighted sum,
-    // divided by 65536 with halves rounded to even and saturated - k_blur7's arithmetic at one point.
+    // divided by 65536 with halves rounded to even and saturated: integer taps cvRound(k * 256), exact sums.
     const uint32_t k0 = P.gk7[0], k1 = P.gk7[1], k2 = P.gk7[2], k3 = P.gk7[3], k4 = P.gk7[4], k5 = P.gk7[5], k6 = P.gk7[6];
     const uint32_t tlo = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), thi = k4 | (k5 << 8) | (k6 << 16);
     auto blurred = [&](int ix, int iy) -> int {
