@@ -257,6 +257,31 @@ def test_hip_warp_blend_region_much_larger_than_the_frame(fixed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cw", [161, 162, 163])
+def test_hip_warp_blend_canvas_width_not_a_multiple_of_four(cw):
+    """Canvas rows that do not start on 16-byte boundaries: the commit kernel with one pixel per lane and every
+    plane at an odd pitch (a multiple of 4 takes the kernel with four pixels per lane)."""
+    fh, fw, ch = 48, 64, 150
+    rng = np.random.default_rng(cw)
+    frames = [rng.integers(0, 256, (fh, fw, 3), dtype=np.uint8) for _ in range(4)]
+    frames[2][10:20, 5:30] = 0   # zero pixels inside a frame: holes in its mask
+    c = rtvm.Context(fh, fw, ch, cw)
+    try:
+        c.canvas_init(frames[0], 40, 50)
+        ref = np.zeros((ch, cw, 3), np.uint8)
+        ref[40:40 + fh, 50:50 + fw] = frames[0]
+        for f, H in [(frames[1], np.array([[1.02, 0.01, 58.0], [-0.01, 0.99, 44.0], [0, 0, 1]])),
+                     (frames[2], np.array([[0.98, -0.02, 66.0], [0.02, 1.01, 37.0], [1e-5, 0, 1]])),
+                     (frames[3], np.array([[1.0, 0.0, float(cw - 40)], [0.0, 1.0, 80.0], [0, 0, 1]]))]:   # clipped at the right edge
+            c.warp_blend(f, H)
+            ref = orc.warp_blend(ref, f, H, 0)
+            got = c.canvas_read()
+            assert np.array_equal(got, ref), "%d pixels differ" % int((got != ref).any(axis=2).sum())
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_hip_warp_blend_no_overlap(ctxs):
     frames, _ = frames_small(2, zeros=False)
     c = ctxs[1]
