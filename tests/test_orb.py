@@ -82,7 +82,9 @@ def _check_equal(got, ref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("h,w,n", [(240, 320, 500), (200, 200, 50), (480, 640, 700), (720, 1280, 1000)])
+@pytest.mark.parametrize("h,w,n", [(240, 320, 500), (200, 200, 50), (480, 640, 700), (720, 1280, 1000),
+                                   # widths and heights around the tiles of the chained resize: not multiples of 4, primes
+                                   (251, 331, 300), (333, 509, 400), (257, 258, 200), (130, 1027, 300)])
 def test_hip_orb_bit_exact(h, w, n):
     c = rtvm.Context(h, w, 0, 0, nfeatures=n)
     for t in (0, 1):
