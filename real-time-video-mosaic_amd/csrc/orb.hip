@@ -578,30 +578,54 @@ __global__ __launch_bounds__(1024) void k_orb_select(OrbDev P, const FrameSlot* 
     __shared__ int s_wave[16];
     const int quota = P.quota[l];
     const int n_cand = min(cand_count[l], P.cand_cap[l]);
+    // The score histogram of the level and its sums from the top: S[t] = candidates with a score of at least t.
+    // (One thread walking down the histogram in memory until the sum reaches the quota was a chain of some two
+    // hundred dependent loads: most of the kernel's time.)
+    __shared__ int s_h[256], s_suf[256], s_wsum[4], s_wthr[4];
+    const int want = 2 * quota;
+    if (tid < 256) {
+        const int hv = hist[l * 256 + tid];
+        s_h[tid] = hv;
+        int v = hv;   // inclusive sum over the lanes at and after this one
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_down(v, d);
+            if (lane + d < 64) v += o;
+        }
+        s_suf[tid] = v;
+        if (lane == 0) s_wsum[wave] = v;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        int v = s_suf[tid];
+        for (int w = wave + 1; w < 4; w++) v += s_wsum[w];
+        s_suf[tid] = v;
+        // the largest score t of this wave's 64 with S[t] >= want
+        const unsigned long long b = __ballot(v >= want);
+        if (lane == 0) s_wthr[wave] = b ? 64 * wave + 63 - __clzll((long long)b) : -1;
+    }
+    __syncthreads();
     if (tid == 0) {
         s_n = 0;
         s_base = 0;
         int thr = 0;
-        const int want = 2 * quota;
         if (want == 0) thr = 256;
         else if (n_cand > want) {
-            int cum = 0;
-            for (int s = 255; s >= 0; s--) {
-                cum += hist[l * 256 + s];
-                if (cum >= want) {
-                    thr = s;
+            for (int w = 3; w >= 0; w--)
+                if (s_wthr[w] >= 0) {
+                    thr = s_wthr[w];
                     break;
                 }
-            }
+            int cum = s_suf[thr];   // all candidates when no score reaches the quota (thr = 0)
             // more ties at the cut than the workgroup can hold: raise the cut
             while (cum > SEL_CAP && thr < 256) {
-                cum -= hist[l * 256 + thr];
+                cum -= s_h[thr];
                 thr++;
             }
         } else if (n_cand > SEL_CAP) {
             int cum = n_cand;
             while (cum > SEL_CAP && thr < 256) {
-                cum -= hist[l * 256 + thr];
+                cum -= s_h[thr];
                 thr++;
             }
         }
