@@ -583,34 +583,44 @@ __device__ int update_num_iters(double p, double ep, int modelPoints, int maxIte
 
 // The sequential keep/stop rule of RANSACPointSetRegistrator::run over the inlier
 // counts of iterations [h0, h1).
-__global__ void k_rs_replay(const FrameSlot* __restrict__ slots, int sb, int h0, int h1, double confidence,
-                            int last) {
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(64) void k_rs_replay(const FrameSlot* __restrict__ slots, int sb, int h0, int h1, double confidence,
+                                                  int last) {
     const FrameSlot& S = slots[sb + blockIdx.x];
     const int* __restrict__ count_p = S.rs_count;
     RsState* __restrict__ st = (RsState*)S.rs_state;
     const int* __restrict__ good = S.rs_good;
     const int count = *count_p;
-    if (count <= 4 || st->done) return;
+    if (count <= 4 || st->done) return;   // the same for the wave
     int niters = st->niters, max_good = st->max_good, best = st->best;
+    const int fail_at = st->fail_at;
     bool done = false;
-    for (int h = h0; h < h1; h++) {
-        if (h >= niters) {
-            done = true;
-            break;
+    // the hypotheses' inlier counts come 64 at a time, one load per lane; lane 0 then walks through them in order
+    // (a load per hypothesis behind the test on the one before it made the walk a chain of memory round trips)
+    __shared__ int s_good[64];
+    const int lane = threadIdx.x;
+    for (int hb = h0; hb < h1 && !done; hb += 64) {
+        s_good[lane] = hb + lane < h1 ? good[hb + lane] : -1;
+        wave_lds_phase();
+        if (lane == 0) {
+            const int he = min(hb + 64, h1);
+            for (int h = hb; h < he; h++) {
+                if (h >= niters || fail_at == h) {
+                    done = true;
+                    break;
+                }
+                const int g = s_good[h - hb];
+                if (g < 0) continue;
+                if (g > (max_good > 3 ? max_good : 3)) {
+                    best = h;
+                    max_good = g;
+                    niters = update_num_iters(confidence, (double)(count - g) / count, 4, niters);
+                }
+            }
         }
-        if (st->fail_at == h) {
-            done = true;
-            break;
-        }
-        const int g = good[h];
-        if (g < 0) continue;
-        if (g > (max_good > 3 ? max_good : 3)) {
-            best = h;
-            max_good = g;
-            niters = update_num_iters(confidence, (double)(count - g) / count, 4, niters);
-        }
+        done = __shfl((int)done, 0) != 0;
+        wave_lds_phase();
     }
+    if (lane != 0) return;
     if (h1 >= niters || last) done = true;
     st->niters = niters;
     st->max_good = max_good;
