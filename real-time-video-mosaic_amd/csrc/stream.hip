@@ -276,7 +276,9 @@ __global__ __launch_bounds__(64) void k_batch_collect(const FrameSlot* __restric
 // report the host reads.
 // host_glue: the homographies came from the host, which keeps the stream state itself; there is
 // no device state to go back to.
-__device__ void batch_finish(StreamState* st, const StreamState* snap, int n, BatchReport* rep, int host_glue) {
+// lists = false: the caller copies the per-frame lists of the report itself (batch_report_lists, a frame per lane)
+__device__ void batch_finish(StreamState* st, const StreamState* snap, int n, BatchReport* rep, int host_glue,
+                             bool lists = true) {
     const int bad = st->bad_frame;
     int reason = RTVM_PENDING_NONE;
     bool later = false;
@@ -303,7 +305,18 @@ __device__ void batch_finish(StreamState* st, const StreamState* snap, int n, Ba
     rep->abort = st->abort;
     rep->tail_ok = st->tail_ok;
     rep->reason = reason;
-    for (int j = 0; j < n; j++) {
+    if (lists)
+        for (int j = 0; j < n; j++) {
+            rep->status[j] = st->b_status[j];
+            rep->matches[j] = st->b_matches[j];
+            rep->kp[j] = st->b_kp[j];
+        }
+}
+
+// the report's per-frame lists, frame j by thread j (after batch_finish and a barrier)
+__device__ __forceinline__ void batch_report_lists(const StreamState* st, int n, BatchReport* rep) {
+    const int j = threadIdx.x;
+    if (j < n) {
         rep->status[j] = st->b_status[j];
         rep->matches[j] = st->b_matches[j];
         rep->kp[j] = st->b_kp[j];
@@ -352,8 +365,9 @@ __global__ void k_batch_finish(StreamState* __restrict__ st, const StreamState* 
 __global__ __launch_bounds__(1024) void k_batch_finish_advance(StreamState* st, const StreamState* snap, int n, BatchReport* rep,
                                                                int host_glue, const FrameSlot* __restrict__ slots, int sb,
                                                                FeatSet prev, int max_kp, int desc_bytes) {
-    if (threadIdx.x == 0) batch_finish(st, snap, n, rep, host_glue);
+    if (threadIdx.x == 0) batch_finish(st, snap, n, rep, host_glue, false);
     __syncthreads();
+    batch_report_lists(st, n, rep);
     const int j = st->last_good;
     if (j < 0) return;
     const FeatSet cur = slots[sb + j].feat;
