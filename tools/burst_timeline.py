@@ -1,14 +1,15 @@
 """Time line of the last burst of kernels in a rocprofv3 kernel trace (…_kernel_trace.csv) of `bench.py --steps K`:
 start, duration and queue of every kernel of the timed pass, relative to the first one.
 usage: python tools/burst_timeline.py TRACE.csv [gap_us]"""
-import csv, sys
+import csv, re, sys
 rows = []
 with open(sys.argv[1]) as fh:
     for r in csv.DictReader(fh):
         n = r["Kernel_Name"]
         if "k_" not in n and "rocclr" not in n:
             continue
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), n.split("::")[-1].split("(")[0]))
+        m = re.search(r"k_[A-Za-z0-9_]+(<[^>]*>)?|__amd_rocclr_[A-Za-z]+", n)
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), m.group(0) if m else n[:40]))
 rows.sort()
 gap = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 2e6
 # the last burst: walk back from the end until a gap of more than `gap` ns
