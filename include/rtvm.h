@@ -134,7 +134,8 @@ int rtvm_sift(rtvm_ctx* ctx, const uint8_t* bgr, int h, int w, int nfeatures, in
 
 /* cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(q, t)  main.py:37,695.
  * q: nq*32 u8, t: nt*32 u8; outputs have capacity nq; matches are emitted in
- * ascending query index.  nq, nt <= 65535. */
+ * ascending query index.  nq, nt <= 16384 (RTVM_NOALLOC_MAX_DESCRIPTORS, the limit of every form of the
+ * Hamming matcher), more is refused with RTVM_E_ARG. */
 int rtvm_match_hamming_xcheck(rtvm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
                               int32_t* qidx, int32_t* tidx, int32_t* dist, int* m_out);
 /* Same, followed by the stable sort by distance of main.py:698. */
@@ -148,7 +149,8 @@ int rtvm_match_hamming_xcheck_sorted(rtvm_ctx* ctx, const uint8_t* q, int nq, co
  * allocates: the work buffers of the matcher (slot descriptor, counts, nearest-neighbour keys of
  * both directions, 129 KiB) are a fixed array in the library's device image, one copy per GPU,
  * held until the process ends.  All pointers are DEVICE pointers on the current device:
- * q_dev nq*32 u8, t_dev nt*32 u8; qidx_dev / tidx_dev / dist_dev have capacity nq; *m_out_dev
+ * q_dev nq*32 u8, t_dev nt*32 u8, both 16-byte aligned (hipMalloc's addresses are; an address that is
+ * not is refused with RTVM_E_ARG); qidx_dev / tidx_dev / dist_dev have capacity nq; *m_out_dev
  * receives the number of matches.  Matches come in ascending query index, or, with sorted != 0,
  * stably sorted by distance (main.py:698).  nq, nt <= RTVM_NOALLOC_MAX_DESCRIPTORS, more is
  * refused with RTVM_E_ARG.  The kernels are queued on hip_stream (a hipStream_t, NULL = the
@@ -240,8 +242,10 @@ int rtvm_batch_status(rtvm_ctx* ctx, int* n_done, int* status, int* n_matches, i
  * then waits for them too. */
 int rtvm_batch_status_at(rtvm_ctx* ctx, int back, int* n_done, int* status, int* n_matches,
                          int* n_keypoints, int cap);
-/* Ticket of the batch queued last (rtvm_process_batch, rtvm_process_frame or rtvm_batch_retry);
- * tickets count up from 1 after rtvm_stream_begin. */
+/* Ticket of the batch queued last (rtvm_process_batch, rtvm_process_frame, rtvm_batch_detect, rtvm_batch_retry or
+ * rtvm_batch_commit); tickets count up from 1 after rtvm_stream_begin.  The library keeps the reports (and, for
+ * rtvm_batch_commit, the homographies) of the last 16 tickets: a call that takes a 17th ticket first waits until
+ * the piece 16 tickets before it has run. */
 long rtvm_batch_ticket(rtvm_ctx* ctx);
 /* rtvm_batch_status for one of the last 16 tickets, plus the reason (RTVM_PENDING_*) when
  * frames were left pending.  Waits for that batch only. */

@@ -212,6 +212,11 @@ struct NoAllocScratch {
 
 static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
 
+// k_xcheck_compact sizes its LDS arrays by RTVM_MAX_MATCH and the packed keys hold 16-bit indices: the public
+// limit of the entry point may not outgrow either.
+static_assert(RTVM_NOALLOC_MAX_DESCRIPTORS <= RTVM_MAX_MATCH, "the compaction kernel's LDS arrays hold RTVM_MAX_MATCH entries");
+static_assert(RTVM_NOALLOC_MAX_DESCRIPTORS <= 65535, "the nearest-neighbour keys carry 16-bit indices");
+
 constexpr int kMaxDevices = 64;
 void* g_scratch_ptr[kMaxDevices];   // device address of `scratch` on device d, null until looked up
 std::mutex g_scratch_mutex;
@@ -240,6 +245,8 @@ extern "C" int rtvm_match_hamming_xcheck_noalloc(const uint8_t* q_dev, int nq, c
     g_noalloc_err[0] = 0;
     if (nq < 0 || nt < 0 || !m_out_dev || (nq > 0 && (!q_dev || !qidx_dev || !tidx_dev || !dist_dev)) || (nt > 0 && !t_dev))
         return noalloc_fail(RTVM_E_ARG, "match_hamming_xcheck_noalloc: bad argument");
+    if (((uintptr_t)q_dev | (uintptr_t)t_dev) & 15)   // the kernels read descriptors as 16-byte words
+        return noalloc_fail(RTVM_E_ARG, "match_hamming_xcheck_noalloc: q_dev and t_dev must be 16-byte aligned");
     if (nq > RTVM_NOALLOC_MAX_DESCRIPTORS || nt > RTVM_NOALLOC_MAX_DESCRIPTORS) {
         snprintf(g_noalloc_err, sizeof(g_noalloc_err),
                  "match_hamming_xcheck_noalloc: %d x %d descriptors, the fixed scratch holds at most %d per side", nq, nt,

@@ -514,10 +514,11 @@ extern "C" int rtvm_canny(rtvm_ctx* c, const uint8_t* gray, int h, int w, double
     HIP_TRY(c, hipMemcpyAsync(in.p, gray, n, hipMemcpyHostToDevice, c->stream));
     const dim3 grid((w + CN_TW - 1) / CN_TW, (h + CN_TH - 1) / CN_TH);
     RTVM_LAUNCH(c, k_canny_nms, grid, dim3(256), 0, (const uint8_t*)in.u8(), h, w, low, high, map.u8());
-    // an edge crosses at least one tile per launch: the diagonal of the tile grid bounds the rounds
-    const int max_rounds = (int)(grid.x * grid.y) + 2;
+    // Hysteresis inside every tile until nothing changes there, launched again until no tile changed.  A round only
+    // turns "weak" pixels into "edge" pixels, so the rounds end; an edge that weaves across a tile border needs one
+    // round per crossing, which no function of the tile grid bounds.
     int* h_flag = (int*)c->h_pinned;
-    for (int round = 0; round < max_rounds; round++) {
+    for (;;) {
         HIP_TRY(c, hipMemsetAsync(flag.p, 0, sizeof(int), c->stream));
         RTVM_LAUNCH(c, k_canny_hyst, grid, dim3(256), 0, map.u8(), h, w, (int*)flag.p);
         HIP_TRY(c, hipGetLastError());

@@ -5,7 +5,7 @@
 // u8 plane per level, pitch a multiple of 64):
 //   k_gray        BGR -> level 0
 //   k_resize_chain  levels 1-3 and 4-7, bit-exact fixed-point bilinear, level by level through LDS
-//                 (two launches; k_resize, one launch per level, for sizes the chains do not fit)
+//                 (two launches)
 //   k_fast        FAST-9/16 on 64x32 tiles in LDS, all levels in one launch: quick test, eight-pair
 //                 test and arc scores on compacted lists, 3x3 non-maximum suppression, 31-pixel
 //                 border, aggregated append of candidates + per-level score histogram
@@ -70,74 +70,8 @@ __global__ __launch_bounds__(256) void k_gray(const FrameSlot* __restrict__ slot
 }
 
 // INTER_LINEAR_EXACT: 8.8 coefficients (xw/yw = weight of the second tap, 0xFFFF = clamped
-// single tap, evaluated as weight 0 on a repeated tap: (256-0)*a + 0*a = a << 8).  One
-// workgroup per tile of 64 x 16 outputs: the source pixels the tile reads (about 80 x 22
-// at the pyramid's factor 1.2) are staged in LDS with aligned word loads; a lane computes 4
-// rows of one column.  A tile whose footprint does not fit the staging area reads global
-// memory directly.
-__global__ __launch_bounds__(256) void k_resize(const FrameSlot* __restrict__ slots, int sb, unsigned soff, int sp,
-                                                int sh, unsigned doff, int dw, int dh, int dp,
-                                                const uint16_t* __restrict__ xofs, const uint16_t* __restrict__ xw,
-                                                const uint16_t* __restrict__ yofs, const uint16_t* __restrict__ yw) {
-    constexpr int TR = 28, TC = 112;  // staged rows / columns
-    const FrameSlot& S = slots[sb + blockIdx.z];
-    const uint8_t* __restrict__ src = S.pyr + soff;
-    uint8_t* __restrict__ dst = S.pyr + doff;
-    __shared__ __align__(16) uint8_t t[TR][TC];
-    const int tiles_x = (dw + 63) / 64;
-    const int tile = xcd_tile(blockIdx.x, tiles_x * ((dh + 15) / 16));
-    if (tile < 0) return;
-    const int tx0 = (tile % tiles_x) * 64, ty0 = (tile / tiles_x) * 16;
-    const int tid = threadIdx.x;
-    // footprint of the tile in the source level (block-uniform)
-    const int xlast = min(tx0 + 63, dw - 1), ylast = min(ty0 + 15, dh - 1);
-    const int sx0 = (int)xofs[tx0] & ~3, sx1 = (int)xofs[xlast] + 1;   // inclusive last column
-    const int sy0 = yofs[ty0], sy1 = (int)yofs[ylast] + 1;           // inclusive last row
-    const bool staged = sx1 - sx0 < TC && sy1 - sy0 < TR;
-    if (staged) {
-        const int nq = (sx1 - sx0) / 4 + 1, nr = sy1 - sy0 + 1;  // at most TC / 4 = 28 words per row
-        const int q = tid & 31;
-        if (q < nq)
-            for (int r = tid >> 5; r < nr; r += 8) {
-                const int y = min(sy0 + r, sh - 1), x = min(sx0 + 4 * q, sp - 4);
-                *reinterpret_cast<uint32_t*>(&t[r][4 * q]) = *reinterpret_cast<const uint32_t*>(src + (unsigned)(y * sp + x));
-            }
-    }
-    __syncthreads();
-    const int x = tx0 + (tid & 63);
-    if (x >= dw) return;
-    const int xo = xofs[x];
-    const unsigned cxr = xw[x];
-    const unsigned cx = cxr == 0xFFFFu ? 0u : cxr;
-    const int xo1 = cxr == 0xFFFFu ? xo : xo + 1;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int y = ty0 + 4 * (tid >> 6) + i;
-        if (y >= dh) break;
-        const int yo = yofs[y];
-        const unsigned cyr = yw[y];
-        const unsigned cy = cyr == 0xFFFFu ? 0u : cyr;
-        const int yo1 = cyr == 0xFFFFu ? yo : yo + 1;
-        unsigned a00, a01, a10, a11;
-        if (staged) {
-            a00 = t[yo - sy0][xo - sx0];
-            a01 = t[yo - sy0][xo1 - sx0];
-            a10 = t[yo1 - sy0][xo - sx0];
-            a11 = t[yo1 - sy0][xo1 - sx0];
-        } else {
-            a00 = src[(size_t)yo * sp + xo];
-            a01 = src[(size_t)yo * sp + xo1];
-            a10 = src[(size_t)yo1 * sp + xo];
-            a11 = src[(size_t)yo1 * sp + xo1];
-        }
-        // 9-bit weights, 8- and 16-bit values: 24-bit multiplies
-        const unsigned h0 = __umul24(256u - cx, a00) + __umul24(cx, a01);
-        const unsigned h1 = __umul24(256u - cx, a10) + __umul24(cx, a11);
-        unsigned v = __umul24(256u - cy, h0) + __umul24(cy, h1);
-        v = (v + 32768u) >> 16;
-        dst[(size_t)y * dp + x] = (uint8_t)(v > 255u ? 255u : v);
-    }
-}
+// single tap, evaluated as weight 0 on a repeated tap: (256-0)*a + 0*a = a << 8):
+//   h0 = (256-cx)*a00 + cx*a01, h1 = (256-cx)*a10 + cx*a11, v = ((256-cy)*h0 + cy*h1 + 32768) >> 16.
 
 // ---- several levels per launch
 // The rectangle of a level a chain workgroup computes (x0, y0, w, h; x0 and w multiples of 4) and the part
@@ -201,7 +135,7 @@ __host__ __device__ inline void rc_regions(const OrbDev& P, int a, int n, int tx
 }
 
 // Levels a+1 .. a+N of the pyramid in one launch: one workgroup per 64 x 16 tile of level a+N stages the
-// rectangle of level a under it in LDS and resizes level by level from LDS to LDS (k_resize's arithmetic),
+// rectangle of level a under it in LDS and resizes level by level from LDS to LDS (the arithmetic above),
 // four pixels of a row per thread, storing the pixels it owns as words.  What neighbouring workgroups both
 // need of a level both compute (about a third more pixels than the levels have); no level is read back
 // from memory and no launch waits for another.  The host has checked every rectangle against its staging buffer.
@@ -984,8 +918,10 @@ int rtvm_orb_setup(rtvm_ctx* c) {
         }
     HIP_TRY(c, hipMemcpy(c->d_xsel, xsel.data(), xsel.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_xwp, xwp.data(), xwp.size() * 4, hipMemcpyHostToDevice));
-    // Levels 1-3 and 4-7 as two chained launches when every rectangle of every tile fits the staging
-    // buffers (any frame size the pyramid factor 1.2 leaves above a few pixels); else level by level.
+    // Levels 1-3 and 4-7 as two chained launches: every rectangle of every tile must fit the staging buffers
+    // (checked here for every tile; true for any frame size the pyramid factor 1.2 leaves above a few pixels).
+    // Frames of fewer than 29 pixels a side have levels too small for the chains, and no level of theirs is
+    // wide enough for a keypoint (63 pixels): their pyramid is not built at all.
     c->orb_chain = sel_ok ? 1 : 0;
     const int chain_a[2] = {0, 3}, chain_n[2] = {3, 4};
     std::vector<RcRegion> regs;
@@ -1008,6 +944,8 @@ int rtvm_orb_setup(rtvm_ctx* c) {
     }
     if ((int)regs.size() != c->orb_rc_total) RTVM_FAIL(c, RTVM_E_STATE, "resize chain: %d rectangles, %d planned", (int)regs.size(), c->orb_rc_total);
     HIP_TRY(c, hipMemcpy(c->d_rc_regions, regs.data(), regs.size() * sizeof(RcRegion), hipMemcpyHostToDevice));
+    if (!c->orb_chain && P.tile_off[RTVM_NLEVELS] > 0)
+        RTVM_FAIL(c, RTVM_E_ARG, "ORB pyramid: a %d x %d frame does not fit the resize kernels' staging buffers", P.w[0], P.h[0]);
     return RTVM_OK;
 }
 
@@ -1024,11 +962,7 @@ int rtvm_launch_orb(rtvm_ctx* c, int sb, int nb) {
         RTVM_LAUNCH(c, k_resize_chain<4>, dim3(xcd_grid(((P.w[7] + RC_TW - 1) / RC_TW) * ((P.h[7] + RC_TH - 1) / RC_TH)), 1, nb),
                     dim3(256), 0, P, sl, sb, 3, c->d_xofs, c->d_xsel, c->d_xwp, c->d_yofs, c->d_yw,
                     (const RcRegion*)c->d_rc_regions + ((P.w[3] + RC_TW - 1) / RC_TW) * ((P.h[3] + RC_TH - 1) / RC_TH) * 4);
-    } else
-    for (int l = 1; l < RTVM_NLEVELS; l++)
-        RTVM_LAUNCH(c, k_resize, dim3(xcd_grid(((P.w[l] + 63) / 64) * ((P.h[l] + 15) / 16)), 1, nb), dim3(256), 0, sl, sb, P.off[l - 1],
-                    P.pitch[l - 1], P.h[l - 1], P.off[l], P.w[l], P.h[l], P.pitch[l], c->d_xofs + P.xtab_off[l],
-                    c->d_xw + P.xtab_off[l], c->d_yofs + P.ytab_off[l], c->d_yw + P.ytab_off[l]);
+    }
     if (P.tile_off[RTVM_NLEVELS] > 0) {
         RTVM_LAUNCH(c, k_fast, dim3(xcd_grid_runs(P.tile_off[RTVM_NLEVELS]), nb), dim3(256), 0, P, sl, sb);
     }

@@ -493,6 +493,9 @@ int queue_back_half(rtvm_ctx* c, int set, int sb, const uint8_t* const* ptrs, in
     int r;
     c->seq += 1;
     const int slot = (int)(c->seq % RTVM_REPORTS);
+    // the report slot (and its event) served ticket seq - RTVM_REPORTS: that piece must have run before this one's
+    // launches are queued behind the same event
+    if (c->seq > RTVM_REPORTS) HIP_TRY(c, hipEventSynchronize(c->ev_done[slot]));
     if (c->set_owner[set] == c->seq) {  // the batch that owns the slot set (not a later piece of it)
         BatchRecord& rec = c->recs[set];
         rec.ticket = c->seq;
@@ -868,6 +871,8 @@ extern "C" int rtvm_batch_commit(rtvm_ctx* c, long ticket, int first, int count,
     // the homographies wait in pinned memory of the report slot this piece will get (queue_back_half
     // counts the ticket up); the device reads them from there
     const int slot = (int)((c->seq + 1) % RTVM_REPORTS);
+    // ... which the piece RTVM_REPORTS tickets ago used: its glue kernel must have read its homographies first
+    if (c->seq + 1 > RTVM_REPORTS) HIP_TRY(c, hipEventSynchronize(c->ev_done[slot]));
     double* hH = c->h_commit_H + (size_t)slot * RTVM_MAX_BATCH * 9;
     memcpy(hH, H_abs, (size_t)count * 9 * sizeof(double));
     HIP_TRY(c, hipStreamWaitEvent(c->stream_main, c->ev_front[rec.set], 0));  // the frames and their features

@@ -7,18 +7,18 @@ main.py:733-746 is the reference's numpy, kept on the host so that the public
 thresholds, the history list and H_old behave exactly like the reference's
 attributes.
 
-With a display flag set (``visualize`` or ``show_intermediate``, the reference's
-defaults: a window per frame) every ``process_frame`` call completes before it
-returns: ``frame_register`` (upload, ORB, match, RANSAC) and ``frame_commit``
-(warp, blend, state advance).  Headless (both flags off, what ``main.py --hide``
-passes at main.py:1603) and with the ORB detector, ``process_frame`` only takes
-the frame: frames are detected, matched and fitted in batches on the device
-while the caller fetches the next ones, the host applies the reference's rules
-to each batch's results in frame order, and the warps and blends follow in
-pieces.  Reading any result (``H``, ``H_old``, ``output_img``, ``matches``,
-``kp_*``, ``homography_history``, ...) first brings the object to the state the
-reference would have after the last ``process_frame`` call; warnings are printed
-in frame order, at the latest then.
+``visualize`` and ``show_intermediate`` are accepted and change nothing: they only
+open windows in the reference (main.py:703-707, 932-934) and no window is opened
+here.  For every combination of them ``process_frame`` only takes the frame:
+frames are detected, matched and fitted in batches on the device while the caller
+fetches the next ones, the host applies the reference's rules to each batch's
+results in frame order, and the warps and blends follow in pieces.  Reading any
+result (``H``, ``H_old``, ``output_img``, ``matches``, ``kp_*``,
+``homography_history``, ...) first brings the object to the state the reference
+would have after the last ``process_frame`` call; warnings are printed in frame
+order, at the latest then.  ``pipeline_batch=0`` opts out: every ``process_frame``
+call then completes before it returns (``frame_register``: upload, detect, match,
+RANSAC; ``frame_commit``: warp, blend, state advance).
 """
 import collections
 import threading
@@ -56,7 +56,7 @@ class _Batch:
 
 
 class _Pipeline:
-    """process_frame without waiting (headless; ORB or SIFT: the context's detector).  Frames go through a ring of pinned host slots
+    """process_frame without waiting (ORB or SIFT: the context's detector).  Frames go through a ring of pinned host slots
     to the device; detection, matching and RANSAC run in batches of `batch` frames, up to three
     batches ahead (rtvm_batch_detect); when a batch's results arrive the host applies main.py:722-746
     to its frames in order (skip rules, validate, smooth, chain: the owner's own methods and
@@ -188,13 +188,15 @@ class _Pipeline:
             # matched against the wrong frame
             redo = [(b.idx0 + i, b.frames[i]) for i in range(j + 1, b.n)]
             b.frames, b.n = b.frames[:j + 1], j + 1
+            again = len(redo)
             while self.batches[-1] is not b:
                 later = self.batches.pop()
                 self.ctx.batch_release(later.ticket)
                 redo_later = [(later.idx0 + i, f) for i, f in enumerate(later.frames)]
                 self.pend.extendleft(reversed(redo_later))
+                again += len(redo_later)
             self.pend.extendleft(reversed(redo))
-            self.stats["frames_detected_again"] += len(self.pend)
+            self.stats["frames_detected_again"] += again
             self.need_rebase = True
             break
         return True
@@ -285,9 +287,10 @@ class VideMosaic:
             canvas_size = (int(output_height_times * fh), int(output_width_times * fw))
         self._ch, self._cw = int(canvas_size[0]), int(canvas_size[1])
         flags = _ffi.FLAG_WARP_FIXED if warp_mode == "fixed" else 0
-        # headless: process_frame only enqueues (see the module docstring); pipeline_batch = 0 turns it off
-        self._deferred = not visualize and not show_intermediate and pipeline_batch > 0 and nfeatures <= 7936
-        # SIFT with a display flag set runs stage by stage, the way the reference itself does
+        # process_frame only enqueues (see the module docstring), whatever the display flags say: nothing observable
+        # distinguishes the two modes once no window is opened; pipeline_batch = 0 turns it off
+        self._deferred = pipeline_batch > 0 and nfeatures <= 7936
+        # frame-synchronous SIFT runs stage by stage, the way the reference itself does
         self._staged_sift = detector_type == "sift" and not self._deferred
         det = _ffi.DET_ORB if detector_type == "orb" else \
             (_ffi.DET_SIFT_MATCH_ONLY if self._staged_sift else _ffi.DET_SIFT)
@@ -432,8 +435,8 @@ class VideMosaic:
         self._canvas_cache = None
 
     def flush(self):
-        """Waits until every frame handed to process_frame has been dealt with (headless mode; a no-op
-        otherwise).  Reading a result does the same."""
+        """Waits until every frame handed to process_frame has been dealt with (a no-op with
+        pipeline_batch=0).  Reading a result does the same."""
         self._sync()
 
     def _synced(name):   # noqa: N805 - attribute whose value depends on the frames still in flight
@@ -576,7 +579,7 @@ class VideMosaic:
 
     # ------------------------------------------------------------------ lazily fetched state
     def _held_frame(self):
-        """(ticket, index) of the newest frame when it went through the headless pipeline, else None."""
+        """(ticket, index) of the newest frame when it went through the pipeline, else None."""
         p = self._pipe
         if p is None or p.held is None or p.last is None or p.last[0] is not p.held:
             return None

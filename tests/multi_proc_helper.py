@@ -1,6 +1,6 @@
 """One of several stitching processes that share a GPU (tests/test_multi_proc.py): its own seeded video through
 Context.process_video, then a line with the statuses, the final homography and a checksum of the canvas.
-usage: python multi_proc_helper.py <seed> <frames>"""
+usage: python multi_proc_helper.py <seed> <frames> [<frame height> <frame width> <features>]"""
 import hashlib
 import json
 import os
@@ -34,4 +34,4 @@ def run(seed, n, fh=360, fw=640, nf=500):
 
 
 if __name__ == "__main__":
-    print(json.dumps(run(int(sys.argv[1]), int(sys.argv[2]))))
+    print(json.dumps(run(*[int(v) for v in sys.argv[1:6]])))

@@ -1,6 +1,7 @@
-"""VideMosaic in headless mode (visualize=False, show_intermediate=False, ORB): process_frame only takes
+"""VideMosaic's pipeline (the default for every combination of the display flags): process_frame only takes
 the frame, the work follows in batches, and reading any result brings the object to the state the
-reference has after the last call.  Checked against the oracle and against the frame-synchronous class."""
+reference has after the last call.  Checked against the oracle and against the frame-synchronous class
+(pipeline_batch=0)."""
 import numpy as np
 import pytest
 
@@ -48,11 +49,14 @@ def tricky_video():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("detector,batch", [("orb", 1), ("orb", 4), ("orb", 8), ("orb", 32), ("sift", 1), ("sift", 5),
-                                            ("sift", 16)])
-def test_headless_pipeline_equals_frame_by_frame_and_oracle(detector, batch, capsys):
+@pytest.mark.parametrize("detector,batch,display", [("orb", 1, (False, False)), ("orb", 4, (True, True)),
+                                                    ("orb", 8, (False, True)), ("orb", 32, (True, False)),
+                                                    ("orb", 32, (False, False)), ("sift", 1, (False, False)),
+                                                    ("sift", 5, (True, True)), ("sift", 16, (False, False))])
+def test_headless_pipeline_equals_frame_by_frame_and_oracle(detector, batch, display, capsys):
+    """display = (visualize, show_intermediate): accepted, and without effect on results or on the mode."""
     frames = tricky_video()
-    sync = rtvm.VideMosaic(frames[0], detector_type=detector, visualize=False, show_intermediate=True, nfeatures=500)
+    sync = rtvm.VideMosaic(frames[0], detector_type=detector, nfeatures=500, pipeline_batch=0)
     assert not sync._deferred
     om = OracleMosaic(frames[0], nfeatures=500, glue="numpy", detector=detector)
     for t, f in enumerate(frames[1:], 1):
@@ -63,7 +67,7 @@ def test_headless_pipeline_equals_frame_by_frame_and_oracle(detector, batch, cap
     assert np.array_equal(sync.H, om.H) and np.array_equal(sync.output_img_u8(), om.canvas)
     want = state_of(sync)
 
-    kw = dict(HEADLESS, detector_type=detector)
+    kw = dict(detector_type=detector, visualize=display[0], show_intermediate=display[1])
     vm = rtvm.VideMosaic(frames[0], nfeatures=500, pipeline_batch=batch, **kw)
     assert vm._deferred and vm._ctx.detector == (rtvm._ffi.DET_SIFT if detector == "sift" else rtvm._ffi.DET_ORB)
     for t, f in enumerate(frames[1:], 1):
@@ -94,7 +98,7 @@ def test_headless_attributes_are_live(capsys):
     """The public knobs of the reference (thresholds, history size, stabilisation switch, H_old) are read when a
     frame's rules are applied; setting one first settles the frames handed in before."""
     frames, _ = synth.make_video(FH, FW, 12, world_size=(520, 620), seed=3)
-    a = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=True, nfeatures=400)
+    a = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=True, nfeatures=400, pipeline_batch=0)
     b = rtvm.VideMosaic(frames[0], nfeatures=400, pipeline_batch=4, **HEADLESS)
     for vm in (a, b):
         for t in range(1, 5):

@@ -78,14 +78,19 @@ def test_videmosaic_dropin_matches_oracle(warp_mode, capsys):
 
 
 @pytest.mark.gpu
-def test_videmosaic_skip_rules(capsys):
+@pytest.mark.parametrize("pipeline_batch", [0, 32])
+def test_videmosaic_skip_rules(capsys, pipeline_batch):
+    """With the reference's default display flags; frame-synchronous (pipeline_batch=0) and through the pipeline
+    (flush() settles the frames taken so far: the warnings are printed then at the latest)."""
     frames, _ = video(3)
-    vm = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=False, nfeatures=300)
+    vm = rtvm.VideMosaic(frames[0], detector_type="orb", nfeatures=300, pipeline_batch=pipeline_batch)
+    assert vm.visualize and vm.show_intermediate and vm._deferred == (pipeline_batch > 0)
     before = vm.output_img.copy()
     H_old = vm.H_old.copy()
     des_prev = vm.des_prev.copy()
     flat = np.full_like(frames[0], 90)                     # featureless frame: < 4 matches
     vm.process_frame(flat, 1)
+    vm.flush()
     assert "Недостаточно совпадений" in capsys.readouterr().out
     assert np.array_equal(vm.output_img, before) and np.array_equal(vm.H_old, H_old)
     assert np.array_equal(vm.des_prev, des_prev)           # state not advanced
@@ -98,6 +103,7 @@ def test_videmosaic_skip_rules(capsys):
     h_before, last_valid, canvas_before = vm.H_old.copy(), vm.last_valid_H.copy(), vm.output_img.copy()
     n_hist = len(vm.homography_history)
     vm.process_frame(far, 3)
+    vm.flush()
     out = capsys.readouterr().out
     assert "большое смещение" in out and "Невалидная гомография" in out
     assert np.array_equal(vm.homography_history[-1], np.eye(3)) and len(vm.homography_history) == n_hist + 1
@@ -395,8 +401,8 @@ def test_dropin_with_the_default_sift_detector_matches_oracle(capsys):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("detector,workers,display", [("sift", 3, False), ("sift", 1, False), ("orb", 4, True),
-                                                      ("orb", 4, False)])
+@pytest.mark.parametrize("detector,workers,display", [("sift", 3, True), ("sift", 1, True), ("orb", 4, True),
+                                                      ("orb", 4, False), ("sift", 2, False)])
 def test_process_frames_equals_frame_by_frame(capsys, detector, workers, display):
     """process_frames (SIFT: detection, matching and RANSAC of several frames on worker threads ahead of the
     sequential part) leaves the same mosaic, homographies, features, matches and printed warnings as one
@@ -406,9 +412,10 @@ def test_process_frames_equals_frame_by_frame(capsys, detector, workers, display
     frames.insert(4, np.zeros_like(frames[0]))        # no features: skipped, the next frame matches frame 3
     frames.insert(7, np.zeros_like(frames[0]))
     frames.insert(8, np.zeros_like(frames[0]))        # two skipped frames in a row
-    # display on: every call completes before it returns, process_frames runs detection on worker threads;
-    # off (ORB): process_frame itself only enqueues and process_frames is a loop over it
-    kw = dict(detector_type=detector, visualize=False, show_intermediate=display, nfeatures=300)
+    # display: every call completes before it returns (pipeline_batch=0), process_frames runs detection on worker
+    # threads; otherwise process_frame itself only enqueues and process_frames is a loop over it
+    kw = dict(detector_type=detector, visualize=display, show_intermediate=display, nfeatures=300,
+              pipeline_batch=0 if display else 32)
     a = rtvm.VideMosaic(frames[0], **kw)
     Hs = []
     for t, f in enumerate(frames[1:], 1):
@@ -441,7 +448,7 @@ def test_process_frames_at_720p_equals_frame_by_frame(detector, nf):
     Gs, wh, ww = rtvm.synth.bounded_path(25, fh, fw, seed=2)
     world = rtvm.synth.make_world(wh, ww, seed=0)
     frames = list(rtvm.synth.render_video_torch(world, Gs, fh, fw, torch.device("cuda", 0)).cpu().numpy())
-    kw = dict(detector_type=detector, visualize=False, show_intermediate=True, nfeatures=nf)
+    kw = dict(detector_type=detector, nfeatures=nf, pipeline_batch=0)   # frame-synchronous: detection on worker threads
     a = rtvm.VideMosaic(frames[0], **kw)
     for t, f in enumerate(frames[1:], 1):
         a.process_frame(f, t)
@@ -457,18 +464,19 @@ def test_process_frames_at_720p_equals_frame_by_frame(detector, nf):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fh,fw,ch,cw,nf,batch", [(1080, 1920, 2160, 2304, 1000, 4), (2160, 3840, 4096, 16384, 4000, 3)])
-def test_full_size_configs_batched_equals_frame_by_frame(fh, fw, ch, cw, nf, batch):
-    """At the 1080p and the 4K / 16384-wide-canvas sizes the oracle is too slow to run per test; what is checked
-    there is the size-independent property of the batched path: any batching of the frames (detection ahead,
-    predicted masks, retries) gives the canvas, homography and status of frame-by-frame processing."""
+@pytest.mark.parametrize("fh,fw,ch,cw,nf,batch,n", [(1080, 1920, 2160, 2304, 1000, 4, 6),
+                                                    (2160, 3840, 4096, 16384, 4000, 3, 4)])
+def test_full_size_configs_batched_match_oracle_and_frame_by_frame(fh, fw, ch, cw, nf, batch, n):
+    """The 1080p stream shape and the 4K / 16384-wide-canvas configuration at their own sizes: the batched device
+    pipeline (detection ahead, predicted masks, pieces) against the CPU restatement frame by frame -- statuses,
+    match count, homography and every canvas pixel -- and against frame-by-frame processing on the device."""
     import torch
-    n = 7
     Gs, wh, ww = rtvm.synth.bounded_path(n + 1, fh, fw, seed=21)
     world = rtvm.synth.make_world(wh, ww, seed=3, n_shapes=4000)
     dev = torch.device("cuda", 0)
     frames = rtvm.synth.render_video_torch(world, Gs, fh, fw, dev)
     torch.cuda.synchronize()
+    host = frames.cpu().numpy()
     stride = fh * fw * 3
     base = frames.data_ptr()
     row_off, col_off = ch - fh, int(cw / 2 - fw / 2)
@@ -491,3 +499,11 @@ def test_full_size_configs_batched_equals_frame_by_frame(fh, fw, ch, cw, nf, bat
     assert np.array_equal(H_a, H_b)
     assert np.array_equal(canvas_a, canvas_b)
     assert canvas_a[row_off:row_off + 8, col_off:col_off + 8].any()
+    del canvas_a
+    om = OracleMosaic(host[0], nfeatures=nf, canvas_size=(ch, cw), glue="explicit")
+    for f in host[1:]:
+        om.process_frame(f)
+        assert om.status == 0
+    assert nm_b == om.n_matches
+    assert np.array_equal(H_b, om.H)
+    assert np.array_equal(canvas_b, om.canvas)

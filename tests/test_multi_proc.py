@@ -10,8 +10,9 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _start(seed, frames):
-    return subprocess.Popen([sys.executable, os.path.join(HERE, "multi_proc_helper.py"), str(seed), str(frames)],
+def _start(seed, frames, *shape):
+    return subprocess.Popen([sys.executable, os.path.join(HERE, "multi_proc_helper.py"), str(seed), str(frames)] +
+                            [str(v) for v in shape],
                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
 
@@ -22,10 +23,11 @@ def _result(p):
 
 
 @pytest.mark.gpu
-def test_two_processes_side_by_side_stitch_what_each_stitches_alone():
-    n = 96
-    alone = [_result(_start(seed, n)) for seed in (3, 4)]
-    procs = [_start(seed, n) for seed in (3, 4)]       # both at once on the one GPU
+@pytest.mark.parametrize("n,shape", [(96, ()), (40, (1080, 1920, 1000))])
+def test_two_processes_side_by_side_stitch_what_each_stitches_alone(n, shape):
+    """360 x 640 / 500 features, and the per-GPU shape of the eight-stream configuration (1080p, 1000 features)."""
+    alone = [_result(_start(seed, n, *shape)) for seed in (3, 4)]
+    procs = [_start(seed, n, *shape) for seed in (3, 4)]       # both at once on the one GPU
     together = [_result(p) for p in procs]
     for a, t in zip(alone, together):
         assert t["status"] == a["status"] == [0] * n

@@ -95,6 +95,35 @@ def test_hip_orb_bit_exact(h, w, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("h,w,n", [(1080, 1920, 1000), (2160, 3840, 4000)])
+def test_hip_orb_bit_exact_at_the_1080p_and_4k_sizes(h, w, n):
+    """The detection sizes of the 1080p streams and of the 4K / 4000-feature configuration: tile runs of the FAST
+    kernel over far more tiles, the selection's histogram and rank counting at 4000 features, the chained resize's
+    rectangle tables of a large pyramid.  One textured frame each, all six outputs."""
+    world = synth.make_world(h + 96, w + 96, seed=8, n_shapes=6000)
+    f = np.ascontiguousarray(world[48:48 + h, 48:48 + w])
+    c = rtvm.Context(h, w, 0, 0, nfeatures=n)
+    got, ref = c.orb(f), orc.orb(f, n)
+    assert np.array_equal(c.gray(f), orc.gray(f))
+    assert len(ref["xy"]) >= n * 0.95 and np.bincount(ref["octave"], minlength=8).min() > 0
+    _check_equal(got, ref)
+    c.close()
+
+
+@pytest.mark.gpu
+def test_hip_orb_frames_too_small_for_a_pyramid():
+    """Frames of fewer than 29 pixels a side: their upper levels are too small for the resize kernels and no level
+    can hold a keypoint; gray still works and the feature set is empty, as the oracle's."""
+    for h, w in ((20, 400), (300, 24)):
+        rng = np.random.default_rng(h)
+        f = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        c = rtvm.Context(h, w, 0, 0, nfeatures=100)
+        assert np.array_equal(c.gray(f), orc.gray(f))
+        assert len(c.orb(f)["xy"]) == 0 and len(orc.orb(f, 100)["xy"]) == 0
+        c.close()
+
+
+@pytest.mark.gpu
 def test_hip_orb_featureless_and_tiny():
     c = rtvm.Context(120, 160, 0, 0, nfeatures=100)
     flat = np.full((120, 160, 3), 77, np.uint8)

@@ -63,6 +63,20 @@ def test_hip_sift_matches_oracle(shape, nf, seed):
 
 
 @pytest.mark.gpu
+def test_hip_sift_at_1080p_with_2000_features_matches_oracle():
+    """The detection size of the 1080p SIFT-2000 configuration, every output field."""
+    h, w, nf = 1080, 1920, 2000
+    world = rtvm.synth.make_world(h + 64, w + 64, seed=12, n_shapes=5000)
+    a = np.ascontiguousarray(world[32:32 + h, 32:32 + w])
+    ctx = rtvm.Context()
+    got, want = ctx.sift(a, nf), orc.sift(a, nf)
+    assert len(got["xy"]) == len(want["xy"]) >= nf
+    for k in ("xy", "size", "angle", "response", "octave", "desc"):
+        assert np.array_equal(got[k], want[k]), k
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_hip_sift_flat_image_and_bad_arguments():
     ctx = rtvm.Context()
     flat = np.full((64, 80, 3), 90, np.uint8)

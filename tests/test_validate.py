@@ -95,11 +95,14 @@ def test_device_validate_matches_oracle(ctx_small):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("display", [True, False])
-def test_rejected_frames_through_the_dropin_match_oracle(capsys, display):
-    """display: every call completes before it returns; headless: the frame is only taken, flush() settles it."""
+@pytest.mark.parametrize("display,pipeline_batch", [(True, 0), (False, 0), (True, 32), (False, 32)])
+def test_rejected_frames_through_the_dropin_match_oracle(capsys, display, pipeline_batch):
+    """pipeline_batch=0: every call completes before it returns; otherwise the frame is only taken and flush()
+    settles it, whatever the display flags (the reference's defaults: both on) say."""
     frames, labels = rc.sequence()
-    vm = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=False, show_intermediate=display, nfeatures=500)
+    vm = rtvm.VideMosaic(frames[0], detector_type="orb", visualize=display, show_intermediate=display, nfeatures=500,
+                         pipeline_batch=pipeline_batch)
+    assert vm._deferred == (pipeline_batch > 0)
     om = OracleMosaic(frames[0], nfeatures=500, glue="numpy")
     texts = {0: "большое смещение", 1: "большое изменение масштаба", 2: "сильные перспективные искажения"}
     for t, (f, lab) in enumerate(zip(frames[1:], labels), 1):

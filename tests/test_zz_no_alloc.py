@@ -64,6 +64,23 @@ def test_noalloc_matcher_equals_the_context_matcher_on_consecutive_calls(ctx_sma
 
 
 @pytest.mark.gpu
+def test_noalloc_matcher_at_its_limit(ctx_small):
+    """The largest input the fixed scratch takes (both sides at RTVM_NOALLOC_MAX_DESCRIPTORS), then a small one."""
+    rng = np.random.default_rng(43)
+    n = F.NOALLOC_MAX_DESCRIPTORS
+    t1 = descriptors(rng, n)
+    q1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    rows = rng.permutation(n)[:n // 2]
+    q1[rows] = t1[rng.permutation(n)[:n // 2]] ^ rng.integers(0, 2, (n // 2, 32), dtype=np.uint8)
+    for q, t in ((q1, t1), (q1[:100], t1[:90])):
+        want = ctx_small.match_hamming(q, t, sorted_by_distance=True)
+        got = run_noalloc(q, t, True)
+        assert len(want[0]) == len(got[0]) > len(q) // 4
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_noalloc_matcher_refuses_what_the_fixed_scratch_cannot_hold():
     import torch
     d = torch.zeros((8, 32), dtype=torch.uint8, device="cuda")
@@ -75,4 +92,7 @@ def test_noalloc_matcher_refuses_what_the_fixed_scratch_cannot_hold():
         assert e.value.code == F.E_ARG and "at most %d" % F.NOALLOC_MAX_DESCRIPTORS in str(e.value)
     with pytest.raises(F.RtvmError):
         F.match_hamming_noalloc(d.data_ptr(), 8, d.data_ptr(), 8, o.data_ptr(), o.data_ptr(), o.data_ptr(), 0)
+    with pytest.raises(F.RtvmError) as e:   # descriptors are read as 16-byte words
+        F.match_hamming_noalloc(d.data_ptr() + 4, 4, d.data_ptr(), 8, o.data_ptr(), o.data_ptr(), o.data_ptr(), o.data_ptr())
+    assert e.value.code == F.E_ARG and "aligned" in str(e.value)
     torch.cuda.synchronize()

@@ -7,6 +7,8 @@ PAT=${2:-k_warp}
 mkdir -p "$OUT"
 LIB=real-time-video-mosaic_amd/lib/librtvm.so
 cp $LIB "$OUT/keep.so"
+# whatever happens, the build under test goes back where the package loads it from
+trap 'cp "$OUT/keep.so" $LIB; rm -f "$OUT/keep.so"' EXIT
 for so in abtest/*.so; do
     tag=$(basename $so .so)
     cp $so $LIB
@@ -25,4 +27,3 @@ for k in ks:
 P
     done
 done
-rm -f "$OUT"/keep.so
