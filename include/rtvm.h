@@ -38,7 +38,8 @@ enum {
     RTVM_E_HIP = -2,        /* HIP runtime error, or no device */
     RTVM_E_NOMEM = -3,      /* device or host allocation failed */
     RTVM_E_DEGENERATE = -4, /* geometry is degenerate (singular H, ...) */
-    RTVM_E_STATE = -5       /* call order violated (e.g. warp before canvas_init) */
+    RTVM_E_STATE = -5,      /* call order violated (e.g. warp before canvas_init) */
+    RTVM_E_CALLBACK = -6    /* a function the caller supplied (rtvm_glue_fn, rtvm_frame_source) reported a failure */
 };
 
 /* rtvm_create: detector */
@@ -310,6 +311,67 @@ int rtvm_batch_get_features(rtvm_ctx* ctx, long ticket, int index, int* n_out, f
                             float* angle_deg, float* response, int32_t* octave, uint8_t* desc);
 int rtvm_batch_get_matches(rtvm_ctx* ctx, long ticket, int index, int* m_out, int32_t* qidx, int32_t* tidx,
                            int32_t* dist);
+
+/* ---- the reference's main loop (main.py:1596-1634) as one call --------------------------------------
+ * `for frame in video: video_mosaic.process_frame(frame, i)` for n device-resident frames, after
+ * rtvm_stream_begin with the first frame: detection, matching and RANSAC of up to four batches (of `batch`
+ * frames, 1..32) run ahead of the canvas half, which follows in pieces of canvas_batch frames (0 = half a batch);
+ * the skip rules, validate, smooth and chain (main.py:722-746) are applied on the device.  Everything the batch
+ * entry points above leave to their caller happens inside: frames left pending behind a blend that cleared a
+ * canvas pixel get their canvas half queued again, frames detected behind a skipped frame are detected again.
+ * status[i] receives the RTVM_FRAME_* bits of frame i (never RTVM_FRAME_PENDING: every frame is consumed);
+ * stats (may be NULL) counts what was queued.  Returns when every frame has been stitched or skipped; H_abs of
+ * the last frame: rtvm_frame_status, the mosaic: rtvm_canvas_read. */
+typedef struct {
+    int frames, batches_queued, frames_queued, batches_with_pending_frames, retries, frames_retried, frames_void,
+        frames_detected_again, canvas_pieces, canvas_frames;
+} rtvm_video_stats;
+int rtvm_process_video(rtvm_ctx* ctx, const uint8_t* const* bgr_dev, int n, int batch, int canvas_batch,
+                       int32_t* status, rtvm_video_stats* stats);
+/* The same with the frames handed out batch by batch: source(user, first, count, dev) stores the device
+ * addresses of frames first .. first+count-1 (count <= batch; e.g. after copying them through the ingest ring)
+ * and returns RTVM_OK; it is asked for a range again when detection starts over after a skipped frame.
+ * pieces_in_flight: canvas halves queued ahead (0 = 2; 3 suits a source that copies host frames meanwhile).
+ * events (may be NULL): one record per canvas half whose outcome was read -- seconds on a steady clock, first
+ * video frame, length, frames consumed, RTVM_PENDING_* reason; *n_events counts them all, events_cap are kept. */
+typedef int (*rtvm_frame_source)(void* user, int first, int count, const uint8_t** dev);
+typedef struct {
+    double seconds;
+    int first, count, done, reason;
+} rtvm_video_event;
+int rtvm_process_video_source(rtvm_ctx* ctx, rtvm_frame_source source, void* user, int n, int batch, int canvas_batch,
+                              int pieces_in_flight, int32_t* status, rtvm_video_stats* stats, rtvm_video_event* events,
+                              int events_cap, int* n_events);
+
+/* ---- process_frame (main.py:710-759) as a call that only takes the frame, for hosts that keep the rules of
+ * main.py:722-746 on their side (public thresholds, a history the caller may read or replace: the Python
+ * VideMosaic).  rtvm_pipe_put copies a host frame (frame_h x frame_w x 3 u8) into a ring of pinned slots and
+ * returns; frames are detected, matched and fitted in batches of `batch`, up to four batches ahead.  When a
+ * batch's results are in, glue(user, frame, n_matches, found, H_rel, H_abs) is called for its frames in order,
+ * on the thread that is inside rtvm_pipe_put / rtvm_pipe_flush at that time: `frame` counts the put calls from 0,
+ * found = 0 means fewer than 4 matches or no model; it returns 1 after writing the absolute homography the frame
+ * is to be warped with, 0 when the frame is skipped (main.py:722-731: state not advanced; the frames detected
+ * behind it are detected again, matched against the last stitched frame), negative on failure (the call then
+ * returns RTVM_E_CALLBACK).  The frames to stitch are warped and blended in pieces of up to `piece` frames
+ * (0 = half a batch), three in flight; pieces that come back with frames pending are committed again.
+ * rtvm_pipe_flush returns when every frame taken so far has been dealt with.  One pipe per context; opening it
+ * reserves the batch slots and the ingest ring (rtvm_reserve_batch, rtvm_ingest_reserve). */
+typedef int (*rtvm_glue_fn)(void* user, long frame, int n_matches, int found, const double H_rel[9], double H_abs[9]);
+typedef struct {
+    long frames, batches, pieces, pieces_with_pending_frames, pieces_void, frames_detected_again;
+} rtvm_pipe_stats;
+int rtvm_pipe_open(rtvm_ctx* ctx, int batch, int piece, rtvm_glue_fn glue, void* user);
+int rtvm_pipe_put(rtvm_ctx* ctx, const uint8_t* bgr_host);
+int rtvm_pipe_flush(rtvm_ctx* ctx);
+/* 1 while frames taken by rtvm_pipe_put have not been dealt with, else 0. */
+int rtvm_pipe_busy(rtvm_ctx* ctx);
+/* After a flush the batch of the newest frame stays held (until the next rtvm_pipe_put detects again) so that
+ * kp_cur / des_cur / matches (main.py:718-720) can be read lazily: its ticket and the frame's index in it for
+ * rtvm_batch_get_features / rtvm_batch_get_matches; ticket 0 when there is none. */
+int rtvm_pipe_last(rtvm_ctx* ctx, long* ticket, int* index);
+int rtvm_pipe_get_stats(rtvm_ctx* ctx, rtvm_pipe_stats* out);
+/* Drops the pipe and what it still holds. */
+int rtvm_pipe_close(rtvm_ctx* ctx);
 
 /* Status bits, match count and the absolute homography of the most recent
  * rtvm_process_frame (any may be NULL).  Syncs the stream. */

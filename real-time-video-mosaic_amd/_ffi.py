@@ -6,13 +6,12 @@ opened, the calls raise.
 import ctypes as C
 import os
 
-import time
-
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librtvm.so")
-# Canvas-half pieces Context.process_video keeps queued for frames resident on the device (one more when the
+# RTVM_LIBRARY=<path> loads another build of the library (A/B runs of two builds on one box)
+LIB_PATH = os.environ.get("RTVM_LIBRARY") or os.path.join(_HERE, "lib", "librtvm.so")
+# Canvas-half pieces rtvm_process_video keeps queued for frames resident on the device (one more when the
 # frames come from host memory through the ingest ring): the outcome of a piece is read while the next one runs.  A
 # third one only adds a piece that did nothing (and its launches) to every mispredicted canvas mask: measured
 # 17 450 frames/s with three, 17 720 with two, 17 350 with four (720p ORB-1000).
@@ -92,6 +91,15 @@ SIGNATURES = {
     "rtvm_batch_rebase": (C.c_int, [_vp]),
     "rtvm_batch_get_features": (C.c_int, [_vp, C.c_long, C.c_int, _intp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtvm_batch_get_matches": (C.c_int, [_vp, C.c_long, C.c_int, _intp, _vp, _vp, _vp]),
+    "rtvm_process_video": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rtvm_process_video_source": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _intp]),
+    "rtvm_pipe_open": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "rtvm_pipe_put": (C.c_int, [_vp, _vp]),
+    "rtvm_pipe_flush": (C.c_int, [_vp]),
+    "rtvm_pipe_busy": (C.c_int, [_vp]),
+    "rtvm_pipe_last": (C.c_int, [_vp, C.POINTER(C.c_long), _intp]),
+    "rtvm_pipe_get_stats": (C.c_int, [_vp, _vp]),
+    "rtvm_pipe_close": (C.c_int, [_vp]),
     "rtvm_first_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "rtvm_frame_register": (C.c_int, [_vp, _vp, _intp, _intp, _vp]),
     "rtvm_frame_commit": (C.c_int, [_vp, _vp]),
@@ -102,6 +110,30 @@ SIGNATURES = {
     "rtvm_profile_stop": (C.c_int, [_vp]),
     "rtvm_profile_report": (C.c_int, [_vp, C.c_char_p, C.c_int]),
 }
+
+
+
+class VideoStats(C.Structure):
+    """rtvm_video_stats"""
+    _fields_ = [(k, C.c_int) for k in ("frames", "batches_queued", "frames_queued", "batches_with_pending_frames", "retries",
+                                       "frames_retried", "frames_void", "frames_detected_again", "canvas_pieces",
+                                       "canvas_frames")]
+
+
+class VideoEvent(C.Structure):
+    """rtvm_video_event"""
+    _fields_ = [("seconds", C.c_double), ("first", C.c_int), ("count", C.c_int), ("done", C.c_int), ("reason", C.c_int)]
+
+
+class PipeStats(C.Structure):
+    """rtvm_pipe_stats"""
+    _fields_ = [(k, C.c_long) for k in ("frames", "batches", "pieces", "pieces_with_pending_frames", "pieces_void",
+                                        "frames_detected_again")]
+
+
+FRAME_SOURCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p))   # rtvm_frame_source
+GLUE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p)   # rtvm_glue_fn (the matrices as addresses)
+E_CALLBACK = -6
 
 _lib = None
 HIP_RUNTIME = None   # path of the HIP runtime preloaded for librtvm.so (None: the linker's choice)
@@ -679,163 +711,80 @@ class Context:
         k = m.value
         return qi[:k].copy(), ti[:k].copy(), self._distances(di[:k].copy())
 
-    def _stitch_rest(self, ticket, start, k, first, status, stats, trace=None):
-        """Frames first .. k-1 of the detected batch `ticket` (video frames start+first ..) came back
-        pending although their detection, matching and RANSAC results stand: queues their canvas
-        half again, one frame at first (such events come in runs), twice as many after every retry
-        that goes through whole.  The next piece is queued before the outcome of the current one
-        is read, so the device does not wait for the host between pieces; when the current one
-        leaves frames pending, that next piece did nothing and is queued again.  Returns None when
-        all k frames are consumed, else the video frame from which detection has to start again (a
-        skipped frame invalidated the matching behind it)."""
-        skip_bits = FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY
-        m, pos, q = 1, first, []   # q: pieces in flight, oldest first: (ticket, first frame of the piece, length)
-
-        def queue():
-            nonlocal pos, m
-            cnt = min(m, k - pos)
-            q.append((self.batch_retry(ticket, pos, cnt), pos, cnt))
-            stats["retries"] += 1
-            stats["frames_retried"] += cnt
-            pos += cnt
-            m = min(2 * m, k)
-
-        while first < k:
-            while len(q) < 2 and pos < k:
-                queue()
-            t2, p0, cnt = q.pop(0)
-            d2, reason, st2, _, _ = self.batch_status_of(t2, cnt)
-            if trace is not None:
-                trace.append((time.perf_counter(), start + p0, cnt, d2, reason))
-            status[start + p0:start + p0 + d2] = st2[:d2]
-            first = p0 + d2
-            skipped = d2 > 0 and bool(st2[d2 - 1] & skip_bits)
-            if d2 == cnt and not skipped:
-                continue
-            for t3, _, c3 in q:   # queued behind a piece that left frames pending: void
-                self.batch_status_of(t3, c3)
-                stats["frames_void"] += c3
-            q.clear()
-            if skipped and d2 == cnt:
-                return start + first if start + first < len(status) else None
-            if reason != PENDING_MASK:
-                return start + first
-            m, pos = 1, first
-        return None
-
     def process_video(self, bgr_dev_ptrs, batch=16, trace=None, canvas_batch=None):
-        """process_frame over a whole list of device-resident frames.  Detection, matching and
-        RANSAC run up to four batches ahead (rtvm_batch_detect) of the canvas half, which follows in
-        pieces of canvas_batch frames (default: half a batch; rtvm_batch_retry), PIECES_IN_FLIGHT in flight.
-        Frames come back pending (a) behind a blend that cleared a canvas pixel and so broke the
-        canvas masks predicted for the rest of its piece: what was computed for them is lost
-        (hence pieces shorter than the detection batches: a piece of 16 frames costs no more per
-        frame than one of 32), the pieces queued behind did nothing, and the rest of that batch is
-        stitched one frame at first and twice as many after every piece that goes through whole,
-        while detection keeps running ahead; (b) behind a frame the reference skips: the frames
-        detected behind it were matched against the wrong frame, detection starts again from there.
-        Returns the per-frame status codes; self.video_stats counts what was queued.  trace: a
-        list that receives (seconds, first frame, length, frames consumed, reason) for every
-        canvas half whose outcome was read."""
-        # The loop allocates only short-lived tuples and lists (no reference cycles), but their
-        # number sets off the cyclic collector now and then, and a full collection in a process that
-        # has imported numpy and torch walks a million objects: 40 ms, the time of 500 frames.
-        import gc
-        collector_was_on = gc.isenabled()
-        gc.disable()
-        try:
-            return self._process_video(bgr_dev_ptrs, batch, trace, canvas_batch)
-        finally:
-            if collector_was_on:
-                gc.enable()
-
-    def _process_video(self, bgr_dev_ptrs, batch, trace, canvas_batch):
-        self.reserve_batch(batch)
+        """process_frame over a whole list of device-resident frames: rtvm_process_video.  Detection, matching and
+        RANSAC run up to four batches ahead of the canvas half, which follows in pieces of canvas_batch frames
+        (default: half a batch), PIECES_IN_FLIGHT in flight; frames that come back pending (behind a blend that
+        cleared a canvas pixel, behind a frame the reference skips) are dealt with inside the library.
+        bgr_dev_ptrs: a list of device addresses, or a frame source with acquire(first, k) -> addresses
+        (HostFrameRing).  Returns the per-frame status codes; self.video_stats counts what was queued.  trace: a
+        list that receives (seconds, first frame, length, frames consumed, reason) for every canvas half whose
+        outcome was read."""
         n = len(bgr_dev_ptrs)
-        cb = max(1, min(batch, canvas_batch if canvas_batch else (batch + 1) // 2))
-        # a frame source (HostFrameRing) hands out device addresses batch by batch; a list has them all
-        acquire = getattr(bgr_dev_ptrs, "acquire", None) or (lambda first, k: bgr_dev_ptrs[first:first + k])
-        # a frame source copies host frames while pieces run: one piece more keeps the device busy meanwhile
-        in_flight = PIECES_IN_FLIGHT + 1 if getattr(bgr_dev_ptrs, "acquire", None) else PIECES_IN_FLIGHT
-        status = np.zeros(n, np.int32)
-        det = []     # detected batches, oldest first: [detect ticket, first frame, length, frames queued, frames consumed]
-        inb = []     # canvas-half pieces in flight, oldest first: (batch entry, piece ticket, first frame of the batch, length)
-        nxt = 0      # next frame to detect
-        stats = {"frames": n, "batches_queued": 0, "frames_queued": 0, "batches_with_pending_frames": 0,
-                 "retries": 0, "frames_retried": 0, "frames_void": 0, "frames_detected_again": 0,
-                 "canvas_pieces": 0, "canvas_frames": 0}
-        skip_bits = FRAME_FEW_MATCHES | FRAME_NO_HOMOGRAPHY
+        status = np.zeros(max(n, 1), np.int32)
+        stats = VideoStats()
+        cap = 0 if trace is None else 8 * n + 64
+        events = (VideoEvent * cap)() if cap else None
+        n_events = C.c_int(0)
+        acquire = getattr(bgr_dev_ptrs, "acquire", None)
+        cb = int(canvas_batch or 0)
+        if acquire is None and trace is None:
+            arr = (C.c_void_p * max(n, 1))(*bgr_dev_ptrs)
+            self._check(lib().rtvm_process_video(self._h, arr, n, int(batch), cb, ptr(status), C.byref(stats)))
+        else:
+            failure = []
 
-        def start_over(frame):
-            # a skipped frame: everything detected behind it is void
-            nonlocal nxt
-            for rec in det:
-                self.batch_release(rec[0])
-            stats["frames_detected_again"] += nxt - frame
-            det.clear()
-            inb.clear()
-            nxt = frame
+            def source(user, first, count, dev):
+                try:
+                    got = acquire(first, count) if acquire else bgr_dev_ptrs[first:first + count]
+                    for j in range(count):
+                        dev[j] = got[j]
+                    return OK
+                except BaseException as e:   # must not unwind through the C frames
+                    failure.append(e)
+                    return E_CALLBACK
+            fn = FRAME_SOURCE(source)
+            # a frame source copies host frames while pieces run: one piece more keeps the device busy meanwhile
+            in_flight = PIECES_IN_FLIGHT + 1 if acquire else PIECES_IN_FLIGHT
+            rc = lib().rtvm_process_video_source(self._h, fn, None, n, int(batch), cb, in_flight, ptr(status), C.byref(stats),
+                                                 events, cap, C.byref(n_events))
+            if failure:
+                raise failure[0]
+            self._check(rc)
+        if trace is not None:
+            trace.extend((e.seconds, e.first, e.count, e.done, e.reason) for e in events[:min(cap, n_events.value)])
+        self.video_stats = {k: getattr(stats, k) for k, _ in VideoStats._fields_}
+        return status[:n]
 
-        def drain():
-            # the pieces queued behind a piece that left frames pending did nothing
-            for e2, t2, _, c2 in inb:
-                self.batch_status_of(t2, c2)
-                stats["frames_void"] += c2
-            inb.clear()
-            for e2 in det:
-                e2[3] = e2[4]
+    # ---- process_frame as a call that only takes the frame (rtvm_pipe_*) ----------------
+    def pipe_open(self, batch, piece, glue_fn):
+        """glue_fn: a GLUE_FN instance; the caller keeps it alive as long as the pipe."""
+        self._check(lib().rtvm_pipe_open(self._h, int(batch), int(piece), glue_fn, None))
 
-        while nxt < n or det:
-            while len(det) < 4 and nxt < n:
-                k = min(batch, n - nxt)
-                det.append([self.batch_detect(acquire(nxt, k)), nxt, k, 0, 0])
-                stats["batches_queued"] += 1
-                stats["frames_queued"] += k
-                nxt += k
-            while len(inb) < in_flight:
-                e = next((r for r in det if r[3] < r[2]), None)
-                if e is None:
-                    break
-                rem = e[2] - e[3]
-                cnt = rem if rem <= cb + cb // 2 else cb   # no short piece at the end of a batch: it costs a piece's fixed time
-                inb.append((e, self.batch_retry(e[0], e[3], cnt), e[3], cnt))
-                e[3] += cnt
-                stats["canvas_pieces"] += 1
-                stats["canvas_frames"] += cnt
-            e, bt, off, cnt = inb.pop(0)
-            start = e[1]
-            done, reason, st, _, _ = self.batch_status_of(bt, cnt)
-            status[start + off:start + off + done] = st[:done]
-            if trace is not None:
-                trace.append((time.perf_counter(), start + off, cnt, done, reason))
-            e[4] = off + done
-            skipped = done > 0 and bool(st[done - 1] & skip_bits)
-            if done == cnt and not skipped:
-                if e[4] == e[2]:
-                    self.batch_release(e[0])
-                    det.remove(e)
-                continue
-            if done == cnt:   # a skipped last frame: what follows was matched against it
-                drain()
-                if start + e[4] < n:
-                    start_over(start + e[4])
-                else:
-                    self.batch_release(e[0])
-                    det.remove(e)
-                continue
-            stats["batches_with_pending_frames"] += 1
-            drain()
-            if reason != PENDING_MASK:
-                start_over(start + e[4])
-                continue
-            # canvas half again for the rest of this batch; the batches behind it follow in pieces as before
-            redo = self._stitch_rest(e[0], start, e[2], e[4], status, stats, trace)
-            self.batch_release(e[0])
-            det.remove(e)
-            if redo is not None:
-                start_over(redo)
-        self.video_stats = stats
-        return status
+    def pipe_put(self, bgr):
+        """bgr: C-contiguous u8 array of the context's frame shape (the caller has checked).  Returns the code."""
+        return lib().rtvm_pipe_put(self._h, bgr.ctypes.data)   # the address as an integer: once per frame, no cast object
+
+    def pipe_flush(self):
+        return lib().rtvm_pipe_flush(self._h)
+
+    def pipe_busy(self):
+        return self._flag(lib().rtvm_pipe_busy(self._h))
+
+    def pipe_last(self):
+        """(ticket, index) of the newest frame in the batch that stays held after a flush, or None."""
+        t, i = C.c_long(0), C.c_int(-1)
+        self._check(lib().rtvm_pipe_last(self._h, C.byref(t), C.byref(i)))
+        return (t.value, i.value) if t.value else None
+
+    def pipe_stats(self):
+        st = PipeStats()
+        self._check(lib().rtvm_pipe_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in PipeStats._fields_}
+
+    def pipe_close(self):
+        if getattr(self, "_h", None):
+            self._check(lib().rtvm_pipe_close(self._h))
 
     # ---- frame ingest (host frames -> device ring) ------------------------------
     def ingest_reserve(self, n_slots):

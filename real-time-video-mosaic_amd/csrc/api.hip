@@ -342,6 +342,7 @@ void free_all(rtvm_ctx* c) {
         c->sift_buf[i] = nullptr;
         c->sift_bytes[i] = 0;
     }
+    rtvm_pipe_free(c);
     rtvm_ingest_pool_free(c);
     if (c->stream_copy) {
         (void)hipStreamSynchronize(c->stream_copy);

@@ -293,6 +293,7 @@ struct rtvm_ctx {
     hipEvent_t ev_ingest;      // the last copy queued
     int ingest_used;           // a copy was queued: streams that read frames wait for ev_ingest
     void* ingest_pool = nullptr;  // threads of rtvm_ingest_write (ingest.hip)
+    void* pipe = nullptr;         // state of rtvm_pipe_* (video.hip)
     int rs_alone = 0;   // at most a batch's worth of frames in flight: latency is what counts (ransac.hip)
     hipEvent_t ev_done[RTVM_REPORTS];  // batch number (seq % RTVM_REPORTS) is complete
     hipEvent_t ev_main;
@@ -456,6 +457,8 @@ int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int kind);
 size_t rtvm_ransac_state_bytes();
 void rtvm_ransac_raw_table(uint32_t* raw, int n);
 void rtvm_ingest_pool_free(rtvm_ctx* c);
+// video.hip
+void rtvm_pipe_free(rtvm_ctx* c);
 int rtvm_launch_ransac(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence);
 int rtvm_launch_ransac_search(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence);
 int rtvm_launch_ransac_refine(rtvm_ctx* c, int sb, int nb, double thresh);

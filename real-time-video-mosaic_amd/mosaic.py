@@ -20,7 +20,7 @@ order, at the latest then.  ``pipeline_batch=0`` opts out: every ``process_frame
 call then completes before it returns (``frame_register``: upload, detect, match,
 RANSAC; ``frame_commit``: warp, blend, state advance).
 """
-import collections
+import ctypes
 import threading
 
 import numpy as np
@@ -29,6 +29,7 @@ from . import _ffi
 from .types import KeyPoint, DMatch, keypoints_from_arrays, matches_from_arrays
 
 _stage_local = threading.local()
+_Mat9 = ctypes.c_double * 9
 
 
 def _stage_ctx(device=0):
@@ -42,225 +43,71 @@ def _stage_ctx(device=0):
     return ctxs[device]
 
 
-class _Batch:
-    """A detected batch of the headless pipeline."""
-    __slots__ = ("ticket", "idx0", "frames", "n", "res", "glued", "H", "queued", "done")
-
-    def __init__(self, ticket, idx0, frames):
-        self.ticket, self.idx0, self.frames, self.n = ticket, idx0, frames, len(frames)
-        self.res = None      # (matches, found, keypoints, H_rel) once read
-        self.glued = 0       # frames the host rules have been applied to
-        self.H = []          # absolute homographies of the frames to stitch: frames 0 .. len(H)-1
-        self.queued = 0      # of those, queued in commit pieces
-        self.done = 0        # of those, confirmed stitched
-
-
 class _Pipeline:
-    """process_frame without waiting (ORB or SIFT: the context's detector).  Frames go through a ring of pinned host slots
-    to the device; detection, matching and RANSAC run in batches of `batch` frames, up to three
-    batches ahead (rtvm_batch_detect); when a batch's results arrive the host applies main.py:722-746
-    to its frames in order (skip rules, validate, smooth, chain: the owner's own methods and
-    attributes); the frames to stitch are committed in pieces of up to `piece` frames
-    (rtvm_batch_commit), three in flight.
+    """process_frame without waiting (ORB or SIFT: the context's detector): the binding of rtvm_pipe_*.  Frames go
+    through a ring of pinned host slots to the device; detection, matching and RANSAC run in batches of `batch`
+    frames, up to four batches ahead; when a batch's results arrive the library calls back for each of its frames in
+    order and the owner's own methods and attributes apply main.py:722-746 (skip rules, validate, smooth, chain);
+    the frames to stitch are warped and blended in pieces of up to `piece` frames, three in flight.
 
-    The homographies do not depend on the canvas, so a piece that comes back with frames pending
-    (a blend cleared a canvas pixel: the canvas masks predicted for the frames behind it are
-    wrong) is simply committed again from the first pending frame, one frame at first and twice as
-    many each time.  A frame the reference skips (main.py:722-731) invalidates the matching of
-    everything detected behind it: those frames are detected again, matched against the last
-    stitched frame."""
+    The homographies do not depend on the canvas, so a piece that comes back with frames pending (a blend cleared a
+    canvas pixel: the canvas masks predicted for the frames behind it are wrong) is simply committed again from the
+    first pending frame.  A frame the reference skips (main.py:722-731) invalidates the matching of everything
+    detected behind it: those frames are detected again, matched against the last stitched frame.  All of that
+    happens inside the library (csrc/video.hip); what stays here is the frame objects the rules are handed and the
+    exception a rule may raise."""
 
     def __init__(self, vm, batch=32, piece=16):
         self.vm, self.ctx = vm, vm._ctx
-        self.B, self.P = int(batch), max(1, min(int(piece), int(batch)))
-        self.ctx.reserve_batch(self.B)
-        self.R = 6 * self.B                      # four batches alive, one being filled, one spare
-        self.ctx.ingest_reserve(self.R)
-        self.views = [self.ctx.ingest_host_slot(i) for i in range(self.R)]
-        self.n_in = 0                            # frames taken so far
-        self.retired = 0                         # frames whose ring slot may be written again
-        self.pend = collections.deque()          # (index, frame) in the ring, not yet detected
-        self.batches = collections.deque()       # detected batches, oldest first
-        self.inflight = collections.deque()      # commit pieces, oldest first: (ticket, batch, first, count)
-        self.m = self.P                          # frames of the next piece
-        self.need_rebase = False
-        self.flushing = False
-        self.held = None                         # the batch of the last frame, kept for kp_cur / matches
-        self.last = None                         # (batch, index) of the last frame the rules were applied to
-        self.stats = {"frames": 0, "batches": 0, "pieces": 0, "pieces_with_pending_frames": 0,
-                      "pieces_void": 0, "frames_detected_again": 0}
+        self.shape = (self.ctx.frame_h, self.ctx.frame_w, 3)
+        self.frames = {}      # index -> the array handed to process_frame, until the rules have been applied to it
+        self.n_in = 0
+        self.error = None
 
-    # ------------------------------------------------------------------ the caller's side
+        def glue(user, index, n_matches, found, H_rel, H_abs):
+            try:
+                frame = self.frames.pop(index)
+                Hr = np.frombuffer(_Mat9.from_address(H_rel), np.float64).reshape(3, 3).copy()
+                H = vm._glue(frame, n_matches, bool(found), Hr)
+                if H is None:
+                    return 0
+                ctypes.memmove(H_abs, np.ascontiguousarray(H, np.float64).ctypes.data, 72)
+                return 1
+            except BaseException as e:   # must not unwind through the C frames; raised again by _check
+                self.error = e
+                return -1
+        self._glue_fn = _ffi.GLUE_FN(glue)
+        self.ctx.pipe_open(int(batch), max(1, min(int(piece), int(batch))), self._glue_fn)
+
+    def _check(self, rc):
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+        self.ctx._check(rc)
+
+    @property
+    def stats(self):
+        return self.ctx.pipe_stats()
+
     def put(self, frame):
-        idx = self.n_in
-        while idx - self.retired >= self.R:      # the slot still holds a frame that may be needed again
-            self._pump(block=True)
-        view = self.views[idx % self.R]
-        if frame.shape != view.shape:
-            raise ValueError("process_frame: frame of shape %s, the mosaic was created for %s" % (frame.shape, view.shape))
-        if frame.dtype == np.uint8 and frame.flags["C_CONTIGUOUS"]:
-            self.ctx.ingest_write(idx % self.R, frame)   # complete on return, on several threads for large frames
-        else:
-            np.copyto(view, frame)
-        self.pend.append((idx, frame))
+        if frame.shape != self.shape:
+            raise ValueError("process_frame: frame of shape %s, the mosaic was created for %s" % (frame.shape, self.shape))
+        self.frames[self.n_in] = frame
         self.n_in += 1
-        self.stats["frames"] += 1
-        self._pump(block=False)
+        self._check(self.ctx.pipe_put(frame))   # complete on return: the caller may reuse the array
 
     def busy(self):
-        return bool(self.pend or self.batches)
+        return self.ctx.pipe_busy()
 
     def flush(self):
-        self.flushing = True
-        try:
-            while self.pend or self.batches:
-                self._pump(block=True)
-        finally:
-            self.flushing = False
+        self._check(self.ctx.pipe_flush())
+
+    def last(self):
+        return self.ctx.pipe_last()
 
     def close(self):
-        self.pend.clear()
-        self.batches.clear()
-        self.inflight.clear()
-        self.held = None
-
-    # ------------------------------------------------------------------ the state machine
-    def _live_sets(self):
-        return len(self.batches) + (1 if self.held is not None else 0)
-
-    def _pump(self, block):
-        progressed = self._detect()
-        progressed |= self._results(block and not self.inflight)
-        progressed |= self._commit()
-        progressed |= self._confirm(block)
-        progressed |= self._retire()
-        if block and not progressed:
-            # nothing was there to wait for: detection must be possible now
-            if not self._detect(force=True) and (self.pend or self.batches):
-                raise RuntimeError("VideMosaic pipeline stalled (%d frames waiting, %d batches)"
-                                   % (len(self.pend), len(self.batches)))
-
-    def _detect(self, force=False):
-        progressed = False
-        while self.pend and (len(self.pend) >= self.B or self.flushing or force):
-            if self.need_rebase:
-                # what is detected next is matched against the last stitched frame: its commit
-                # (which makes its features the previous ones) has to be confirmed first
-                if self.inflight or any(b.done < len(b.H) or b.glued < b.n for b in self.batches):
-                    break
-                self.ctx.batch_rebase()
-                self.need_rebase = False
-            if self.held is not None:            # the lazy reads of the last flush are over
-                self.ctx.batch_release(self.held.ticket)
-                self.held = None
-            if self._live_sets() >= 4:
-                break
-            k = min(self.B, len(self.pend))
-            items = [self.pend.popleft() for _ in range(k)]
-            idx0 = items[0][0]
-            s0 = idx0 % self.R
-            if s0 + k <= self.R:
-                ptrs = self.ctx.ingest_submit_range(s0, k)
-            else:
-                ptrs = [self.ctx.ingest_submit((idx0 + j) % self.R) for j in range(k)]
-            ticket = self.ctx.batch_detect(ptrs)
-            self.batches.append(_Batch(ticket, idx0, [f for _, f in items]))
-            self.stats["batches"] += 1
-            progressed = True
-            force = False
-        return progressed
-
-    def _results(self, block):
-        b = next((x for x in self.batches if x.res is None), None)
-        if b is None or not (block or self.ctx.batch_results_ready(b.ticket)):
-            return False
-        b.res = self.ctx.batch_results(b.ticket, b.n)
-        nm, fd, _, Hrel = b.res
-        vm = self.vm
-        for j in range(b.n):
-            H = vm._glue(b.frames[j], int(nm[j]), bool(fd[j]), Hrel[j])
-            b.glued = j + 1
-            self.last = (b, j)
-            if H is not None:
-                b.H.append(H)
-                continue
-            # the frame is skipped and the state did not advance: everything detected behind it was
-            # matched against the wrong frame
-            redo = [(b.idx0 + i, b.frames[i]) for i in range(j + 1, b.n)]
-            b.frames, b.n = b.frames[:j + 1], j + 1
-            again = len(redo)
-            while self.batches[-1] is not b:
-                later = self.batches.pop()
-                self.ctx.batch_release(later.ticket)
-                redo_later = [(later.idx0 + i, f) for i, f in enumerate(later.frames)]
-                self.pend.extendleft(reversed(redo_later))
-                again += len(redo_later)
-            self.pend.extendleft(reversed(redo))
-            self.stats["frames_detected_again"] += again
-            self.need_rebase = True
-            break
-        return True
-
-    def _commit(self):
-        progressed = False
-        while len(self.inflight) < 3:
-            b = next((x for x in self.batches if x.queued < len(x.H)), None)
-            if b is None:
-                break
-            if any(x.res is None or x.queued < len(x.H) for x in self._before(b)):
-                break                            # frame order across batches
-            cnt = min(self.m, len(b.H) - b.queued)
-            t = self.ctx.batch_commit(b.ticket, b.queued, b.H[b.queued:b.queued + cnt])
-            self.inflight.append((t, b, b.queued, cnt))
-            b.queued += cnt
-            self.m = min(2 * self.m, self.P)
-            self.stats["pieces"] += 1
-            progressed = True
-        return progressed
-
-    def _before(self, b):
-        for x in self.batches:
-            if x is b:
-                return
-            yield x
-
-    def _confirm(self, block):
-        if not self.inflight:
-            return False
-        t, b, first, cnt = self.inflight[0]
-        if not (block or self.ctx.batch_done(t)):
-            return False
-        self.inflight.popleft()
-        done = self.ctx.batch_status_of(t, cnt)[0]
-        b.done = first + done
-        if done < cnt:
-            # a blend cleared a canvas pixel: the frames behind it are committed again (their
-            # homographies stand); the pieces queued behind did nothing
-            self.stats["pieces_with_pending_frames"] += 1
-            for t2, _, _, c2 in self.inflight:
-                self.ctx.batch_status_of(t2, c2)
-                self.stats["pieces_void"] += 1
-            self.inflight.clear()
-            for x in self.batches:
-                x.queued = x.done
-            self.m = 1
-        return True
-
-    def _retire(self):
-        progressed = False
-        while self.batches:
-            b = self.batches[0]
-            if b.res is None or b.glued < b.n or b.done < len(b.H):
-                break
-            self.batches.popleft()
-            self.retired = b.idx0 + b.n
-            b.frames = None
-            if not self.batches and not self.pend:
-                self.held = b                    # the batch of the newest frame: kp_cur / matches read from it
-            else:
-                self.ctx.batch_release(b.ticket)
-            progressed = True
-        return progressed
+        self.frames.clear()
+        self.ctx.pipe_close()
 
 
 class VideMosaic:
@@ -324,6 +171,9 @@ class VideMosaic:
     def process_first_frame(self, first_image):
         """main.py:104-112 plus the canvas set-up of main.py:80-90."""
         self._sync()
+        if getattr(self, "_pipe", None) is not None:   # a new video: the stream's batches start over
+            self._pipe.close()
+            self._pipe = None
         self.frame_prev = first_image
         self.frame_cur = first_image
         if self._staged_sift:
@@ -580,10 +430,7 @@ class VideMosaic:
     # ------------------------------------------------------------------ lazily fetched state
     def _held_frame(self):
         """(ticket, index) of the newest frame when it went through the pipeline, else None."""
-        p = self._pipe
-        if p is None or p.held is None or p.last is None or p.last[0] is not p.held:
-            return None
-        return p.held.ticket, p.last[1]
+        return None if self._pipe is None else self._pipe.last()
 
     def _features(self, slot):
         if self._staged_sift:

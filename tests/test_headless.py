@@ -183,3 +183,98 @@ def test_device_stream_with_the_sift_detector_matches_oracle(batch):
     with pytest.raises(RuntimeError):
         ctx.orb(frames[0])
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_an_exception_in_the_callers_rules_surfaces_from_process_frame_or_flush():
+    """The rules run inside the library's call-back; what they raise is raised again by the call that was in
+    progress (process_frame or a read), not swallowed."""
+    frames, _ = synth.make_video(FH, FW, 8, world_size=(520, 620), seed=3)
+    vm = rtvm.VideMosaic(frames[0], detector_type="orb", nfeatures=300, pipeline_batch=4)
+    calls = []
+
+    def picky(H):
+        calls.append(1)
+        if len(calls) == 3:
+            raise ValueError("no thanks")
+        return True
+    vm.validate_homography = picky
+    with pytest.raises(ValueError, match="no thanks"):
+        for t in range(1, 8):
+            vm.process_frame(frames[t], t)
+        vm.flush()
+    assert len(calls) == 3
+    vm.close()
+
+
+@pytest.mark.gpu
+def test_process_video_through_a_frame_source_with_events_and_a_failing_source():
+    """rtvm_process_video_source: the frames handed out batch by batch by a Python function, the canvas halves'
+    outcomes as events; a source that fails ends the call with its own exception."""
+    import torch
+    frames, _ = synth.make_video(FH, FW, 20, world_size=(520, 620), seed=5)
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+    ptrs = [d.data_ptr() for d in dev[1:]]
+
+    class Source:
+        def __init__(self, fail_at=None):
+            self.asked, self.fail_at = [], fail_at
+
+        def __len__(self):
+            return len(ptrs)
+
+        def acquire(self, first, k):
+            self.asked.append((first, k))
+            if self.fail_at is not None and first >= self.fail_at:
+                raise KeyError("frame %d is gone" % first)
+            return ptrs[first:first + k]
+
+    a = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=400)
+    a.stream_begin(dev[0].data_ptr(), FH, int(1.2 * FW / 2 - FW / 2))
+    st_a = a.process_video(ptrs, batch=8)
+    want = a.canvas_read()
+    a.close()
+    b = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=400)
+    b.stream_begin(dev[0].data_ptr(), FH, int(1.2 * FW / 2 - FW / 2))
+    src, trace = Source(), []
+    st_b = b.process_video(src, batch=8, trace=trace)
+    assert st_b.tolist() == st_a.tolist() == [0] * 20 and np.array_equal(b.canvas_read(), want)
+    assert src.asked == [(0, 8), (8, 8), (16, 4)]
+    assert sum(e[3] for e in trace) == 20 and all(e[4] == 0 for e in trace)      # every frame consumed once, nothing pending
+    assert all(t1[0] >= t0[0] for t0, t1 in zip(trace, trace[1:]))
+    assert b.video_stats["frames"] == 20 and b.video_stats["canvas_frames"] == 20
+    b.stream_begin(dev[0].data_ptr(), FH, int(1.2 * FW / 2 - FW / 2))
+    with pytest.raises(KeyError, match="frame 8 is gone"):
+        b.process_video(Source(fail_at=8), batch=8)
+    b.close()
+
+
+@pytest.mark.gpu
+def test_pipe_entry_points_refuse_misuse():
+    F = rtvm._ffi
+    frames, _ = synth.make_video(FH, FW, 3, world_size=(520, 620), seed=5)
+    ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=300)
+    noop = F.GLUE_FN(lambda *a: 0)
+    with pytest.raises(F.RtvmError) as e:       # no stream yet
+        ctx.pipe_open(4, 2, noop)
+    assert e.value.code == F.E_STATE
+    ctx.first_frame(frames[0], FH, 32)
+    inside = []
+
+    def glue(user, index, nm, found, H_rel, H_abs):
+        inside.append(F.lib().rtvm_pipe_flush(ctx._h))     # from inside the rules: refused, not a deadlock
+        return 0
+    fn = F.GLUE_FN(glue)
+    ctx.pipe_open(2, 1, fn)
+    with pytest.raises(F.RtvmError) as e:       # one pipe per context
+        ctx.pipe_open(2, 1, fn)
+    assert e.value.code == F.E_STATE
+    for f in frames[1:]:
+        assert ctx.pipe_put(np.ascontiguousarray(f)) == F.OK
+    assert ctx.pipe_flush() == F.OK and not ctx.pipe_busy()
+    assert inside and all(rc == F.E_STATE for rc in inside)
+    assert ctx.pipe_stats()["frames"] == 2
+    ctx.pipe_close()
+    ctx.pipe_open(2, 1, fn)                     # and again after closing; the ring is kept
+    ctx.close()

@@ -31,6 +31,16 @@ namespace {
 
 constexpr int RS_BATCH0 = 64;  // iterations evaluated in the first two stages (a quarter of them in the first)
 
+#ifdef RTVM_RS_TRACE
+__device__ long long g_tr[16];
+__device__ __forceinline__ long long tnow() { return (long long)__builtin_readcyclecounter(); }
+#define TR(i) do { if ((threadIdx.x & 63) == 0) g_tr[i] = tnow(); } while (0)
+#define TRADD(i, v) do { if ((threadIdx.x & 63) == 0) g_tr[i] += (v); } while (0)
+#else
+#define TR(i)
+#define TRADD(i, v)
+#endif
+
 struct RsState {
     int niters, max_good, best, done, found, fail_at, next_pos, next_iter;
 };
@@ -72,49 +82,6 @@ __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
     return v;
-}
-
-// The same sums (and maxima) for NE values per lane at once, through LDS instead of NE butterflies (a butterfly
-// is six dependent trips through the LDS crossbar, and a lone wave waits for each of them): lane l stores its
-// values in column l of an NE x 64 table, then lane e < NE adds the 64 entries of row e in the butterfly's order
-// -- v[j] + v[j ^ 32] first, then ^ 16, ..., ^ 1, a balanced tree that is the same for every lane of the butterfly
-// because IEEE addition commutes -- so the result has the bits of wave_sum.  Row stride 65: the lanes' stores are
-// consecutive words and their reads of a row two banks apart.
-constexpr int WS_STRIDE = 65;
-struct OpAdd {
-    static __device__ __forceinline__ double f(double a, double b) { return a + b; }
-};
-struct OpMax {
-    static __device__ __forceinline__ double f(double a, double b) { return fmax(a, b); }
-};
-template <int S, class Op>
-struct WsTree {
-    static __device__ __forceinline__ double run(const double* r, int j) {
-        return Op::f(WsTree<2 * S, Op>::run(r, j), WsTree<2 * S, Op>::run(r, j + S));
-    }
-};
-template <class Op>
-struct WsTree<64, Op> {
-    static __device__ __forceinline__ double run(const double* r, int j) { return r[j]; }
-};
-// Lane e < NE returns the sum over the wave of acc[e] (entries >= n_max: their maximum); other lanes a value
-// nobody reads.  T: NE * WS_STRIDE doubles of LDS, free again after the call.
-template <int NE>
-__device__ __forceinline__ double wave_reduce_rows(const double (&acc)[NE], double* T, int n_max = NE) {
-    const int lane = threadIdx.x & 63;
-    wave_lds_phase();
-#pragma unroll
-    for (int e = 0; e < NE; e++) T[e * WS_STRIDE + lane] = acc[e];
-    wave_lds_phase();
-    const double* row = T + (lane < NE ? lane : 0) * WS_STRIDE;
-    const double sum = WsTree<1, OpAdd>::run(row, 0);
-    double r = sum;
-    if (n_max < NE) {
-        const double mx = WsTree<1, OpMax>::run(row, 0);
-        r = lane >= n_max ? mx : sum;
-    }
-    wave_lds_phase();
-    return r;
 }
 
 // Lane j of a row of 16 lanes receives the value of lane j - N of the same row (row_shr:N on the
@@ -171,139 +138,163 @@ __device__ __forceinline__ double row_all_max(double v) {
     v = max_f64(v, dpp_f64<0x140>(v));  // row_mirror
     return v;
 }
-// cv::JacobiImpl_<double> executed by one full wave on LDS-resident matrices
-// (A: n x n, only the upper triangle is used and it is destroyed; V: rows are the
-// eigenvectors; W: eigenvalues, descending).  The pivot choice, the rotation
-// formulas and the bookkeeping of the per-row / per-column maxima follow the
-// sequential algorithm exactly; lanes only share out independent element updates.
-__device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int* indR, int* indC, int* perm, int n) {
+// Every lane receives the value its image in the lower half of the wave (lane & 31) holds (lo) and the value
+// its image in the upper half (lane | 32) holds (hi): one exchange of the halves of two copies.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void halves_i32(int v, int& lo, int& hi) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    lo = (int)r.x;
+    hi = (int)r.y;
+}
+__device__ __forceinline__ void halves_f64(double v, double& lo, double& hi) {
+    int l0, h0, l1, h1;
+    halves_i32(__double2loint(v), l0, h0);
+    halves_i32(__double2hiint(v), l1, h1);
+    lo = __hiloint2double(l1, l0);
+    hi = __hiloint2double(h1, h0);
+}
+
+// cv::JacobiImpl_<double> executed by one full wave (A: n x n in LDS, only the upper triangle is used and it
+// is destroyed; V: rows are the eigenvectors; W: eigenvalues, descending; n <= 9).  The pivot choice, the
+// rotation formulas and the bookkeeping of the per-row / per-column maxima follow the sequential algorithm
+// exactly; lanes only share out independent element updates.
+//
+// A lone wave is bound by the chain of dependent instructions of one rotation, so nothing on that chain goes
+// through LDS.  The sequential code keeps, per row r, the column indR[r] of the largest |a| right of the
+// diagonal and, per column c, the row indC[c] of the largest |a| above it, finds the pivot among the elements
+// those (possibly stale) indices point at, and after a rotation scans rows and columns k and l again.  Here
+// lane i16 of the groups of 16 lanes 0 and 2 holds (indR[i16], |A[i16][indR[i16]]|), of groups 1 and 3
+// (indC[i16], |A[indC[i16]][i16]|), and W[i16], in registers:
+//   * the pivot is a maximum over registers (rows in group 0, columns in group 1);
+//   * every group computes the rotated pairs of A (lane i16 < n: the pair that row / column i16 shares with k
+//     and l), so a lane refreshes the value its index points at from its own pair, and the four scans (row k,
+//     column k, row l, column l: groups 0..3) are maxima over the pairs' registers;
+//   * the halves of the wave exchange the scans' results (lanes k and l take them);
+//   * the pairs of V belong to lanes 9..15 of the four groups.
+// LDS holds A and V for the pair loads of the next rotation (requested as soon as k and l are known, consumed
+// after the coefficients' divisions and square roots) and the sign of the pivot.
+__device__ __forceinline__ void jacobi_wave(double* A, double* W, double* V, int* perm, int n) {
     const int lane = threadIdx.x & 63;
     const double eps = DBL_EPSILON;
     for (int e = lane; e < n * n; e += 64) V[e] = (e / n == e % n) ? 1. : 0.;
-    // One index array for both kinds of maxima, so that the pivot search reads its 2n - 2 candidates
-    // with one address per lane: ind[r] = column of the largest |a| of row r right of the diagonal
-    // (rows 0..n-2), ind[n - 2 + c] = row of the largest |a| of column c above it (columns 1..n-1).
-    int* ind = indR;  // 16 entries are enough for n <= 9
-    (void)indC;
-    if (lane < 16) ind[lane] = 0;  // every lane reads an entry, the candidates' are set below
-    wave_lds_phase();
-    if (lane < n) {
-        const int k = lane;
-        W[k] = A[(n + 1) * k];
-        if (k < n - 1) {
-            int m = k + 1;
-            double mv = fabs(A[n * k + m]);
-            for (int i = k + 2; i < n; i++) {
-                const double val = fabs(A[n * k + i]);
-                if (mv < val) mv = val, m = i;
-            }
-            ind[k] = m;
+    const int i16 = lane & 15, grp = lane >> 4;
+    const bool colk = (grp & 1) != 0;   // this lane keeps a column's maximum (else a row's)
+    const int of_l = grp >> 1;          // its group scans row / column l after a rotation (else k)
+    // rows 0..n-2 and columns 1..n-1 have candidates
+    const bool cand = colk ? (i16 >= 1 && i16 < n) : (i16 < n - 1);
+    int sind = 0;
+    double sabs = -1.;
+    double Wi = i16 < n ? A[(n + 1) * i16] : 0.;
+    if (cand) {
+        // first largest |a| of row i16 right of the diagonal (elements n*i16 + i16+1+t) / of column i16 above
+        // it (elements n*t + i16)
+        const int cnt = colk ? i16 : n - 1 - i16;
+        const int e0 = colk ? i16 : n * i16 + i16 + 1, es = colk ? n : 1, m0 = colk ? 0 : i16 + 1;
+        int m = m0;
+        double mv = fabs(A[e0]);
+        for (int t = 1; t < cnt; t++) {
+            const double val = fabs(A[e0 + es * t]);
+            if (mv < val) mv = val, m = m0 + t;
         }
-        if (k > 0) {
-            int m = 0;
-            double mv = fabs(A[k]);
-            for (int i = 1; i < k; i++) {
-                const double val = fabs(A[n * i + k]);
-                if (mv < val) mv = val, m = i;
-            }
-            ind[n - 2 + k] = m;
-        }
+        sind = m;
+        sabs = mv;
     }
     __syncthreads();
     const int maxIters = n * n * 30;
-    const bool is_row = lane < n - 1, is_cand = lane < 2 * n - 2;
-    const int voff = (int)(V - A);  // V addressed from A: one base for the rotation's loads and stores
-    // What the lanes' parts in a rotation do not depend on the pivot for, arranged so that the pivot enters
-    // by arithmetic only (choices between differently computed addresses compile to branches on the
-    // execution mask, a dozen per rotation).
-    // Rotation: lanes 0..n-1 take the pair of A that row / column lane shares with k and l (none for
-    // lane = k, l): elements n * min(lane, k) + max(lane, k) and the same with l; lanes 16..16+n-1 take the
-    // pair of V of column lane - 16: elements voff + n * k + lane - 16 and the same with l, which is the same
-    // formula for an index rr = lane - 16 + 64 beyond every k and a base 64 lower.
-    const bool isA = lane < n, live = isA || (lane >= 16 && lane < 16 + n);
-    const int rr = isA ? lane : lane + 48, rbase = isA ? 0 : voff - 64;
-    // Scans: the four groups of 16 lanes take row k, column k, row l, column l; lane i16 of a group looks at
-    // element i16: of a row idx that is A[n * idx + i16] for idx < i16 < n, of a column A[n * i16 + idx] for
-    // i16 < idx.
-    const int i16 = lane & 15;
-    const bool col = (lane & 16) != 0;
-    const int of_l = (lane >> 5) & 1;                               // idx = k + of_l * (l - k)
-    const int scan_a = col ? n * i16 : i16, scan_b = col ? 1 : n;   // the element: scan_a + scan_b * idx
-    const int side_i = col ? -i16 : i16, side_s = col ? -1 : 1;     // it exists iff side_i - side_s * idx > 0 ...
-    const bool in_n = col || i16 < n;                               // ... and i16 < n
-    const int slot_off = col ? n - 2 : 0;
+    int jac_rot = 0;
+    const int voff = (int)(V - A);
+    // The pairs: lanes i16 < n take the pair of A of index i16: elements n * min(i16, k) + max(i16, k) and the same
+    // with l (none for i16 = k, l); lanes i16 >= 9 take the pair of V of column vi: elements voff + n * k + vi and
+    // the same with l, which is the same formula for an index rr = vi + 64 beyond every k and a base 64 lower.
+    const bool isA = i16 < n;
+    const int vi = grp * 7 + i16 - 9;
+    const bool live = isA || (i16 >= 9 && vi < n);
+    const int rr = isA ? i16 : vi + 64, rbase = isA ? 0 : voff - 64;
+    const bool writes = !isA || grp == 0;   // the pairs of A are the same in the four groups: group 0 stores them
     if (n > 1)
         for (int iters = 0; iters < maxIters; iters++) {
-            // pivot: first maximum over rows 0..n-2, then columns 1..n-1
-            // the candidate element and the two eigenvalue estimates it would touch (lanes that are no
-            // candidates read element (0, 0) and never win)
-            const int ix = ind[lane & 15];
-            const int ck = is_row ? lane : is_cand ? ix : 0;
-            const int cl = is_row ? ix : is_cand ? lane - (n - 2) : 0;
-            double sval = A[n * ck + cl], wck = W[ck], wcl = W[cl];
-            // (all three requested here, in one round trip: the estimates are not needed to recognise the
-            // end of the iteration, and the compiler would fetch them after that test, in a trip of their own)
-            asm volatile("" : "+v"(sval), "+v"(wck), "+v"(wcl));
-            const double val = is_cand ? fabs(sval) : -1.;
-            const double mx = row0_max(val);  // the 2n-2 <= 16 candidates sit in lanes 0..15
-            const unsigned long long hit = __ballot(val == mx);
-            const int win = __builtin_ctzll(hit);  // some lane holds the maximum
-            const int k = __builtin_amdgcn_readlane(ck, win), l = __builtin_amdgcn_readlane(cl, win);
-            const double p = readlane_f64(sval, win);
-            if (fabs(p) <= eps) break;
-            const double wk = readlane_f64(wck, win), wl = readlane_f64(wcl, win);
-            // The pairs are requested now (only k and l are needed to find them) and arrive while the
-            // divisions and square roots of the rotation's coefficients run.
+            // pivot: first maximum over rows 0..n-2 (group 0), then over columns 1..n-1 (group 1) if larger
+            const double v = cand ? sabs : -1.;
+            const double gm = row_all_max(v);
+            const unsigned long long hit = __ballot(v == gm);
+            const double m1 = readlane_f64(gm, 0), m2 = readlane_f64(gm, 16);
+            const bool from_col = m2 > m1;
+            const double pabs = from_col ? m2 : m1;   // |p|
+            if (pabs <= eps) break;
+            const unsigned h16 = (unsigned)(from_col ? hit >> 16 : hit) & 0xFFFFu;
+            const int win = __builtin_ctz(h16);   // some lane holds the maximum
+            const int other = __builtin_amdgcn_readlane(sind, win + (from_col ? 16 : 0));
+            const int k = from_col ? other : win, l = from_col ? win : other;
+            const double wk = readlane_f64(Wi, k), wl = readlane_f64(Wi, l);
+            // The pairs and the pivot (for its sign) are requested now and arrive while the divisions and
+            // square roots of the rotation's coefficients run.
             const bool act = live && rr != k && rr != l;
             const int e0 = rbase + n * min(rr, k) + max(rr, k);
             const int e1 = rbase + n * min(rr, l) + max(rr, l);
             double a0 = 0, b0 = 0;
             if (act) a0 = A[e0], b0 = A[e1];
+            const double p = A[n * k + l];
+#ifdef FAKE_MATH
+            double c = 0.8 + 1e-9 * (wl - wk), s = 0.6 * (p > 0 ? 1. : -1.), t = pabs * 0.3;
+#else
             const double y = (wl - wk) * 0.5;
-            double t = fabs(y) + cv_hypot_nz(p, y);  // |p| > eps
+            double t = fabs(y) + cv_hypot_nz(pabs, y);  // |p| > eps
             // hypot(p, t): t >= hypot(p, y) >= |p|, so t is the larger magnitude (for t = |p| both orders give
             // the same), and its ratio q = |p| / t is, but for the sign of p, the quotient p / t of the next
             // line of the sequential code: (p / t) * p = q * |p| bit for bit.  One division less.
-            const double q = fabs(p) / t;
+            const double q = pabs / t;
             double s = t * sqrt_1to2(1 + q * q);
             const double c = t / s;
             s = p / s;
-            t = q * fabs(p);
+            t = q * pabs;
             if (y < 0) s = -s, t = -t;
+#endif
             // W[k] -= t, W[l] += t on the values the pivot search already holds
             double wk_new = wk - t, wl_new = wl + t, a1 = a0 * c - b0 * s, b1 = a0 * s + b0 * c;
             // All of that in every lane and in one piece: left to itself the compiler moves the division by t
             // under "lane 0" and the rest under "lanes with a pair", one chain of dependent operations after
             // the other, where side by side each fills the other's waits.
             asm volatile("" : "+v"(wk_new), "+v"(wl_new), "+v"(a1), "+v"(b1));
-            wave_lds_phase();  // every lane has read its candidate and its pair
-            if (lane == 0) {
-                A[n * k + l] = 0;
-                W[k] = wk_new;
-                W[l] = wl_new;
-            }
-            if (act) {
+            wave_lds_phase();  // every lane has read its pair and the pivot
+            if (lane == 0) A[n * k + l] = 0;
+            if (act && writes) {
                 A[e0] = a1;
                 A[e1] = b1;
             }
-            wave_lds_phase();
-            // the maxima of row k, column k, row l, column l again: the sequential scans "first largest
-            // |a| of row idx right of the diagonal" / "... of column idx above it", each by one group of
-            // 16 lanes: lane i16 looks at element i16, the group's largest value reaches all its lanes, and
-            // the first lane that holds it is the scan's answer
+            if (i16 == k) Wi = wk_new;
+            if (i16 == l) Wi = wl_new;
+            // the element a kept index points at changed when the index is k or l: row i16 then holds A[i16][k]
+            // = a1 (i16 < k) or A[i16][l] = b1 (i16 < l), column i16 A[k][i16] = a1 (i16 > k) or A[l][i16] = b1
+            // (i16 > l): the pair's halves either way.  (Lanes k and l take the scans' results below.)
+            const double na = fabs(a1), nb = fabs(b1);
+            sabs = sind == k ? na : sind == l ? nb : sabs;
+            // the maxima of row k, column k, row l, column l again: the sequential scans "first largest |a| of
+            // row idx right of the diagonal" / "... of column idx above it", one per group: row k is a1 of lanes
+            // > k (0 at l), column k a1 of lanes < k, row l b1 of lanes > l, column l b1 of lanes < l (0 at k)
             {
-                const int idx = k + of_l * (l - k);
-                const bool has = in_n && side_i - side_s * idx > 0;
-                // (lanes without an element read some other entry of A or V and discard it)
-                const double av = fabs(A[scan_a + scan_b * idx]);
-                const double v = has ? av : -1.;
-                const double gm = row_all_max(v);
-                const unsigned long long eq = __ballot(v == gm);
+                const int idx = of_l ? l : k, zl = of_l ? k : l;
+                const bool has = colk ? i16 < idx : (i16 > idx && i16 < n);
+                const double sv = has ? (i16 == zl ? 0. : (of_l ? nb : na)) : -1.;
+                const double sg = row_all_max(sv);
+                const unsigned long long eq = __ballot(sv == sg);
                 const int first = __ffs((unsigned)(eq >> (lane & 48)) & 0xFFFFu) - 1;
-                if (i16 == 15 && gm >= 0.) ind[slot_off + idx] = first;
+                // groups 0 and 1 hold the results for k, groups 2 and 3 those for l, rows in the even groups
+                // and columns in the odd ones, as the lanes that keep them
+                int fk, fl;
+                double gk, gl;
+                halves_i32(first, fk, fl);
+                halves_f64(sg, gk, gl);
+                if (i16 == k) sabs = gk, sind = fk;
+                if (i16 == l) sabs = gl, sind = fl;
             }
             wave_lds_phase();
+            jac_rot++;
+#ifdef MAXROT
+            if (jac_rot >= MAXROT) break;
+#endif
         }
+    if (lane == 0) perm[15] = jac_rot;
+    if (lane < n) W[lane] = Wi;
     __syncthreads();
     // selection sort (descending) with row swaps: the permutation is found with compile-time indices
     // only (values and positions stay in registers; arrays indexed at run time would live in scratch
@@ -355,8 +346,7 @@ __device__ __forceinline__ void mat3mul(const double* a, const double* b, double
 
 struct JacobiLds {
     double A[81], V[81], W[9];
-    int indR[16], indC[16], perm[16];
-    double T[46 * WS_STRIDE];   // table of wave_reduce_rows (45 sums of runKernel; 44 sums + |r|^2 + max |r| of the LM step)
+    int perm[16]; int indR[1], indC[1];
 };
 
 // HomographyEstimatorCallback::runKernel for `count` point pairs (M -> m), one wave.
@@ -365,25 +355,23 @@ struct JacobiLds {
 __device__ int run_kernel_wave(const float* __restrict__ M, const float* __restrict__ m, int count, JacobiLds* L,
                                double* H) {
     const int lane = threadIdx.x & 63;
-    double a4[4] = {0, 0, 0, 0};
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (int i = lane; i < count; i += 64) {
-        a4[0] += m[2 * i];
-        a4[1] += m[2 * i + 1];
-        a4[2] += M[2 * i];
-        a4[3] += M[2 * i + 1];
+        a0 += m[2 * i];
+        a1 += m[2 * i + 1];
+        a2 += M[2 * i];
+        a3 += M[2 * i + 1];
     }
-    double r4 = wave_reduce_rows(a4, L->T);
-    const double cmx = readlane_f64(r4, 0) / count, cmy = readlane_f64(r4, 1) / count;
-    const double cMx = readlane_f64(r4, 2) / count, cMy = readlane_f64(r4, 3) / count;
-    a4[0] = a4[1] = a4[2] = a4[3] = 0;
+    const double cmx = wave_sum(a0) / count, cmy = wave_sum(a1) / count;
+    const double cMx = wave_sum(a2) / count, cMy = wave_sum(a3) / count;
+    a0 = a1 = a2 = a3 = 0;
     for (int i = lane; i < count; i += 64) {
-        a4[0] += fabs(m[2 * i] - cmx);
-        a4[1] += fabs(m[2 * i + 1] - cmy);
-        a4[2] += fabs(M[2 * i] - cMx);
-        a4[3] += fabs(M[2 * i + 1] - cMy);
+        a0 += fabs(m[2 * i] - cmx);
+        a1 += fabs(m[2 * i + 1] - cmy);
+        a2 += fabs(M[2 * i] - cMx);
+        a3 += fabs(M[2 * i + 1] - cMy);
     }
-    r4 = wave_reduce_rows(a4, L->T);
-    double smx = readlane_f64(r4, 0), smy = readlane_f64(r4, 1), sMx = readlane_f64(r4, 2), sMy = readlane_f64(r4, 3);
+    double smx = wave_sum(a0), smy = wave_sum(a1), sMx = wave_sum(a2), sMy = wave_sum(a3);
     if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON)
         return 0;
     smx = count / smx;
@@ -408,18 +396,22 @@ __device__ int run_kernel_wave(const float* __restrict__ M, const float* __restr
     }
     __syncthreads();
     {
-        // lane e < 45 holds entry e of the upper triangle, rows first: (j, k) with j <= k
-        const double v = wave_reduce_rows(acc, L->T);
-        const int e = lane;
-        const int j = (e >= 9) + (e >= 17) + (e >= 24) + (e >= 30) + (e >= 35) + (e >= 39) + (e >= 42) + (e >= 44);
-        const int k = j + e - (9 * j - j * (j - 1) / 2);
-        if (e < 45) {
-            L->A[j * 9 + k] = v;
-            L->A[k * 9 + j] = v;
-        }
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+#pragma unroll
+            for (int k = j; k < 9; k++) {
+                const double v = wave_sum(acc[e++]);
+                if (lane == 0) {
+                    L->A[j * 9 + k] = v;
+                    L->A[k * 9 + j] = v;
+                }
+            }
     }
     __syncthreads();
-    jacobi_wave(L->A, L->W, L->V, L->indR, L->indC, L->perm, 9);
+    TR(2);
+    jacobi_wave(L->A, L->W, L->V, L->perm, 9);
+    TR(3);
     double H0v[9], Htemp[9], H0[9];
     for (int i = 0; i < 9; i++) H0v[i] = L->V[72 + i];
     mat3mul(invHnorm, H0v, Htemp);
@@ -733,27 +725,26 @@ __device__ double lm_compute_wave(const float* __restrict__ M, const float* __re
     }
     if (with_J) {
         __syncthreads();
-        // 36 entries of the upper triangle of JtJ (the nine between parameters 0..2 and 3..5 were never touched:
-        // sums of +0), 8 of Jt r, |r|^2, max |r|: lane e holds entry e
-        double all[46];
+        int e = 0;
 #pragma unroll
-        for (int e = 0; e < 44; e++) all[e] = acc[e];
-        all[44] = ss;
-        all[45] = rmax;
-        const double v = wave_reduce_rows(all, S->J.T, 45);
-        const int e = lane;
-        const int a = (e >= 8) + (e >= 15) + (e >= 21) + (e >= 26) + (e >= 30) + (e >= 33) + (e >= 35);
-        const int b = a + e - (8 * a - a * (a - 1) / 2);
-        if (e < 36) {
-            S->A[a * 8 + b] = v;
-            S->A[b * 8 + a] = v;
-        } else if (e < 44) {
-            S->v[e - 36] = v;
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int b = a; b < 8; b++) {
+                const bool zero = a < 3 && b >= 3 && b < 6;  // never touched: a sum of +0 terms
+                const double v = zero ? 0. : wave_sum(acc[e]);
+                e++;
+                if (lane == 0) {
+                    S->A[a * 8 + b] = v;
+                    S->A[b * 8 + a] = v;
+                }
+            }
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const double v = wave_sum(acc[36 + a]);
+            if (lane == 0) S->v[a] = v;
         }
-        *rinf = readlane_f64(v, 45);
-        const double total = readlane_f64(v, 44);
+        *rinf = wave_max(rmax);
         __syncthreads();
-        return total;
     }
     return wave_sum(ss);
 }
@@ -764,7 +755,7 @@ __device__ void eig8_apply(RefineLds* S, const double* Asrc, bool solve) {
     __syncthreads();
     S->J.A[lane] = Asrc[lane];
     __syncthreads();
-    jacobi_wave(S->J.A, S->J.W, S->J.V, S->J.indR, S->J.indC, S->J.perm, 8);
+    jacobi_wave(S->J.A, S->J.W, S->J.V, S->J.perm, 8);
     // back-substitution through the eigenvectors, as cv::solve(DECOMP_EIG) does it: for every
     // eigenpair above the threshold, s = (v_i . b) / w_i and x += s v_i, the pairs taken in order.
     // Lane i < 8 forms s of pair i (its own sequential dot product); lane j < 8 then adds the
@@ -816,6 +807,10 @@ __global__ __launch_bounds__(64) void k_rs_refine(const FrameSlot* __restrict__ 
     int* __restrict__ found = SL.rs_found;
     __shared__ RefineLds S;
     const int lane = threadIdx.x;
+#ifdef RTVM_RS_TRACE
+    if (lane == 0) for (int i = 0; i < 16; i++) g_tr[i] = 0;
+    TR(0);
+#endif
     const int count = *count_p;
     double H[9];
     if (count < 4) {
@@ -865,6 +860,7 @@ __global__ __launch_bounds__(64) void k_rs_refine(const FrameSlot* __restrict__ 
         n += __popcll(bal);
     }
     __syncthreads();
+    TR(1);
     if (n > 0) {
         double H2[9];
         if (run_kernel_wave(csrc, cdst, n, &S.J, H2))
@@ -875,7 +871,9 @@ __global__ __launch_bounds__(64) void k_rs_refine(const FrameSlot* __restrict__ 
         if (lane < 8) S.x[lane] = H[lane];
         __syncthreads();
         double rinf = 0;
+        TR(4);
         double Sres = lm_compute_wave(csrc, cdst, n, S.x, true, &S, &rinf);
+        TR(5);
         if (lane < 8) S.D[lane] = S.A[lane * 8 + lane];
         const double Rlo = 0.25, Rhi = 0.75;
         double lambda = 1, lc = 0.75;
@@ -883,10 +881,20 @@ __global__ __launch_bounds__(64) void k_rs_refine(const FrameSlot* __restrict__ 
         for (;;) {
             __syncthreads();
             S.Ap[lane] = ((lane >> 3) == (lane & 7)) ? S.A[lane] + lambda * S.D[lane & 7] : S.A[lane];
+#ifdef RTVM_RS_TRACE
+            const long long te0 = tnow();
+#endif
             eig8_apply(&S, S.Ap, true);
+#ifdef RTVM_RS_TRACE
+            TRADD(11, tnow() - te0); TRADD(12, 1);
+            const long long tl0 = tnow();
+#endif
             if (lane < 8) S.xd[lane] = S.x[lane] - S.d[lane];
             __syncthreads();
             const double Sd = lm_compute_wave(csrc, cdst, n, S.xd, false, &S, nullptr);
+#ifdef RTVM_RS_TRACE
+            TRADD(13, tnow() - tl0);
+#endif
             double temp_d[8], d[8], v[8];
             for (int i = 0; i < 8; i++) d[i] = S.d[i], v[i] = S.v[i];
             for (int i = 0; i < 8; i++) {
@@ -904,6 +912,7 @@ __global__ __launch_bounds__(64) void k_rs_refine(const FrameSlot* __restrict__ 
                 double nu = (Sd - Sres) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
                 nu = fmin(fmax(nu, 2.), 10.);
                 if (lambda == 0) {
+                    TRADD(14, 1);
                     eig8_apply(&S, S.A, false);
                     double maxval = DBL_EPSILON;
                     for (int i = 0; i < 8; i++) maxval = fmax(maxval, fabs(S.diag[i]));
@@ -916,7 +925,13 @@ __global__ __launch_bounds__(64) void k_rs_refine(const FrameSlot* __restrict__ 
                 __syncthreads();
                 if (lane < 8) S.x[lane] = S.xd[lane];
                 __syncthreads();
+#ifdef RTVM_RS_TRACE
+                const long long tj0 = tnow();
+#endif
                 Sres = lm_compute_wave(csrc, cdst, n, S.x, true, &S, &rinf);
+#ifdef RTVM_RS_TRACE
+                TRADD(15, tnow() - tj0); TRADD(9, 1);
+#endif
             }
             iter++;
             double dinf = 0;
@@ -931,6 +946,18 @@ __global__ __launch_bounds__(64) void k_rs_refine(const FrameSlot* __restrict__ 
     }
     if (lane == 0) *found = 1;
     if (lane < 9) outH[lane] = H[lane];
+#ifdef RTVM_RS_TRACE
+    TR(6);
+    __syncthreads();
+    if (lane == 0) {
+        // cycles: compaction, DLT sums, DLT Jacobi, DLT tail, first J, whole; counts
+        double* o = outH;
+        o[0] = (double)(g_tr[1] - g_tr[0]); o[1] = (double)(g_tr[2] - g_tr[1]); o[2] = (double)(g_tr[3] - g_tr[2]);
+        o[3] = (double)(g_tr[4] - g_tr[3]); o[4] = (double)(g_tr[5] - g_tr[4]); o[5] = (double)(g_tr[6] - g_tr[0]);
+        o[6] = (double)g_tr[10] + 1e-3 * (double)g_tr[12] + 1e-6 * (double)g_tr[14] + 1e-9 * (double)g_tr[9];
+        o[7] = (double)g_tr[11]; o[8] = (double)g_tr[13] + 1e-9 * (double)g_tr[15];
+    }
+#endif
 }
 
 }  // namespace
