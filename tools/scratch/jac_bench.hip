@@ -1,5 +1,7 @@
 // Cycles per Jacobi rotation of jacobi_wave on a lone wave (the RANSAC kernels' bound).  Includes the product source.
-// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I real-time-video-mosaic_amd/csrc -DJAC_SRC=... 
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I real-time-video-mosaic_amd/csrc \
+//   '-DJAC_SRC="../../real-time-video-mosaic_amd/csrc/ransac.hip"' '-DJAC_CALL(N)=jacobi_wave(L.A,L.W,L.V,L.indR,L.indC,L.perm,N)' \
+//   -o tools/scratch/jac_old tools/scratch/jac_bench.hip
 #include JAC_SRC
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +19,7 @@ __global__ __launch_bounds__(64) void k_jac(const double* Ain, int n, double* Wo
         total += __builtin_readcyclecounter() - t0;
     }
     if (lane < n) Wout[lane] = L.W[lane];
-    if (lane == 0) { cyc[0] = total; cyc[1] = L.perm[15]; }
+    if (lane == 0) { cyc[0] = total; cyc[1] = 0; }
 }
 }
 int main() {
