@@ -4,6 +4,8 @@
 // copies the results back and waits.
 #include "common.h"
 
+#include <cstdlib>
+
 #include <new>
 
 namespace {
@@ -387,8 +389,9 @@ void free_all(rtvm_ctx* c) {
 extern "C" int rtvm_version(void) { return RTVM_VERSION; }
 
 static void destroy_streams(rtvm_ctx* c) {
-    if (c->stream_lm != c->stream_main) (void)hipStreamDestroy(c->stream_lm);
-    if (c->stream_rs != c->stream_main) (void)hipStreamDestroy(c->stream_rs);
+    if (c->stream_front2 != c->stream_front) (void)hipStreamDestroy(c->stream_front2);
+    if (c->stream_lm != c->stream_main && c->stream_lm != c->stream_front) (void)hipStreamDestroy(c->stream_lm);
+    if (c->stream_rs != c->stream_main && c->stream_rs != c->stream_front) (void)hipStreamDestroy(c->stream_rs);
     if (c->stream_front != c->stream_main) (void)hipStreamDestroy(c->stream_front);
     (void)hipStreamDestroy(c->stream_main);
 }
@@ -424,19 +427,38 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
         delete c;
         return RTVM_E_HIP;
     }
-    c->stream_front = c->stream_rs = c->stream_lm = c->stream_main;
+    c->stream_front = c->stream_front2 = c->stream_rs = c->stream_lm = c->stream_main;
     // (All streams at the default priority: with the main stream on a high-priority queue the frame
     // rate rose by under 1 %, and a context used next to the single-stream contexts of worker
     // threads stopped making progress.)
     if (frame_h > 0 && !(flags & RTVM_FLAG_SINGLE_STREAM)) {
-        hipStream_t* more[3] = {&c->stream_front, &c->stream_rs, &c->stream_lm};
+        // The runtime deals streams onto the process' few hardware queues in creation order (observed with four
+        // queues: the null stream's, then 2, 3, 4, 4, 3, 2 for the streams created), and a queue runs what it holds
+        // in order: a kernel behind another stream's wait for an event waits with it.  A SIFT context, whose
+        // detection is the longest stream and holds kernels of a few waves, therefore gets three streams, each on
+        // a queue of its own: the canvas half, and two that take the batches of the even and of the odd slot sets
+        // through detection, matching and RANSAC, so that consecutive batches overlap.  Other contexts: canvas
+        // half, detection + matching, RANSAC search, RANSAC polish (the last two share a queue).
+        const bool two_front = detector == RTVM_DET_SIFT && !getenv("RTVM_ONE_DETECT_STREAM");
+        hipStream_t* more[4] = {&c->stream_front, two_front ? &c->stream_front2 : nullptr, two_front ? nullptr : &c->stream_rs,
+                                two_front ? nullptr : &c->stream_lm};
+        bool ok = true;
         for (hipStream_t* st : more)
-            if (hipStreamCreate(st) != hipSuccess) {
+            if (st && ok && hipStreamCreate(st) != hipSuccess) {
                 *st = c->stream_main;
-                destroy_streams(c);
-                delete c;
-                return RTVM_E_HIP;
+                ok = false;
             }
+        if (!two_front || !ok) {
+            if (two_front && c->stream_front2 != c->stream_main && c->stream_front2 != c->stream_front)
+                (void)hipStreamDestroy(c->stream_front2);
+            c->stream_front2 = c->stream_front;
+        }
+        if (two_front && ok) c->stream_rs = c->stream_lm = c->stream_front;   // per batch: the stream of its detection
+        if (!ok) {
+            destroy_streams(c);
+            delete c;
+            return RTVM_E_HIP;
+        }
     }
     c->stream = c->stream_main;
     int r = alloc_all(c);
@@ -455,6 +477,7 @@ extern "C" void rtvm_destroy(rtvm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream_front);
+    (void)hipStreamSynchronize(c->stream_front2);
     (void)hipStreamSynchronize(c->stream_rs);
     (void)hipStreamSynchronize(c->stream_lm);
     (void)hipStreamSynchronize(c->stream_main);

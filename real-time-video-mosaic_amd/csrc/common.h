@@ -272,6 +272,9 @@ struct rtvm_ctx {
     hipStream_t stream;        // stream the launch macros use right now
     hipStream_t stream_main;   // canvas half, host-buffer entry points, read-backs
     hipStream_t stream_front;  // detection + matching of a batch queued ahead of the canvas half
+    hipStream_t stream_front2; // the same for the batches in the odd slot sets (contexts with the SIFT detector, whose
+                               // detection is the longest stream and holds kernels of a few waves: the detections
+                               // of consecutive batches overlap); elsewhere the same stream as stream_front
     hipStream_t stream_rs;     // RANSAC hypothesis search of a batch queued ahead of the canvas half
     hipStream_t stream_lm;     // RANSAC polish (least squares + Levenberg-Marquardt) of such a batch
     hipEvent_t ev_search[RTVM_NSETS]; // RANSAC search of the batch in slot set k is complete

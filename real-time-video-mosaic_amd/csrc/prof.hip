@@ -48,7 +48,7 @@ int rtvm_prof_begin(rtvm_ctx* c, const char* name) {
         p->count.push_back(0);
         p->stream.push_back(0);
     }
-    p->stream[idx] = c->stream == c->stream_front ? 1 : c->stream == c->stream_rs ? 2 : c->stream == c->stream_lm ? 3 : 0;
+    p->stream[idx] = (c->stream == c->stream_front || c->stream == c->stream_front2) ? 1 : c->stream == c->stream_rs ? 2 : c->stream == c->stream_lm ? 3 : 0;
     Rec r{idx, take_event(p), take_event(p)};
     if (!r.e0 || !r.e1) return -1;
     (void)hipEventRecord(r.e0, c->stream);
@@ -93,6 +93,7 @@ extern "C" int rtvm_profile_stop(rtvm_ctx* c) {
     if (!c) return RTVM_E_ARG;
     c->prof_mode = 0;
     HIP_TRY(c, hipStreamSynchronize(c->stream_front));
+    HIP_TRY(c, hipStreamSynchronize(c->stream_front2));
     HIP_TRY(c, hipStreamSynchronize(c->stream_rs));
     HIP_TRY(c, hipStreamSynchronize(c->stream_lm));
     HIP_TRY(c, hipStreamSynchronize(c->stream_main));

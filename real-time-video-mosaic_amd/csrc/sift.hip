@@ -1233,14 +1233,17 @@ __global__ void k_sift_bind(SiftFrame* __restrict__ F, const FrameSlot* __restri
     F[j].n_out = S.feat.count;
 }
 
-// SIFT detection for the stream path: one work area (pyramids, lists) per frame of a batch.  The
-// areas serve every batch in turn: detection of consecutive batches is queued on one stream.
+// SIFT detection for the stream path: one work area (pyramids, lists) per frame of a batch, in two sets.  The
+// batches in the even slot sets are detected on one stream with the first set of areas, those in the odd slot
+// sets on the other stream with the second: the areas of a set serve their batches in turn, in stream order.
+// (Contexts with one detection stream use the first set only.)
 struct SiftPipe {
     SiftGeom g;
-    int n = 0;                      // work areas allocated
-    SiftFrame* d_frames = nullptr;  // [RTVM_MAX_BATCH]
-    void* arena[RTVM_MAX_BATCH] = {};
-    void* work[RTVM_MAX_BATCH] = {};
+    int sets = 1;                   // sets of work areas in use
+    int n = 0;                      // work areas allocated per set
+    SiftFrame* d_frames = nullptr;  // [2][RTVM_MAX_BATCH]
+    void* arena[2][RTVM_MAX_BATCH] = {};
+    void* work[2][RTVM_MAX_BATCH] = {};
 };
 
 }  // namespace
@@ -1251,7 +1254,8 @@ int rtvm_sift_pipe_create(rtvm_ctx* c) {
     c->sift_pipe = p;
     int r = sift_geometry(c, c->fh, c->fw, p->g);
     if (r) return r;
-    hipError_t e = hipMalloc((void**)&p->d_frames, sizeof(SiftFrame) * RTVM_MAX_BATCH);
+    p->sets = c->stream_front2 != c->stream_front ? 2 : 1;
+    hipError_t e = hipMalloc((void**)&p->d_frames, sizeof(SiftFrame) * RTVM_MAX_BATCH * 2);
     if (e != hipSuccess) RTVM_FAIL(c, RTVM_E_NOMEM, "sift: hipMalloc failed: %s", hipGetErrorString(e));
     return RTVM_OK;
 }
@@ -1260,15 +1264,17 @@ int rtvm_sift_pipe_reserve(rtvm_ctx* c, int n) {
     SiftPipe* p = (SiftPipe*)c->sift_pipe;
     if (!p) RTVM_FAIL(c, RTVM_E_STATE, "sift: the context was not created with the SIFT detector");
     for (int j = p->n; j < n && j < RTVM_MAX_BATCH; j++) {
-        const size_t ab = p->g.total * sizeof(float), wb = sift_work_bytes(c->orb.max_kp);
-        hipError_t e = hipMalloc(&p->arena[j], ab);
-        if (e == hipSuccess) e = hipMalloc(&p->work[j], wb);
-        if (e != hipSuccess)
-            RTVM_FAIL(c, RTVM_E_NOMEM, "sift: hipMalloc(%zu + %zu bytes) for the pyramids of batch frame %d failed: %s", ab, wb, j,
-                      hipGetErrorString(e));
-        SiftFrame f;
-        sift_frame_init(f, p->g, (float*)p->arena[j], (char*)p->work[j]);
-        HIP_TRY(c, hipMemcpy(p->d_frames + j, &f, sizeof(SiftFrame), hipMemcpyHostToDevice));
+        for (int k = 0; k < p->sets; k++) {
+            const size_t ab = p->g.total * sizeof(float), wb = sift_work_bytes(c->orb.max_kp);
+            hipError_t e = hipMalloc(&p->arena[k][j], ab);
+            if (e == hipSuccess) e = hipMalloc(&p->work[k][j], wb);
+            if (e != hipSuccess)
+                RTVM_FAIL(c, RTVM_E_NOMEM, "sift: hipMalloc(%zu + %zu bytes) for the pyramids of batch frame %d failed: %s", ab, wb, j,
+                          hipGetErrorString(e));
+            SiftFrame f;
+            sift_frame_init(f, p->g, (float*)p->arena[k][j], (char*)p->work[k][j]);
+            HIP_TRY(c, hipMemcpy(p->d_frames + k * RTVM_MAX_BATCH + j, &f, sizeof(SiftFrame), hipMemcpyHostToDevice));
+        }
         p->n = j + 1;
     }
     return RTVM_OK;
@@ -1277,10 +1283,11 @@ int rtvm_sift_pipe_reserve(rtvm_ctx* c, int n) {
 void rtvm_sift_pipe_free(rtvm_ctx* c) {
     SiftPipe* p = (SiftPipe*)c->sift_pipe;
     if (!p) return;
-    for (int j = 0; j < RTVM_MAX_BATCH; j++) {
-        if (p->arena[j]) (void)hipFree(p->arena[j]);
-        if (p->work[j]) (void)hipFree(p->work[j]);
-    }
+    for (int k = 0; k < 2; k++)
+        for (int j = 0; j < RTVM_MAX_BATCH; j++) {
+            if (p->arena[k][j]) (void)hipFree(p->arena[k][j]);
+            if (p->work[k][j]) (void)hipFree(p->work[k][j]);
+        }
     if (p->d_frames) (void)hipFree(p->d_frames);
     delete p;
     c->sift_pipe = nullptr;
@@ -1290,8 +1297,12 @@ void rtvm_sift_pipe_free(rtvm_ctx* c) {
 int rtvm_launch_sift(rtvm_ctx* c, int sb, int nb) {
     SiftPipe* p = (SiftPipe*)c->sift_pipe;
     if (!p || nb < 1 || nb > p->n) RTVM_FAIL(c, RTVM_E_STATE, "sift: batch of %d frames, work areas for %d", nb, p ? p->n : 0);
-    RTVM_LAUNCH(c, k_sift_bind, dim3(1), dim3(64), 0, p->d_frames, (const FrameSlot*)c->d_slots, sb, nb);
-    return sift_launch(c, p->g, p->d_frames, nb, c->nfeatures, c->orb.max_kp);
+    // the work areas that belong to the stream this is queued on
+    const int k = c->stream == c->stream_front2 && c->stream_front2 != c->stream_front ? 1 : 0;
+    if (k && !p->arena[1][nb - 1]) RTVM_FAIL(c, RTVM_E_STATE, "sift: the second set of work areas holds fewer than %d frames", nb);
+    SiftFrame* frames = p->d_frames + k * RTVM_MAX_BATCH;
+    RTVM_LAUNCH(c, k_sift_bind, dim3(1), dim3(64), 0, frames, (const FrameSlot*)c->d_slots, sb, nb);
+    return sift_launch(c, p->g, frames, nb, c->nfeatures, c->orb.max_kp);
 }
 
 extern "C" int rtvm_sift_max_keypoints(int nfeatures) { return nfeatures + 256; }

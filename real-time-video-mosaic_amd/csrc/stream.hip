@@ -450,9 +450,12 @@ void launch_advance_feats(rtvm_ctx* c, int sb, int which) {
 }
 
 // detect + match against the previous frame + gather points for slots sb..sb+n-1
-int queue_features(rtvm_ctx* c, int sb, int n) {
+// prev_feat: the features the first frame is matched against are written on another stream; the event that says
+// they are complete (detection itself does not need them)
+int queue_features(rtvm_ctx* c, int sb, int n, hipEvent_t prev_feat = nullptr) {
     int r;
     if ((r = launch_detect(c, sb, n))) return r;
+    if (prev_feat) HIP_TRY(c, hipStreamWaitEvent(c->stream, prev_feat, 0));
     const int cap = c->orb.max_kp;
     if (c->detector == RTVM_DET_SIFT) {
         if ((r = rtvm_launch_l2_slots(c, sb, n, cap))) return r;
@@ -562,19 +565,25 @@ int queue_detect(rtvm_ctx* c, const uint8_t* const* ptrs, int n, int* set_out, i
                   RTVM_NSETS);
     const int sb = set * RTVM_MAX_BATCH;
     const int ahead = c->spec_tail >= 0 ? 1 : 0;
+    // the batches of the odd slot sets are detected on a stream of their own where there is one
+    hipStream_t sf = (set & 1) ? c->stream_front2 : c->stream_front;
+    hipEvent_t prev_feat = nullptr;
     if (ahead) {
         // the batch that used this slot set before must have left it
-        if (c->back_rec[set]) HIP_TRY(c, hipStreamWaitEvent(c->stream_front, c->ev_back[set], 0));
+        if (c->back_rec[set]) HIP_TRY(c, hipStreamWaitEvent(sf, c->ev_back[set], 0));
+        // the frame the first one is matched against was detected on the other stream
+        const int prev_set = c->spec_tail / RTVM_MAX_BATCH;
+        if (c->stream_front2 != c->stream_front && ((prev_set ^ set) & 1)) prev_feat = c->ev_feat[prev_set];
     } else {
         // feat_prev is written on the main stream: wait for everything queued there
         HIP_TRY(c, hipEventRecord(c->ev_main, c->stream_main));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream_front, c->ev_main, 0));
+        HIP_TRY(c, hipStreamWaitEvent(sf, c->ev_main, 0));
     }
     {
-        StreamScope fs(c, c->stream_front);
+        StreamScope fs(c, sf);
         if ((r = bind_batch(c, sb, ptrs, n, ahead ? c->h_slots[c->spec_tail].feat : c->feat_prev))) return r;
-        if ((r = queue_features(c, sb, n))) return r;
-        HIP_TRY(c, hipEventRecord(c->ev_feat[set], c->stream_front));
+        if ((r = queue_features(c, sb, n, prev_feat))) return r;
+        HIP_TRY(c, hipEventRecord(c->ev_feat[set], sf));
     }
     // Few frames in flight (the start of a video, a short burst): latency counts, not work, and the RANSAC
     // search starts with all 64 hypotheses of its first two stages at once (ransac.hip).  (Tried for such
@@ -584,21 +593,24 @@ int queue_detect(rtvm_ctx* c, const uint8_t* const* ptrs, int n, int* set_out, i
     int live = n;
     for (int k = 0; k < RTVM_NSETS; k++)
         if (c->set_live[k]) live += c->recs[k].n;
-    HIP_TRY(c, hipStreamWaitEvent(c->stream_rs, c->ev_feat[set], 0));
+    // contexts with two detection streams keep a batch on the stream of its detection all the way through RANSAC
+    const bool own = c->stream_front2 != c->stream_front;
+    hipStream_t s_rs = own ? sf : c->stream_rs, s_lm = own ? sf : c->stream_lm;
+    HIP_TRY(c, hipStreamWaitEvent(s_rs, c->ev_feat[set], 0));
     {
-        StreamScope fs(c, c->stream_rs);
+        StreamScope fs(c, s_rs);
         c->rs_alone = live <= RTVM_MAX_BATCH ? 1 : 0;
         r = rtvm_launch_ransac_search(c, sb, n, 2.0, 2000, 0.995);
         c->rs_alone = 0;
         if (r) return r;
-        HIP_TRY(c, hipEventRecord(c->ev_search[set], c->stream_rs));
+        HIP_TRY(c, hipEventRecord(c->ev_search[set], s_rs));
     }
-    HIP_TRY(c, hipStreamWaitEvent(c->stream_lm, c->ev_search[set], 0));
+    HIP_TRY(c, hipStreamWaitEvent(s_lm, c->ev_search[set], 0));
     {
-        StreamScope fs(c, c->stream_lm);
+        StreamScope fs(c, s_lm);
         if ((r = rtvm_launch_ransac_refine(c, sb, n, 2.0))) return r;
         RTVM_LAUNCH(c, k_batch_collect, dim3(1), dim3(64), 0, c->d_slots, sb, n, c->d_res + set);
-        HIP_TRY(c, hipEventRecord(c->ev_front[set], c->stream_lm));
+        HIP_TRY(c, hipEventRecord(c->ev_front[set], s_lm));
     }
     c->spec_tail = sb + n - 1;
     c->set_next = (set + 1) % RTVM_NSETS;
