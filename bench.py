@@ -47,7 +47,7 @@ SIFT_CONFIGS = ("720p_sift700", "1080p_sift2000")
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E
 HBM_COPY_GBS = 6290.0        # measured float4 copy rate
 MFMA_BF16_TFLOPS = 2500.0    # dense bf16 matrix-core peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
 
 
 def pyramid_pixels(fh, fw):

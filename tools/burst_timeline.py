@@ -18,6 +18,17 @@ i = end - 1
 while i > 0 and rows[i][0] - max(r[1] for r in rows[max(0, i - 40):i]) < gap:
     i -= 1
 burst = rows[i:end]
+# the timed pass of the driver's command inside it: from the bind of the last batch that was detected (k_fast)
+# to the end of its canvas half
+fast = [j for j, r in enumerate(rows) if r[3] == "k_fast"]
+if fast:
+    a = fast[-1]
+    while a > 0 and rows[a][3] != "k_batch_bind":
+        a -= 1
+    b = a
+    while b < len(rows) - 1 and not rows[b][3].startswith("k_batch_finish"):
+        b += 1
+    burst = rows[a:b + 1]
 t0 = burst[0][0]
 print("burst of %d kernels, %.1f us" % (len(burst), (max(r[1] for r in burst) - t0) / 1e3))
 for s, e, q, n in burst:
