@@ -4,7 +4,7 @@
 # Results: gpurun_out/sq/sq.json (per kernel: counters summed over dispatches) and gpurun_out/sq/trace/.
 set -u
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/sq
+OUT=$ROOT/gpurun_out/${SQ_OUT:-sq}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
