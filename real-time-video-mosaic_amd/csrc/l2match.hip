@@ -5,10 +5,11 @@
 // SIFT descriptors are float32 holding the integers 0..255.  For such data every
 // partial sum of squares is an integer below 2^24, so sum((q-t)^2) =
 // |q|^2 + |t|^2 - 2 q.t exactly in float32 in any order, and bf16 holds the values
-// exactly: the dot products run on the matrix cores (v_mfma_f32_32x32x16_bf16,
-// k_l2_knn2_mfma).  Anything else (non-integer values, dim not a multiple of 16)
-// takes k_l2_knn2_direct, which evaluates sum((q-t)^2) in index order with separate
-// multiply and add, exactly as the sequential float32 loop does.
+// exactly: the dot products run on the matrix cores (v_mfma_f32_32x32x16_bf16: k_l2_prep,
+// k_l2_tile, k_l2_merge; rows that hold other values or whose second distance reaches 2^22
+// are recomputed by k_l2_far).  Descriptors whose length is not a multiple of 16 take
+// k_l2_knn2_direct.  Both evaluate sum((q-t)^2) in index order with separate multiply and
+// add, exactly as the sequential float32 loop does.
 #include "common.h"
 
 namespace {
