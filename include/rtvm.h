@@ -354,7 +354,9 @@ int rtvm_process_video_source(rtvm_ctx* ctx, rtvm_frame_source source, void* use
  * behind it are detected again, matched against the last stitched frame), negative on failure (the call then
  * returns RTVM_E_CALLBACK).  The frames to stitch are warped and blended in pieces of up to `piece` frames
  * (0 = half a batch), three in flight; pieces that come back with frames pending are committed again.
- * rtvm_pipe_flush returns when every frame taken so far has been dealt with.  One pipe per context; opening it
+ * rtvm_pipe_flush returns when every frame taken so far has been dealt with.  After a call on the pipe has failed
+ * (the caller's function included) the frames in flight are in an undefined state: the pipe accepts nothing more and
+ * is to be closed.  One pipe per context; opening it
  * reserves the batch slots and the ingest ring (rtvm_reserve_batch, rtvm_ingest_reserve). */
 typedef int (*rtvm_glue_fn)(void* user, long frame, int n_matches, int found, const double H_rel[9], double H_abs[9]);
 typedef struct {

@@ -128,6 +128,14 @@ struct VideoRun {
         const int cb = std::max(1, std::min(batch, canvas_batch > 0 ? canvas_batch : (batch + 1) / 2));
         std::vector<std::unique_ptr<DetRec>> det;   // detected batches, oldest first
         std::deque<Piece> inb;                      // canvas halves in flight, oldest first
+        // whatever way this function is left (a failing frame source, a HIP error), no slot set stays taken
+        struct ReleaseAll {
+            rtvm_ctx* c;
+            std::vector<std::unique_ptr<DetRec>>& det;
+            ~ReleaseAll() {
+                for (auto& r : det) (void)rtvm_batch_release(c, r->ticket);
+            }
+        } release_all{c, det};
         int nxt = 0;                                // next frame to detect
         const uint8_t* ptrs[RTVM_MAX_BATCH];
         int st_buf[RTVM_MAX_BATCH];
@@ -271,6 +279,7 @@ struct Pipe {
     int m;                    // frames of the next piece
     bool need_rebase = false, flushing = false;
     bool in_glue = false;     // inside the caller's function: put and flush are refused there
+    bool failed = false;      // a call failed half way (the caller's function, a HIP error): only rtvm_pipe_close is left
     std::unique_ptr<PipeBatch> held;   // the batch of the newest frame, kept for kp_cur / matches
     long last_ticket = 0;     // batch and index of the last frame the rules were applied to
     int last_index = -1;
@@ -525,13 +534,19 @@ extern "C" int rtvm_pipe_put(rtvm_ctx* c, const uint8_t* bgr_host) {
     if (!p) RTVM_FAIL(c, RTVM_E_STATE, "pipe_put: no pipe (rtvm_pipe_open)");
     if (!bgr_host) RTVM_FAIL(c, RTVM_E_ARG, "pipe_put: null frame");
     if (p->in_glue) RTVM_FAIL(c, RTVM_E_STATE, "pipe_put: called from inside the rules function");
+    if (p->failed) RTVM_FAIL(c, RTVM_E_STATE, "pipe_put: an earlier call on this pipe failed; close it (rtvm_pipe_close)");
     const long idx = p->n_in;
-    while (idx - p->retired >= p->R) TRYV(p->pump(true));   // the slot still holds a frame that may be needed again
-    TRYV(rtvm_ingest_write(c, (int)(idx % p->R), bgr_host));   // complete on return
-    p->pend.push_back(idx);
-    p->n_in += 1;
-    p->st.frames += 1;
-    return p->pump(false);
+    int rc = RTVM_OK;
+    while (rc == RTVM_OK && idx - p->retired >= p->R) rc = p->pump(true);   // the slot still holds a frame that may be needed again
+    if (rc == RTVM_OK) rc = rtvm_ingest_write(c, (int)(idx % p->R), bgr_host);   // complete on return
+    if (rc == RTVM_OK) {
+        p->pend.push_back(idx);
+        p->n_in += 1;
+        p->st.frames += 1;
+        rc = p->pump(false);
+    }
+    if (rc != RTVM_OK) p->failed = true;
+    return rc;
 }
 
 extern "C" int rtvm_pipe_flush(rtvm_ctx* c) {
@@ -539,10 +554,12 @@ extern "C" int rtvm_pipe_flush(rtvm_ctx* c) {
     Pipe* p = pipe_of(c);
     if (!p) return RTVM_OK;
     if (p->in_glue) RTVM_FAIL(c, RTVM_E_STATE, "pipe_flush: called from inside the rules function");
+    if (p->failed) RTVM_FAIL(c, RTVM_E_STATE, "pipe_flush: an earlier call on this pipe failed; close it (rtvm_pipe_close)");
     p->flushing = true;
     int rc = RTVM_OK;
     while (rc == RTVM_OK && p->busy()) rc = p->pump(true);
     p->flushing = false;
+    if (rc != RTVM_OK) p->failed = true;
     return rc;
 }
 

@@ -204,6 +204,9 @@ def test_an_exception_in_the_callers_rules_surfaces_from_process_frame_or_flush(
             vm.process_frame(frames[t], t)
         vm.flush()
     assert len(calls) == 3
+    with pytest.raises(rtvm._ffi.RtvmError) as e:       # the frames in flight are in an undefined state: nothing more is taken
+        vm.process_frame(frames[1], 8)
+    assert e.value.code == rtvm._ffi.E_STATE and "close" in str(e.value)
     vm.close()
 
 
@@ -249,6 +252,9 @@ def test_process_video_through_a_frame_source_with_events_and_a_failing_source()
     b.stream_begin(dev[0].data_ptr(), FH, int(1.2 * FW / 2 - FW / 2))
     with pytest.raises(KeyError, match="frame 8 is gone"):
         b.process_video(Source(fail_at=8), batch=8)
+    # no slot set stays taken after the failure: the context goes on with the next video
+    b.stream_begin(dev[0].data_ptr(), FH, int(1.2 * FW / 2 - FW / 2))
+    assert b.process_video(ptrs, batch=8).tolist() == [0] * 20 and np.array_equal(b.canvas_read(), want)
     b.close()
 
 
