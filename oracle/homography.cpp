@@ -435,6 +435,14 @@ void lm_refine(const float* M, const float* m, int count, double* H) {
 
 }  // namespace
 
+extern "C" void rtvm_oracle_chain3x3(const double A[9], const double B[9], double C[9]) {
+    double out[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            out[3 * r + c] = __builtin_fma(A[3 * r + 2], B[6 + c], __builtin_fma(A[3 * r + 1], B[3 + c], A[3 * r] * B[c]));
+    for (int i = 0; i < 9; i++) C[i] = out[i];
+}
+
 extern "C" int rtvm_oracle_find_homography_ransac(const float* src_xy, const float* dst_xy, int count, double thresh,
                                                   int max_iters, double confidence, double H[9], uint8_t* inlier_mask,
                                                   int* found) {

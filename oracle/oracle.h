@@ -68,6 +68,12 @@ int rtvm_oracle_find_homography_ransac(const float* src_xy, const float* dst_xy,
                                        double thresh, int max_iters, double confidence,
                                        double H[9], uint8_t* inlier_mask, int* found);
 
+/* main.py:745, np.matmul(H_old, H_smoothed) for 3x3 float64: numpy hands the product to its BLAS, and the dgemm
+ * kernels of a CPU with fused multiply-add (OpenBLAS from Haswell / Zen on, which the numpy wheels carry) sum over
+ * k = 0, 1, 2 into a zeroed accumulator with one fused multiply-add per term:
+ * C[r][c] = fma(A[r][2], B[2][c], fma(A[r][1], B[1][c], A[r][0] * B[0][c])). */
+void rtvm_oracle_chain3x3(const double A[9], const double B[9], double C[9]);
+
 /* main.py:871; fixed != 0 selects the 1/32-pixel fixed-point arithmetic */
 int rtvm_oracle_warp_perspective(const uint8_t* bgr, int fh, int fw, const double H[9], int ch,
                                  int cw, int fixed, uint8_t* out);

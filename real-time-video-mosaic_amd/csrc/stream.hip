@@ -182,9 +182,11 @@ __global__ __launch_bounds__(64) void k_batch_glue(const FrameSlot* __restrict__
                     s_Hs[e] = Hs_e;
                 }
                 wave_lds_phase();
-                // self.H = np.matmul(self.H_old, H_relative_smoothed)
+                // self.H = np.matmul(self.H_old, H_relative_smoothed): numpy hands a 3x3 float64 product to its
+                // BLAS, whose dgemm kernels on a CPU with fused multiply-add sum k = 0, 1, 2 into a zeroed
+                // accumulator, one fused multiply-add per term
                 const int c2 = e % 3;
-                const double H_e = (Ho0 * s_Hs[c2] + Ho1 * s_Hs[3 + c2]) + Ho2 * s_Hs[6 + c2];
+                const double H_e = __builtin_fma(Ho2, s_Hs[6 + c2], __builtin_fma(Ho1, s_Hs[3 + c2], Ho0 * s_Hs[c2]));
                 if (lane < 9) {
                     st->H_abs[e] = H_e;
                     st->H_old[e] = H_e;

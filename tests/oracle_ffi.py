@@ -134,6 +134,17 @@ def find_homography(src, dst, thresh=2.0, max_iters=2000, confidence=0.995):
     return H.reshape(3, 3), mask[:m]
 
 
+def chain3x3(A, B):
+    """np.matmul of two 3x3 float64 matrices as a BLAS with fused multiply-add computes it."""
+    A = np.ascontiguousarray(A, np.float64)
+    B = np.ascontiguousarray(B, np.float64)
+    out = np.zeros((3, 3), np.float64)
+    f = lib().rtvm_oracle_chain3x3
+    f.restype = None
+    f(_p(A), _p(B), _p(out))
+    return out
+
+
 _pattern_set = False
 
 

@@ -4,7 +4,8 @@ oracle library.  Tests only.
 glue="numpy": validate / smooth / chain exactly as the reference writes them
 (np.linalg.det, np.linspace, np.matmul).  glue="explicit": the same arithmetic spelled
 out operation by operation (2x2 LU determinant, sequential weighted sum, 3x3 product as
-(a0*b0 + a1*b1) + a2*b2), which is what a device kernel can reproduce bit for bit.
+fma(a2, b2, fma(a1, b1, a0*b0)): the order of a BLAS dgemm kernel with fused multiply-add,
+which is what np.matmul runs on such a CPU), which is what a device kernel reproduces bit for bit.
 """
 import numpy as np
 
@@ -81,11 +82,7 @@ class OracleMosaic:
     def chain(self, A, B):
         if self.glue == "numpy":
             return np.matmul(A, B)
-        C = np.zeros((3, 3))
-        for r in range(3):
-            for c in range(3):
-                C[r, c] = (A[r, 0] * B[0, c] + A[r, 1] * B[1, c]) + A[r, 2] * B[2, c]
-        return C
+        return orc.chain3x3(A, B)
 
     def detect(self, frame):
         return orc.sift(frame, self.nfeatures) if self.detector == "sift" else orc.orb(frame, self.nfeatures)

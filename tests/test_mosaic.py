@@ -20,7 +20,8 @@ def video(n=8, seed=0):
 
 # ------------------------------------------------------------------ CPU
 def test_glue_variants_agree():
-    """np.linalg.det / np.matmul and the spelled-out forms agree to rounding."""
+    """np.linalg.det / np.matmul and the spelled-out forms agree: the decisions always, the product to the bit on
+    a host whose BLAS sums a 3x3 product with fused multiply-adds (any x86-64 with FMA3 under numpy's OpenBLAS)."""
     rng = np.random.default_rng(0)
     f0 = np.zeros((80, 80, 3), np.uint8)
     a = OracleMosaic.__new__(OracleMosaic)
@@ -32,6 +33,7 @@ def test_glue_variants_agree():
         H[:2, 2] = rng.normal(0, 30, 2)
         assert a.validate(H) == b.validate(H)
         assert np.allclose(a.chain(H, H.T), b.chain(H, H.T), rtol=1e-15, atol=1e-15)
+        assert np.array_equal(a.chain(H, H.T), b.chain(H, H.T)), "np.matmul on this host does not fuse k = 0, 1, 2"
 
 
 def test_oracle_mosaic_tracks_ground_truth():
