@@ -36,6 +36,34 @@ def test_glue_variants_agree():
         assert np.array_equal(a.chain(H, H.T), b.chain(H, H.T)), "np.matmul on this host does not fuse k = 0, 1, 2"
 
 
+def test_glue_variants_agree_over_a_long_chain():
+    """Three thousand frames' worth of validate / smooth / chain on random relative homographies, the reference's
+    numpy statements against the spelled-out forms the device runs: every decision and every bit of every
+    absolute homography."""
+    rng = np.random.default_rng(5)
+    a = OracleMosaic.__new__(OracleMosaic)
+    b = OracleMosaic.__new__(OracleMosaic)
+    for o, g in ((a, "numpy"), (b, "explicit")):
+        o.glue, o.history, o.H_old = g, [], np.array([[1.0, 0.0, 32.0], [0.0, 1.0, 240.0], [0.0, 0.0, 1.0]])
+    rejected = 0
+    for t in range(3000):
+        th = rng.normal(0, 0.004)
+        s = 1.0 + rng.normal(0, 0.002)
+        H = np.array([[s * np.cos(th), -s * np.sin(th), rng.normal(0, 3.0)],
+                      [s * np.sin(th), s * np.cos(th), rng.normal(0, 3.0) - 0.002 * np.sin(t / 50.0)],
+                      [rng.normal(0, 2e-6), rng.normal(0, 2e-6), 1.0]])
+        if t % 97 == 0:
+            H[0, 2] = 80.0       # a shaky frame
+        ok = a.validate(H)
+        assert ok == b.validate(H)
+        rejected += not ok
+        for o in (a, b):
+            o.H = o.chain(o.H_old, o.smooth(H if ok else np.eye(3)))
+            o.H_old = o.H
+        assert np.array_equal(a.H, b.H), t
+    assert rejected >= 30
+
+
 def test_oracle_mosaic_tracks_ground_truth():
     frames, Gs = video(6)
     om = OracleMosaic(frames[0], nfeatures=500)
