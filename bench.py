@@ -635,6 +635,11 @@ def main():
         extras = {}
         solo = world == 1
         progress("timed pass done: %.1f frames/s; host-frame legs" % (K / elapsed))
+        if solo:
+            # The legs below build contexts of their own; a caller has one context per video, so the timed
+            # context goes before they start (the parity check builds its own).
+            ctx.close()
+            ctx = None
         if args.dropin_frames > 0 and solo:
             extras["dropin_pcie_inclusive"] = leg_dropin(args, cfg, frames, local_rank, T)
         if args.sift_frames > 0 and solo:
@@ -652,6 +657,9 @@ def main():
                    "sample": "first %d frames of the same synthetic video through the oracle/ C++ restatement, "
                              "one thread" % n1}
             # the same frames through the GPU path: the mosaic must be the oracle's, pixel for pixel
+            ctx = rtvm.Context(fh, fw, ch, cw, detector=rtvm._ffi.DET_SIFT if sift else rtvm._ffi.DET_ORB, nfeatures=nf,
+                               flags=flags, device=local_rank)
+            ctx.reserve_batch(B)
             ctx.stream_begin(base, row_off, col_off)
             st_p, _ = run(1, n1)
             _, _, _, H_p = ctx.frame_status()
@@ -709,7 +717,8 @@ def main():
             with open(args.kernel_table, "w") as f:
                 json.dump({"frames": K, "canvas_half_frames": K1, "kernels": rows}, f, indent=1)
         print(json.dumps(out))
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -215,16 +215,15 @@ class HostFrameRing:
     pinned slot i % n_slots and from there to the device when its batch is about to be detected.
     n_slots must cover the frames process_video keeps alive (four batches) plus the batch that is
     copied ahead; one more slot holds the first frame of the stream.  The copies into the pinned
-    slots run on a few threads (numpy releases the GIL for them; one thread moves about 10 GB/s,
-    some 3.5 K 720p frames/s), and the batch after the one just handed out is copied in the
-    background while the device works."""
+    slots are rtvm_ingest_write calls (a few threads inside the library, non-temporal stores: about
+    30 us for a 720p frame) made from one background thread, so that the batch after the one just
+    handed out is copied while the device works."""
 
-    def __init__(self, ctx, n_slots, copy_threads=4):
+    def __init__(self, ctx, n_slots):
         from concurrent.futures import ThreadPoolExecutor
         ctx.ingest_reserve(n_slots + 1)
         self.ctx, self.n_slots, self.frames = ctx, n_slots, []
-        self.views = [ctx.ingest_host_slot(i) for i in range(n_slots + 1)]
-        self.pool = ThreadPoolExecutor(max_workers=max(1, copy_threads))
+        self.pool = ThreadPoolExecutor(max_workers=1)
         self.ahead = None   # (first, k, futures) of the batch being copied ahead
 
     def __len__(self):
@@ -232,11 +231,16 @@ class HostFrameRing:
 
     def upload_first(self, frame):
         self._settle()
-        np.copyto(self.views[self.n_slots], frame)
+        self.ctx.ingest_write(self.n_slots, frame)
         return self.ctx.ingest_submit(self.n_slots)
 
     def _copy(self, first, k):
-        return [self.pool.submit(np.copyto, self.views[i % self.n_slots], self.frames[i]) for i in range(first, first + k)]
+        frames, n, write = self.frames, self.n_slots, self.ctx.ingest_write
+
+        def job():
+            for i in range(first, first + k):
+                write(i % n, frames[i])
+        return [self.pool.submit(job)]
 
     def _settle(self):
         if self.ahead is not None:
@@ -792,7 +796,8 @@ class Context:
 
     def ingest_write(self, slot, bgr):
         """Copies a host frame into the pinned slot (several threads for large frames); complete on return."""
-        self._check(lib().rtvm_ingest_write(self._h, int(slot), ptr(self._frame(bgr, "ingest_write"))))
+        bgr = self._frame(bgr, "ingest_write")
+        self._check(lib().rtvm_ingest_write(self._h, int(slot), C.c_void_p(bgr.ctypes.data)))
 
     def ingest_host_slot(self, slot):
         """The pinned host frame of a slot as a numpy array (frame_h, frame_w, 3) u8 to write into."""

@@ -388,6 +388,142 @@ void free_all(rtvm_ctx* c) {
 
 extern "C" int rtvm_version(void) { return RTVM_VERSION; }
 
+// ---- streams and the hardware queues behind them -------------------------------------------------
+// The runtime gives a process a few hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise) and puts a new
+// stream on the queue with the fewest streams, the first such in the order of the queues' addresses: which streams
+// end up together depends on what the process created before.  A queue runs its packets in order, so a kernel
+// queued behind another stream's wait for an event waits with it.  Measured with the 720p ORB pipeline on four
+// queues: 19.7 K frames/s with the streams laid out well, 14.5 K with one stray stream created first; host frames
+// through the ingest ring 13 K against 10.5 K.  So the layout is made, not met: candidates are created, a probe
+// finds out which of them share a queue, every role takes a candidate from the class it should be in and the
+// rest are destroyed.
+namespace {
+
+// One lane polls flag[0] until it is set or `ticks` of the 100 MHz wall clock have passed; flag[1] = was it set.
+__global__ void k_probe_wait(volatile int* flag, long long ticks) {
+    const long long t0 = wall_clock64();
+    int seen = 0;
+    for (int i = 0; i < (1 << 16) && wall_clock64() - t0 < ticks; i++) {
+        if (flag[0]) {
+            seen = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    flag[1] = seen;
+}
+__global__ void k_probe_set(volatile int* flag) { flag[0] = 1; }
+
+}  // namespace
+
+bool rtvm_queue_probe_begin(RtvmQueueProbe* P, int device) {
+    P->flag = nullptr;
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) return false;
+    P->ticks = (long long)khz * 200 / 1000;   // 200 us; a kernel on another queue starts within some ten
+    return hipMalloc((void**)&P->flag, 2 * sizeof(int)) == hipSuccess;
+}
+
+void rtvm_queue_probe_end(RtvmQueueProbe* P) {
+    if (P->flag) (void)hipFree(P->flag);
+    P->flag = nullptr;
+}
+
+// 1: a kernel on b does not start while one on a runs (the streams share a hardware queue); 0: it does; -1: error.
+// "It does" cannot be wrong; "it does not" can (a GPU too busy to start one lane in 200 us), so it is asked twice.
+int rtvm_streams_share_queue(RtvmQueueProbe* P, hipStream_t a, hipStream_t b) {
+    for (int rep = 0; rep < 2; rep++) {
+        int h[2] = {0, 0};
+        if (hipMemsetAsync(P->flag, 0, 2 * sizeof(int), a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, a, P->flag, P->ticks);
+        hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, b, P->flag);
+        if (hipGetLastError() != hipSuccess) return -1;
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+        if (hipMemcpyAsync(h, P->flag, sizeof(h), hipMemcpyDeviceToHost, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess)
+            return -1;
+        if (h[1]) return 0;
+    }
+    return 1;
+}
+
+namespace {
+
+// Creates the working streams of a multi-stream context: roles[r] takes a candidate of the first class of
+// prefs[r] (classes in the order they were met) that still has one.  false: nothing was created (the caller
+// falls back to plain creation).
+struct StreamRole {
+    hipStream_t* out;
+    int prefs_many[4];   // when there is a class for every role
+    int prefs_few[4];    // when there is not: -1 ends the list
+};
+
+bool create_streams_by_queue(rtvm_ctx* c, StreamRole* roles, int n_roles) {
+    constexpr int MAXC = 10;
+    RtvmQueueProbe P;
+    if (!rtvm_queue_probe_begin(&P, c->device)) return false;
+    hipStream_t cand[MAXC];
+    int cls[MAXC], rep[MAXC], n = 0, ncls = 0;
+    int pick[8];
+    bool ok = true, ideal = false;
+    while (ok && !ideal && n < MAXC) {
+        if (hipStreamCreate(&cand[n]) != hipSuccess) break;
+        int k = -1;
+        for (int r = 0; r < ncls && k < 0 && ok; r++) {
+            const int same = rtvm_streams_share_queue(&P, cand[rep[r]], cand[n]);
+            if (same < 0) ok = false;
+            if (same == 1) k = r;
+        }
+        if (k < 0) {
+            k = ncls;
+            rep[ncls++] = n;
+        }
+        cls[n++] = k;
+        // the assignment with what there is so far
+        bool used[MAXC] = {};
+        ideal = true;
+        for (int r = 0; r < n_roles; r++) {
+            const int* prefs = ncls > n_roles ? roles[r].prefs_many : roles[r].prefs_few;
+            pick[r] = -1;
+            for (int q = 0; q < 4 && prefs[q] >= 0 && pick[r] < 0; q++) {
+                for (int i = 0; i < n && pick[r] < 0; i++)
+                    if (!used[i] && cls[i] == prefs[q]) pick[r] = i;
+                if (pick[r] < 0) ideal = false;   // the first choice was not to be had
+            }
+            if (pick[r] < 0)
+                for (int i = 0; i < n && pick[r] < 0; i++)
+                    if (!used[i]) pick[r] = i;
+            if (pick[r] >= 0)
+                used[pick[r]] = true;
+            else
+                ideal = false;
+        }
+        // with fewer classes than roles the first choices may never come: one candidate per role and class is enough
+        if (!ideal && n >= 2 * n_roles) break;
+    }
+    rtvm_queue_probe_end(&P);
+    bool all = ok && n >= n_roles;
+    for (int r = 0; r < n_roles && all; r++) all = pick[r] >= 0;
+    if (getenv("RTVM_QUEUE_DEBUG")) {
+        fprintf(stderr, "rtvm: %d candidate streams, queue classes", n);
+        for (int i = 0; i < n; i++) fprintf(stderr, " %d", cls[i]);
+        fprintf(stderr, "; roles take");
+        for (int r = 0; r < n_roles && all; r++) fprintf(stderr, " %d", pick[r]);
+        fprintf(stderr, "%s\n", all ? "" : " nothing (plain creation)");
+    }
+    bool used[MAXC] = {};
+    if (all)
+        for (int r = 0; r < n_roles; r++) {
+            *roles[r].out = cand[pick[r]];
+            used[pick[r]] = true;
+        }
+    for (int i = 0; i < n; i++)
+        if (!used[i]) (void)hipStreamDestroy(cand[i]);
+    return all;
+}
+
+}  // namespace
+
+
 static void destroy_streams(rtvm_ctx* c) {
     if (c->stream_front2 != c->stream_front) (void)hipStreamDestroy(c->stream_front2);
     if (c->stream_lm != c->stream_main && c->stream_lm != c->stream_front) (void)hipStreamDestroy(c->stream_lm);
@@ -420,44 +556,67 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
     c->nfeatures = nfeatures;
     c->flags = flags;
     // A context without a frame size (or with RTVM_FLAG_SINGLE_STREAM) serves the stage entry
-    // points only, one call at a time: it gets a single stream.  (A process has few hardware queues and streams are dealt onto them in
-    // turn; four streams per context would put the working streams of several such contexts, one
-    // per host thread, onto the same queue.)
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream_main) != hipSuccess) {
-        delete c;
-        return RTVM_E_HIP;
-    }
-    c->stream_front = c->stream_front2 = c->stream_rs = c->stream_lm = c->stream_main;
+    // points only, one call at a time: it gets a single stream.
     // (All streams at the default priority: with the main stream on a high-priority queue the frame
     // rate rose by under 1 %, and a context used next to the single-stream contexts of worker
     // threads stopped making progress.)
-    if (frame_h > 0 && !(flags & RTVM_FLAG_SINGLE_STREAM)) {
-        // The runtime deals streams onto the process' few hardware queues in creation order (observed with four
-        // queues: the null stream's, then 2, 3, 4, 4, 3, 2 for the streams created), and a queue runs what it holds
-        // in order: a kernel behind another stream's wait for an event waits with it.  A SIFT context, whose
-        // detection is the longest stream and holds kernels of a few waves, therefore gets three streams, each on
-        // a queue of its own: the canvas half, and two that take the batches of the even and of the odd slot sets
-        // through detection, matching and RANSAC, so that consecutive batches overlap.  Other contexts: canvas
-        // half, detection + matching, RANSAC search, RANSAC polish (the last two share a queue).
-        const bool two_front = detector == RTVM_DET_SIFT && !getenv("RTVM_ONE_DETECT_STREAM");
-        hipStream_t* more[4] = {&c->stream_front, two_front ? &c->stream_front2 : nullptr, two_front ? nullptr : &c->stream_rs,
-                                two_front ? nullptr : &c->stream_lm};
-        bool ok = true;
-        for (hipStream_t* st : more)
-            if (st && ok && hipStreamCreate(st) != hipSuccess) {
-                *st = c->stream_main;
-                ok = false;
-            }
-        if (!two_front || !ok) {
-            if (two_front && c->stream_front2 != c->stream_main && c->stream_front2 != c->stream_front)
-                (void)hipStreamDestroy(c->stream_front2);
-            c->stream_front2 = c->stream_front;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete c;
+        return RTVM_E_HIP;
+    }
+    const bool multi = frame_h > 0 && !(flags & RTVM_FLAG_SINGLE_STREAM);
+    // A SIFT context, whose detection is the longest stream and holds kernels of a few waves, gets three
+    // streams: the canvas half, and two that take the batches of the even and of the odd slot sets through
+    // detection, matching and RANSAC, so that consecutive batches overlap.  Other contexts: canvas half,
+    // detection + matching, RANSAC search, RANSAC polish.
+    const bool two_front = detector == RTVM_DET_SIFT && !getenv("RTVM_ONE_DETECT_STREAM");
+    bool made = false;
+    if (multi && !getenv("RTVM_NO_QUEUE_PROBE")) {
+        // Every stream on a queue of its own where the process has queues to spare (and one left for the ingest
+        // ring's copies); with four queues the two RANSAC streams, which wait for each other anyway, share one.
+        // The canvas half never shares with another stream of the context.
+        if (two_front) {
+            StreamRole roles[3] = {{&c->stream_main, {0, -1, -1, -1}, {0, -1, -1, -1}},
+                                   {&c->stream_front, {1, -1, -1, -1}, {1, 0, -1, -1}},
+                                   {&c->stream_front2, {2, -1, -1, -1}, {2, 1, 0, -1}}};
+            made = create_streams_by_queue(c, roles, 3);
+            if (made) c->stream_rs = c->stream_lm = c->stream_front;   // per batch: the stream of its detection
+        } else {
+            StreamRole roles[4] = {{&c->stream_main, {0, -1, -1, -1}, {0, -1, -1, -1}},
+                                   {&c->stream_front, {1, -1, -1, -1}, {1, 0, -1, -1}},
+                                   {&c->stream_rs, {2, -1, -1, -1}, {2, 1, 0, -1}},
+                                   {&c->stream_lm, {3, -1, -1, -1}, {2, 3, 1, 0}}};
+            made = create_streams_by_queue(c, roles, 4);
+            if (made) c->stream_front2 = c->stream_front;
         }
-        if (two_front && ok) c->stream_rs = c->stream_lm = c->stream_front;   // per batch: the stream of its detection
-        if (!ok) {
-            destroy_streams(c);
+    }
+    if (!made) {
+        // plain creation: the streams land where the runtime puts them
+        if (hipStreamCreate(&c->stream_main) != hipSuccess) {
             delete c;
             return RTVM_E_HIP;
+        }
+        c->stream_front = c->stream_front2 = c->stream_rs = c->stream_lm = c->stream_main;
+        if (multi) {
+            hipStream_t* more[4] = {&c->stream_front, two_front ? &c->stream_front2 : nullptr, two_front ? nullptr : &c->stream_rs,
+                                    two_front ? nullptr : &c->stream_lm};
+            bool ok = true;
+            for (hipStream_t* st : more)
+                if (st && ok && hipStreamCreate(st) != hipSuccess) {
+                    *st = c->stream_main;
+                    ok = false;
+                }
+            if (!two_front || !ok) {
+                if (two_front && c->stream_front2 != c->stream_main && c->stream_front2 != c->stream_front)
+                    (void)hipStreamDestroy(c->stream_front2);
+                c->stream_front2 = c->stream_front;
+            }
+            if (two_front && ok) c->stream_rs = c->stream_lm = c->stream_front;   // per batch: the stream of its detection
+            if (!ok) {
+                destroy_streams(c);
+                delete c;
+                return RTVM_E_HIP;
+            }
         }
     }
     c->stream = c->stream_main;

@@ -460,6 +460,14 @@ int rtvm_slots_alloc(rtvm_ctx* c, int slot, int cap_kp, int kind);
 size_t rtvm_ransac_state_bytes();
 void rtvm_ransac_raw_table(uint32_t* raw, int n);
 void rtvm_ingest_pool_free(rtvm_ctx* c);
+// Which streams share a hardware queue (api.hip): begin allocates the probe's two words on the current device.
+struct RtvmQueueProbe {
+    int* flag;
+    long long ticks;
+};
+bool rtvm_queue_probe_begin(RtvmQueueProbe* P, int device);
+void rtvm_queue_probe_end(RtvmQueueProbe* P);
+int rtvm_streams_share_queue(RtvmQueueProbe* P, hipStream_t a, hipStream_t b);   // 1 shared, 0 not, -1 error
 // video.hip
 void rtvm_pipe_free(rtvm_ctx* c);
 int rtvm_launch_ransac(rtvm_ctx* c, int sb, int nb, double thresh, int max_iters, double confidence);

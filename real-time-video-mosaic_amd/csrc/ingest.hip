@@ -5,16 +5,46 @@
 // (detection, warp) waits for the copy, not the host.
 #include "common.h"
 
+#include <emmintrin.h>
+
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 #include <vector>
 
 namespace {
 
+// memcpy into a pinned slot with non-temporal stores.  The slot is written once and next read by the copy engine:
+// an ordinary store first fetches every destination line into the cache (twice the memory traffic, and the frame
+// pushes the caller's data out of the cache for nothing).  Measured for a 720p frame on four threads: 29 us against
+// 63 us with memcpy, 62 against 92 us on one.
+void copy_streaming(uint8_t* d, const uint8_t* s, size_t n) {
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
+    if (head >= n) {
+        memcpy(d, s, n);
+        return;
+    }
+    memcpy(d, s, head);
+    d += head, s += head, n -= head;
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i + 16));
+        const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i + 32));
+        const __m128i e = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i + 48));
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + i), a);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + i + 16), b);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + i + 32), c);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + i + 48), e);
+    }
+    _mm_sfence();   // the stores are globally visible before the copy engine is told about the slot
+    if (i < n) memcpy(d + i, s + i, n - i);
+}
+
 // A few threads that copy a frame into a pinned slot side by side with the caller: one thread moves about
-// 10 GB/s, a 720p frame (2.8 MB) in a quarter of a millisecond -- more than everything else
-// a process_frame call does.  The workers sleep on a condition variable between frames.
+// 45 GB/s, a 720p frame (2.8 MB) in 60 us -- more than everything else a call that only hands a frame
+// in does.  The workers sleep on a condition variable between frames.
 struct CopyPool {
     static constexpr int WORKERS = 3;
     std::thread th[WORKERS];
@@ -42,7 +72,7 @@ struct CopyPool {
                 lo = (size_t)(id + 1) * chunk;
                 hi = lo + chunk < bytes ? lo + chunk : bytes;
             }
-            if (lo < hi) memcpy(d + lo, s + lo, hi - lo);
+            if (lo < hi) copy_streaming(d + lo, s + lo, hi - lo);
             {
                 std::lock_guard<std::mutex> lk(m);
                 if (--pending == 0) done.notify_one();
@@ -69,7 +99,7 @@ struct CopyPool {
             gen++;
         }
         go.notify_all();
-        memcpy(d, s, chunk < n ? chunk : n);  // the caller's share
+        copy_streaming(d, s, chunk < n ? chunk : n);  // the caller's share
         std::unique_lock<std::mutex> lk(m);
         done.wait(lk, [&] { return pending == 0; });
     }
@@ -111,7 +141,45 @@ extern "C" int rtvm_ingest_reserve(rtvm_ctx* c, int n_slots) {
         memset(c->ingest_host, 0, chunk < bytes ? chunk : bytes);
         for (auto& t : th) t.join();
     }
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+    // The copy stream: the stream's packets (the marker of every copy's event) must not sit behind the waits of the
+    // canvas half or of the RANSAC streams.  A few candidates, the one that shares a hardware queue with the
+    // fewest and least harmful of the context's streams is kept (none: 0; detection only, whose kernels the copy
+    // is needed for anyway: 1; a RANSAC stream: 4; the canvas half: 16).
+    {
+        constexpr int TRIES = 6;
+        hipStream_t cand[TRIES];
+        int n = 0, best = -1, best_cost = 1 << 30;
+        RtvmQueueProbe P;
+        const bool probe = c->stream_front != c->stream_main && !getenv("RTVM_NO_QUEUE_PROBE") && rtvm_queue_probe_begin(&P, c->device);
+        while (n < TRIES) {
+            if (hipStreamCreateWithFlags(&cand[n], hipStreamNonBlocking) != hipSuccess) break;
+            n++;
+            int cost = 0;
+            if (probe) {
+                hipStream_t own[5] = {c->stream_main, c->stream_front, c->stream_front2, c->stream_rs, c->stream_lm};
+                const int weight[5] = {16, 1, 1, 4, 4};
+                for (int i = 0; i < 5 && cost >= 0; i++) {
+                    bool seen = false;
+                    for (int j = 0; j < i; j++) seen |= own[j] == own[i];
+                    if (seen) continue;
+                    const int same = rtvm_streams_share_queue(&P, own[i], cand[n - 1]);
+                    if (same < 0)
+                        cost = -1;
+                    else if (same)
+                        cost += weight[i];
+                }
+                if (cost < 0) cost = 1 << 20;   // the probe failed: any stream will do
+            }
+            if (cost < best_cost) best = n - 1, best_cost = cost;
+            if (!probe || cost == 0) break;
+        }
+        if (probe) rtvm_queue_probe_end(&P);
+        if (getenv("RTVM_QUEUE_DEBUG")) fprintf(stderr, "rtvm: copy stream is candidate %d of %d, cost %d\n", best, n, best_cost);
+        for (int i = 0; i < n; i++)
+            if (i != best) (void)hipStreamDestroy(cand[i]);
+        if (best < 0) RTVM_FAIL(c, RTVM_E_HIP, "ingest_reserve: no stream for the copies");
+        c->stream_copy = cand[best];
+    }
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_ingest, hipEventDisableTiming));
     c->ingest_slots = n_slots;
     return RTVM_OK;
@@ -132,7 +200,7 @@ extern "C" int rtvm_ingest_write(rtvm_ctx* c, int slot, const uint8_t* bgr_host)
     const size_t fb = (size_t)c->fh * c->fw * 3;
     uint8_t* dst = c->ingest_host + (size_t)slot * fb;
     if (fb < ((size_t)1 << 20)) {  // small frames: the hand-over costs more than it saves
-        memcpy(dst, bgr_host, fb);
+        copy_streaming(dst, bgr_host, fb);
         return RTVM_OK;
     }
     if (!c->ingest_pool) c->ingest_pool = new CopyPool();

@@ -110,6 +110,11 @@ class _Pipeline:
         self.ctx.pipe_close()
 
 
+# np.linspace(0.5, 1.0, n) / sum for the history lengths seen so far (smooth_homography): the same values every
+# frame, and a quarter of what the rules of a frame cost when computed anew.  The arrays are never written to.
+_SMOOTH_WEIGHTS = {}
+
+
 class VideMosaic:
     def __init__(self, first_image, output_height_times=2, output_width_times=1.2, detector_type="sift",
                  show_intermediate=True, output_dir=None, visualize=True, *, nfeatures=700, canvas_size=None,
@@ -529,7 +534,7 @@ class VideMosaic:
         """main.py:761-801."""
         if H is None:
             return False
-        if np.any(np.isnan(H)) or np.any(np.isinf(H)):
+        if not np.isfinite(H).all():            # np.any(np.isnan(H)) or np.any(np.isinf(H)), in one pass
             return False
         shift = np.sqrt(H[0, 2] ** 2 + H[1, 2] ** 2)
         zoom = np.sqrt(np.linalg.det(H[:2, :2]))
@@ -555,8 +560,10 @@ class VideMosaic:
         n = len(history)
         if n < 2:
             return H
-        w = np.linspace(0.5, 1.0, n)
-        w = w / np.sum(w)
+        w = _SMOOTH_WEIGHTS.get(n)
+        if w is None:
+            w = np.linspace(0.5, 1.0, n)
+            w = _SMOOTH_WEIGHTS[n] = w / np.sum(w)
         acc = np.zeros_like(H)
         for wi, hi in zip(w, history):
             acc += wi * hi

@@ -222,6 +222,29 @@ def test_batched_stream_matches_oracle(batch, flags):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("detector", ["orb", "sift"])
+def test_streams_laid_out_by_the_queue_probe_or_as_the_runtime_deals_them(detector, monkeypatch, capfd):
+    """A context picks its streams by which hardware queue they sit on (a probe at creation); RTVM_NO_QUEUE_PROBE
+    leaves them where the runtime puts them.  Same results either way, host frames through the ingest ring."""
+    frames, _ = video(14)
+    det = rtvm._ffi.DET_SIFT if detector == "sift" else rtvm._ffi.DET_ORB
+    got = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("RTVM_NO_QUEUE_PROBE", "1")
+        monkeypatch.setenv("RTVM_QUEUE_DEBUG", "1")
+        ctx = rtvm.Context(FH, FW, 2 * FH, int(1.2 * FW), nfeatures=400, detector=det)
+        st = ctx.process_host_video(frames[0], frames[1:], FH, int(1.2 * FW / 2 - FW / 2), batch=4)
+        got.append((st.tolist(), ctx.frame_status()[3], ctx.canvas_read()))
+        ctx.close()
+        err = capfd.readouterr().err
+        assert ("candidate streams, queue classes" in err) == (not plain)
+        assert "copy stream is candidate" in err
+    assert got[0][0] == got[1][0] == [0] * 13
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
+
+
+@pytest.mark.gpu
 def test_batches_queued_back_to_back():
     """Batches queued without reading any status in between (two in flight on two streams):
     same canvas as frame-by-frame processing; after a skipped frame everything later is pending."""

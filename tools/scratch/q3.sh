@@ -1,0 +1,8 @@
+#!/bin/bash
+# the default bench with the streams laid out by the probe, and without
+for v in probe plain probe plain; do
+  if [ $v = plain ]; then export RTVM_NO_QUEUE_PROBE=1; else unset RTVM_NO_QUEUE_PROBE; fi
+  RTVM_QUEUE_DEBUG=1 timeout -k 10 200 python bench.py --cpu-frames 0 > gpurun_out/p_$v.log 2>gpurun_out/p_$v.err || { tail -5 gpurun_out/p_$v.err; exit 1; }
+  grep "^rtvm:" gpurun_out/p_$v.err | sort | uniq -c
+  tail -1 gpurun_out/p_$v.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value']), round(d['dropin_default_flags']['orb']), round(d['dropin_default_flags']['sift']), round(d['host_frames_pcie_inclusive']['value']))"
+done
