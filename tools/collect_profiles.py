@@ -8,13 +8,16 @@ SRC, DST = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles")
 
 
 def last_json(path):
+    if not os.path.exists(path):
+        return None
     for line in reversed(open(path).read().splitlines()):
         if line.startswith("{"):
             return json.loads(line)
     return None
 
 
-cfgs = sys.argv[1:] or ["720p_orb1000", "720p_orb1000_driver_command", "720p_sift700", "1080p_sift2000_l2", "4k_orb4000_canvas16k"]
+cfgs = sys.argv[1:] or ["720p_orb1000", "720p_orb1000_driver_command", "720p_sift700", "1080p_sift2000_l2", "4k_orb4000_canvas16k",
+                        "1080p_orb1000", "360p_orb700"]
 for c in cfgs:
     d = last_json(os.path.join(SRC, "bench_%s.log" % c))
     if d:

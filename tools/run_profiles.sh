@@ -21,6 +21,8 @@ step bench_720p_orb1000_driver_command 300 python3 bench.py --gpus 1 --steps 20 
 step bench_720p_sift700 300 python3 bench.py --config 720p_sift700 --cpu-frames 4 --kernel-table "$OUT/kernels_720p_sift700.json"
 step bench_1080p_sift2000_l2 300 python3 bench.py --config 1080p_sift2000_l2 --cpu-frames 4
 step bench_4k_orb4000_canvas16k 400 python3 bench.py --config 4k_orb4000_canvas16k --steps 64 --warmup 8 --cpu-frames 1 --host-frames 0 --dropin-frames 0 --sift-frames 0 --kernel-table "$OUT/kernels_4k_orb4000_canvas16k.json"
+step bench_1080p_orb1000 300 python3 bench.py --config 1080p_orb1000 --steps 256 --cpu-frames 4 --kernel-table "$OUT/kernels_1080p_orb1000.json"
+step bench_360p_orb700 300 python3 bench.py --config 360p_orb700 --steps 256 --cpu-frames 8 --kernel-table "$OUT/kernels_360p_orb700.json"
 step bench_procs2 300 python3 bench.py --procs 2 --cpu-frames 0 --host-frames 0 --dropin-frames 0 --sift-frames 0
 step bench_procs4 300 python3 bench.py --procs 4 --cpu-frames 0 --host-frames 0 --dropin-frames 0 --sift-frames 0
 cd /tmp
