@@ -97,7 +97,11 @@ int rtvm_version(void);
  * frame_h/frame_w: size of every frame of the stream (0 x 0 for a context that only
  * matches or fits; otherwise at least 2 x 2); canvas_h/canvas_w: mosaic
  * canvas (main.py:80-81 computes int(oh*H) x int(ow*W)); nfeatures: ORB_create(n)
- * (main.py:36).  All device memory the context will ever use is allocated here. */
+ * (main.py:36).  All device memory the context will ever use is allocated here.
+ * A context with a frame size (and without RTVM_FLAG_SINGLE_STREAM) owns several HIP streams and chooses them by
+ * the hardware queue they sit on: it creates a few candidates, launches pairs of one-lane kernels of at most 200 us
+ * to find out which candidates share a queue, keeps one per role and destroys the rest (about 2 ms; environment:
+ * RTVM_NO_QUEUE_PROBE=1 takes the streams as the runtime deals them, RTVM_QUEUE_DEBUG=1 reports on stderr). */
 int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w, int canvas_h, int canvas_w,
                 int detector, int nfeatures, int flags);
 void rtvm_destroy(rtvm_ctx* ctx);
