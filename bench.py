@@ -322,6 +322,24 @@ def leg_dropin(args, cfg, frames, local_rank, T):
               "flags": "reference defaults: visualize=True, show_intermediate=True",
               "note": "Python VideMosaic.process_frame, one host frame per call: copy into the pinned "
                       "ring, PCIe copy, batched detection, host-side validate/smooth/chain, batched warp + blend"}
+    # ... and as the reference's loop runs with a progress call-back (main.py:1630-1632): output_img.copy() after
+    # every frame, i.e. the float64 mosaic read back and copied by the caller once per frame
+    nc = min(48, nd - n_warm)
+    if nc >= 8:
+        t_read = 0.0
+        td0 = time.perf_counter()
+        for t in range(nd + 1 - nc, nd + 1):
+            vm.process_frame(host_frames[t], t)
+            tr0 = time.perf_counter()
+            img = vm.output_img
+            t_read += time.perf_counter() - tr0
+            img = img.copy()
+        td = time.perf_counter() - td0
+        dropin["process_frame_then_output_img_copy"] = {
+            "value": nc / td, "frames": nc, "ms_per_output_img": t_read / nc * 1e3, "mosaic_mbytes_float64": img.nbytes / 1e6,
+            "note": "every call followed by output_img.copy(): the frame is stitched before the read returns, the u8 canvas "
+                    "crosses PCIe and is widened to the reference's float64 on four host threads; the caller's copy of "
+                    "the float64 array is in the time"}
     vm.close()
     # the same class with pipeline_batch=0: every call completes before it returns
     ns = min(136, nd)

@@ -209,6 +209,11 @@ int rtvm_warp_blend(rtvm_ctx* ctx, const uint8_t* bgr, const double H[9]);
 /* output_img readers  main.py:1632,1649: canvas_h*canvas_w*3 u8 (the reference's
  * float64 canvas only ever holds these integers).  Syncs the stream. */
 int rtvm_canvas_read(rtvm_ctx* ctx, uint8_t* out);
+/* The same mosaic as the reference holds it: VideMosaic.output_img is np.zeros((h, w, 3)), float64 (main.py:80-81), into
+ * which every blend stores astype(np.uint8) values (main.py:905-910); main.py:1632 hands output_img.copy() to the
+ * caller's progress call-back after every frame.  out: canvas_h x canvas_w x 3 doubles.  The bytes cross PCIe (into
+ * a pinned buffer the context allocates at the first call) and are widened on the host. */
+int rtvm_canvas_read_f64(rtvm_ctx* ctx, double* out);
 
 /* ---- device-resident stream path -------------------------------------- */
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "rtvm_distance_transform": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "rtvm_warp_blend": (C.c_int, [_vp, _vp, _vp]),
     "rtvm_canvas_read": (C.c_int, [_vp, _vp]),
+    "rtvm_canvas_read_f64": (C.c_int, [_vp, _vp]),
     "rtvm_sift_max_keypoints": (C.c_int, [C.c_int]),
     "rtvm_sift": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _intp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rtvm_ingest_reserve": (C.c_int, [_vp, C.c_int]),
@@ -413,6 +414,13 @@ class Context:
     def canvas_read(self):
         out = np.empty((self.canvas_h, self.canvas_w, 3), np.uint8)
         self._check(lib().rtvm_canvas_read(self._h, ptr(out)))
+        return out
+
+    def canvas_read_f64(self):
+        """The mosaic as float64 (the reference's dtype, main.py:80-81): widened on the host from the bytes that
+        crossed PCIe."""
+        out = np.empty((self.canvas_h, self.canvas_w, 3), np.float64)
+        self._check(lib().rtvm_canvas_read_f64(self._h, C.c_void_p(out.ctypes.data)))
         return out
 
     def sync(self):

@@ -4,6 +4,11 @@
 // copies the results back and waits.
 #include "common.h"
 
+#include <emmintrin.h>
+
+#include <thread>
+#include <vector>
+
 #include <cstdlib>
 
 #include <new>
@@ -354,6 +359,7 @@ void free_all(rtvm_ctx* c) {
     if (c->ev_ingest) (void)hipEventDestroy(c->ev_ingest);
     c->ev_ingest = nullptr;
     if (c->ingest_host) (void)hipHostFree(c->ingest_host);
+    if (c->h_canvas) (void)hipHostFree(c->h_canvas);
     if (c->ingest_dev) (void)hipFree(c->ingest_dev);
     c->ingest_host = c->ingest_dev = nullptr;
     c->ingest_slots = 0;
@@ -913,6 +919,55 @@ extern "C" int rtvm_warp_blend(rtvm_ctx* c, const uint8_t* bgr, const double H[9
     HIP_TRY(c, hipEventRecord(c->ev_upload, c->stream));
     if ((r = rtvm_launch_warp_blend(c, c->d_bgr, c->d_H))) return r;
     HIP_TRY(c, hipEventSynchronize(c->ev_upload));
+    return RTVM_OK;
+}
+
+// u8 -> float64 with non-temporal stores (the destination is eight times the source and is not read back here)
+static void widen_u8_f64(const uint8_t* s, double* d, size_t n) {
+    size_t i = 0;
+    if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) {
+        const __m128i zero = _mm_setzero_si128();
+        for (; i + 16 <= n; i += 16) {
+            const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + i));
+            const __m128i lo = _mm_unpacklo_epi8(b, zero), hi = _mm_unpackhi_epi8(b, zero);
+            const __m128i w[4] = {_mm_unpacklo_epi16(lo, zero), _mm_unpackhi_epi16(lo, zero), _mm_unpacklo_epi16(hi, zero),
+                                  _mm_unpackhi_epi16(hi, zero)};
+            for (int k = 0; k < 4; k++) {
+                _mm_stream_pd(d + i + 4 * k, _mm_cvtepi32_pd(w[k]));
+                _mm_stream_pd(d + i + 4 * k + 2, _mm_cvtepi32_pd(_mm_shuffle_epi32(w[k], 0xEE)));
+            }
+        }
+        _mm_sfence();
+    }
+    for (; i < n; i++) d[i] = (double)s[i];
+}
+
+// The mosaic as the reference keeps it (main.py:80-81: np.zeros((h, w, 3)) is float64, and every blend stores
+// astype(np.uint8) values into it, main.py:905-910): canvas_h x canvas_w x 3 doubles holding integers 0..255.  The bytes come over
+// PCIe into a pinned buffer (a ninth of what the doubles would be) and are widened on the host, on four threads.
+extern "C" int rtvm_canvas_read_f64(rtvm_ctx* c, double* out) {
+    if (!c) return RTVM_E_ARG;
+    if (!out) RTVM_FAIL(c, RTVM_E_ARG, "canvas_read_f64: null output");
+    int r = need_canvas(c, "canvas_read_f64");
+    if (r) return r;
+    if (!c->canvas_ready) RTVM_FAIL(c, RTVM_E_STATE, "canvas_read_f64: call rtvm_canvas_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->ch * c->cw * 3;
+    if (!c->h_canvas) {
+        hipError_t e = hipHostMalloc((void**)&c->h_canvas, n, hipHostMallocDefault);
+        if (e != hipSuccess) RTVM_FAIL(c, RTVM_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_canvas, c->d_canvas, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int nthreads = n >= ((size_t)1 << 20) ? 4 : 1;
+    const size_t chunk = ((n / nthreads + 63) & ~(size_t)63);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) {
+        const size_t lo = (size_t)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        if (lo < hi) th.emplace_back([=] { widen_u8_f64(c->h_canvas + lo, out + lo, hi - lo); });
+    }
+    widen_u8_f64(c->h_canvas, out, chunk < n ? chunk : n);
+    for (auto& t : th) t.join();
     return RTVM_OK;
 }
 

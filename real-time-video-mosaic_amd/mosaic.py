@@ -481,7 +481,7 @@ class VideMosaic:
         """The mosaic as the reference keeps it: (Hc, Wc, 3) float64 holding integers 0..255."""
         self._sync()
         if self._canvas_cache is None:
-            self._canvas_cache = self._ctx.canvas_read().astype(np.float64)
+            self._canvas_cache = self._ctx.canvas_read_f64()
         return self._canvas_cache
 
     def output_img_u8(self):

@@ -297,3 +297,21 @@ def test_hip_warp_blend_requires_init():
     with pytest.raises(rtvm.RtvmError):
         c.warp_blend(np.zeros((FH, FW, 3), np.uint8), np.eye(3))
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch,cw,fh,fw", [(61, 53, 24, 30), (192, 161, 96, 128), (1440, 1536, 720, 1280)])
+def test_hip_canvas_as_float64_is_the_u8_canvas_widened(ch, cw, fh, fw):
+    """rtvm_canvas_read_f64 (the reference's output_img is float64 holding u8 values): every element, for canvases
+    whose byte count is and is not a multiple of the vector width, above and below the size that goes onto threads."""
+    rng = np.random.default_rng(ch)
+    ctx = rtvm.Context(fh, fw, ch, cw, nfeatures=300)
+    first = rng.integers(0, 256, (fh, fw, 3)).astype(np.uint8)
+    ctx.canvas_init(first, ch - fh, (cw - fw) // 2)
+    u8 = ctx.canvas_read()
+    f64 = ctx.canvas_read_f64()
+    again = ctx.canvas_read_f64()
+    ctx.close()
+    assert f64.dtype == np.float64 and f64.shape == (ch, cw, 3)
+    assert np.array_equal(f64, u8.astype(np.float64)) and np.array_equal(again, f64)
+    assert u8[ch - fh:, (cw - fw) // 2:(cw - fw) // 2 + fw].tobytes() == first.tobytes()
