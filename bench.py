@@ -97,6 +97,8 @@ def algorithmic_bytes(name, fh, fw, ch, cw, nkp, roi_px, batch):
         # per frame: mask + warped + two weights in; per batch: canvas + mask in/out and their snapshot
         "k_commit<false>": 12 * roi_px + 12 * roi_px / batch,
         "k_commit4<false>": 12 * roi_px + 12 * roi_px / batch,
+        # the column pass inside the commit: row-blurred weights and warped pixels in per frame; canvas + mask per batch
+        "k_commit_cols<false>": 8 * win + 4 * roi_px + 12 * roi_px / batch,
         "k_hamming_argmin": 2 * nkp * 32 * 2,
         "k_rs_refine": nkp * 16,               # matched point pairs in (latency bound: fp64 solver chains)
     }

@@ -293,6 +293,7 @@ struct rtvm_ctx {
     uint8_t* ingest_dev;
     int ingest_slots;
     hipStream_t stream_copy;
+    int fused_commit;          // the column pass of the blur runs inside the commit kernel (k_commit_cols)
     uint8_t* h_canvas;         // pinned copy of the canvas for rtvm_canvas_read_f64 (allocated at its first call)
     hipEvent_t ev_ingest;      // the last copy queued
     int ingest_used;           // a copy was queued: streams that read frames wait for ev_ingest

@@ -708,19 +708,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 // rows per lane in the column pass of the blur (a workgroup of four waves covers 64 x 4*BC_ROWS pixels)
 constexpr int BC_ROWS = 12;
 
+// The column sums of BC_ROWS consecutive rows (ya ..) of column x from a window of 30 + BC_ROWS row-blurred pairs.
 template <bool EDGE>
-__device__ __forceinline__ void blur_cols_window(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
-                                                 const SideDev& side, int ch, int cw, int x, int ya,
-                                                 const bool (&need)[BC_ROWS]) {
+__device__ __forceinline__ void blur_cols_sums(const float* __restrict__ gk, const SideDev& side, int ch, int cw, int x,
+                                               int ya, f32x2 (&a)[BC_ROWS]) {
     const auto rb = as_global<const f32x2>(side.rb);
-    const auto out_n = as_global(side.dist_new), out_o = as_global(side.dist_old);
     f32x2 v[30 + BC_ROWS];
 #pragma unroll
     for (int j = 0; j < 30 + BC_ROWS; j++) {
         const int y = EDGE ? reflect101(ya - 15 + j, ch) : ya - 15 + j;
         v[j] = rb[(size_t)y * cw + x];
     }
-    f32x2 a[BC_ROWS];
     {
         const float k0 = gk[15];
 #pragma unroll
@@ -752,6 +750,15 @@ __device__ __forceinline__ void blur_cols_window(const WarpParams* __restrict__ 
     }
 #pragma unroll
     for (int i = 0; i < BC_ROWS; i += 4) asm("s_nop 0" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void blur_cols_window(const WarpParams* __restrict__ wp, const float* __restrict__ gk,
+                                                 const SideDev& side, int ch, int cw, int x, int ya,
+                                                 const bool (&need)[BC_ROWS]) {
+    const auto out_n = as_global(side.dist_new), out_o = as_global(side.dist_old);
+    f32x2 a[BC_ROWS];
+    blur_cols_sums<EDGE>(gk, side, ch, cw, x, ya, a);
 #pragma unroll
     for (int i = 0; i < BC_ROWS; i++)
         if (need[i]) {
@@ -1027,6 +1034,141 @@ __global__ __launch_bounds__(256) void k_commit4(const WarpParams* __restrict__ 
     if ((lane & 7) == 0 && bx + 4 * lane < cw) bold[(size_t)y * wpitch + (bx >> 5) + (lane >> 3)] = z;
 }
 
+// Column pass of the blur and commit in one kernel: the final blend weights never go to memory.  A wave is 64
+// columns x BC_ROWS rows of the canvas (lane = column, the rows' pixels in registers as B, G, R and the mask byte of
+// one word each) and carries them through the frames of the batch in order, as k_commit does.  For a frame that
+// covers some of its pixels it fetches the frame's warped pixels; if any of them meets a non-zero canvas pixel it
+// fetches the window of row-blurred weight pairs and runs the column sums of blur_cols_sums (the same operations in
+// the same order as k_blur_cols: same weights), then blends.  Same results as k_blur_cols + k_commit.
+// What it saves: 8 bytes per pixel and frame written by the column pass and read back by the commit; and the
+// column sums where a frame lies on empty canvas.  blockIdx = tile of 64 x 4*BC_ROWS canvas pixels.
+template <bool REDO>
+__global__ __launch_bounds__(256) void k_commit_cols(const WarpParams* __restrict__ wps, const SideDev* __restrict__ sides,
+                                                     const float* __restrict__ gk, int n, uint8_t* __restrict__ mask_old,
+                                                     uint8_t* __restrict__ canvas, uint8_t* __restrict__ snap_mask,
+                                                     uint8_t* __restrict__ snap_canvas, uint32_t* __restrict__ bold,
+                                                     int wpitch, int ch, int cw, StreamState* __restrict__ st,
+                                                     const int* __restrict__ ubox) {
+    int last = n - 1;
+    if (REDO) {
+        last = st->bad_frame;
+        if (last >= n - 1) return;  // every frame was applied with the right weights
+    }
+    const int bx = blockIdx.x * 64, by = blockIdx.y * (4 * BC_ROWS);
+    if (bx >= ubox[2] || bx + 64 <= ubox[0] || by >= ubox[3] || by + 4 * BC_ROWS <= ubox[1]) return;
+    const int lane = threadIdx.x & 63;
+    const int x = bx + lane, ya = by + BC_ROWS * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (ya >= ch) return;
+    // the frames of the batch that touch this wave's pixels, one bit each (a batch has at most 32 frames)
+    uint32_t frames = 0;
+    for (int j = 0; j < n; j++) {
+        const WarpParams* __restrict__ wp = wps + j;
+        if (ya < wp->ry1 && ya + BC_ROWS > wp->ry0 && bx < wp->rx1 && bx + 64 > wp->rx0) frames |= 1u << j;
+    }
+    if (!frames) return;
+    const bool oncanvas = x < cw;
+    const int rows = min(BC_ROWS, ch - ya);   // the same for the whole wave
+    const uint32_t p0 = (uint32_t)ya * (uint32_t)cw + (uint32_t)(oncanvas ? x : 0);
+    uint32_t cv[BC_ROWS];   // B | G << 8 | R << 16 | mask << 24
+#pragma unroll
+    for (int i = 0; i < BC_ROWS; i++) {
+        cv[i] = 0xFF000000u;
+        if (oncanvas && i < rows) {
+            const uint32_t p = p0 + (uint32_t)i * (uint32_t)cw;
+            const uint8_t* __restrict__ src_c = REDO ? snap_canvas : canvas;
+            const uint8_t* __restrict__ src_m = REDO ? snap_mask : mask_old;
+            const uint32_t c0 = src_c[3u * p], c1 = src_c[3u * p + 1], c2 = src_c[3u * p + 2], mo = src_m[p];
+            cv[i] = c0 | (c1 << 8) | (c2 << 16) | (mo << 24);
+            if (!REDO) {
+                snap_canvas[3u * p] = (uint8_t)c0;
+                snap_canvas[3u * p + 1] = (uint8_t)c1;
+                snap_canvas[3u * p + 2] = (uint8_t)c2;
+                snap_mask[p] = (uint8_t)mo;
+            }
+        }
+    }
+    uint32_t changed = REDO ? 0xFFFFFFFFu : 0u;   // bit i: row i was written to
+    const bool edge = !(ya - 15 >= 0 && ya + BC_ROWS + 15 <= ch);   // wave-uniform
+    // The warped pixels of a frame are requested while the frame before it is being blended: a wave walks its
+    // frames one after the other, and with few waves per SIMD nothing else hides the round trips.
+    auto fetch = [&](int j, uint32_t (&px)[BC_ROWS], bool& col_in) {
+        const WarpParams* __restrict__ wp = wps + j;
+        const int rx0 = wp->rx0, rx1 = wp->rx1, ry0 = wp->ry0, ry1 = wp->ry1;
+        col_in = oncanvas && x >= rx0 && x < rx1;
+#pragma unroll
+        for (int i = 0; i < BC_ROWS; i++) {
+            px[i] = 0;
+            if (col_in && ya + i >= ry0 && ya + i < ry1)
+                px[i] = as_global<const uint32_t>(sides[j].warped)[p0 + (uint32_t)i * (uint32_t)cw];
+        }
+    };
+    if (last < 31) frames &= (2u << last) - 1u;
+    uint32_t pxn[BC_ROWS];
+    bool col_in_n = false;
+    if (frames) fetch(__builtin_ctz(frames), pxn, col_in_n);
+    while (frames) {
+        const int j = __builtin_ctz(frames);
+        frames &= frames - 1u;
+        uint32_t px[BC_ROWS];
+        const bool col_in = col_in_n;
+#pragma unroll
+        for (int i = 0; i < BC_ROWS; i++) px[i] = pxn[i];
+        if (frames) fetch(__builtin_ctz(frames), pxn, col_in_n);
+        bool blend = false;
+#pragma unroll
+        for (int i = 0; i < BC_ROWS; i++) blend |= (px[i] >> 24) && (cv[i] >> 24);
+        f32x2 a[BC_ROWS];
+#pragma unroll
+        for (int i = 0; i < BC_ROWS; i++) a[i] = f32x2{0.f, 0.f};
+        if (__any(blend)) {
+            // the lanes outside the frame's columns hold no pixel of it: their sums are never looked at
+            if (col_in) {
+                if (edge)
+                    blur_cols_sums<true>(gk, sides[j], ch, cw, x, ya, a);
+                else
+                    blur_cols_sums<false>(gk, sides[j], ch, cw, x, ya, a);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BC_ROWS; i++) {
+            if (!(px[i] >> 24)) continue;  // outside the frame's mask (or its region)
+            const int w0 = px[i] & 255, w1 = (px[i] >> 8) & 255, w2 = (px[i] >> 16) & 255;
+            changed |= 1u << i;
+            if (!(cv[i] >> 24)) {
+                cv[i] = (px[i] & 0xFFFFFFu) | 0xFF000000u;
+            } else {
+                const float wa = a[i].x, wb = a[i].y;
+                const int c0 = cv[i] & 255, c1 = (cv[i] >> 8) & 255, c2 = (cv[i] >> 16) & 255;
+                const int r0 = (int)((float)c0 * wb + (float)w0 * wa) & 255;  // astype(uint8) truncates
+                const int r1 = (int)((float)c1 * wb + (float)w1 * wa) & 255;
+                const int r2 = (int)((float)c2 * wb + (float)w2 * wa) & 255;
+                const uint32_t mo = (r0 | r1 | r2) ? 255u : 0u;
+                cv[i] = (uint32_t)r0 | ((uint32_t)r1 << 8) | ((uint32_t)r2 << 16) | (mo << 24);
+                // two non-zero pixels blended to zero: the masks predicted for the later frames of
+                // the batch do not hold
+                if (!REDO && !mo) atomicMin(&st->bad_frame, j);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BC_ROWS; i++) {
+        if (i >= rows) continue;
+        const uint32_t p = p0 + (uint32_t)i * (uint32_t)cw;
+        if (oncanvas && ((changed >> i) & 1u)) {
+            canvas[3u * p] = (uint8_t)cv[i];
+            canvas[3u * p + 1] = (uint8_t)(cv[i] >> 8);
+            canvas[3u * p + 2] = (uint8_t)(cv[i] >> 16);
+            mask_old[p] = (uint8_t)(cv[i] >> 24);
+        }
+        const unsigned long long bal = __ballot(oncanvas && (cv[i] >> 24) == 0);
+        if (lane == 0) {
+            uint32_t* B = bold + (size_t)(ya + i) * wpitch + (bx >> 5);
+            B[0] = (uint32_t)bal;
+            B[1] = (uint32_t)(bal >> 32);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_canvas_paste(const uint8_t* __restrict__ src, uint8_t* __restrict__ canvas,
                                                       uint8_t* __restrict__ mask_old, int fh, int fw, int ch, int cw,
                                                       int row_off, int col_off, int* __restrict__ cbox) {
@@ -1149,7 +1291,7 @@ int rtvm_launch_weights(rtvm_ctx* c, int n) {
         const unsigned ex = roi_tiles(c->cw, bw, BR_TILE), ey = roi_tiles(c->ch, bh + 30, 4);
         RTVM_LAUNCH(c, k_blur_rows, dim3(xcd_grid(ex * ey), 1, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->cw);
     }
-    {
+    if (!c->fused_commit) {
         const unsigned ex = roi_tiles(c->cw, bw, 64), ey = roi_tiles(c->ch, bh, 4 * BC_ROWS);
         RTVM_LAUNCH(c, k_blur_cols, dim3(xcd_grid(ex * ey), 1, n), dim3(256), 0, c->d_wp, c->d_gk, c->d_side, c->ch, c->cw);
     }
@@ -1160,6 +1302,17 @@ int rtvm_launch_weights(rtvm_ctx* c, int n) {
 // Blend and commit of the n frames of the batch, in order.
 int rtvm_launch_commit(rtvm_ctx* c, int n) {
     const int wpitch = (c->cw + 31) / 32 + 2;
+    if (c->fused_commit) {   // the column pass of the blur runs inside the commit
+        const dim3 grid((c->cw + 63) / 64, (c->ch + 4 * BC_ROWS - 1) / (4 * BC_ROWS));
+        RTVM_LAUNCH(c, k_commit_cols<false>, grid, dim3(256), 0, c->d_wp, c->d_side, c->d_gk, n, c->d_mask_old, c->d_canvas,
+                    c->d_snap_mask, c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state, (const int*)(c->d_cbox + 4));
+        if (n > 1)
+            RTVM_LAUNCH(c, k_commit_cols<true>, grid, dim3(256), 0, c->d_wp, c->d_side, c->d_gk, n, c->d_mask_old, c->d_canvas,
+                        c->d_snap_mask, c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state,
+                        (const int*)(c->d_cbox + 4));
+        HIP_TRY(c, hipGetLastError());
+        return RTVM_OK;
+    }
     if (c->cw % 4 == 0) {
         const dim3 grid((c->cw + 255) / 256, (c->ch + 3) / 4);
         RTVM_LAUNCH(c, k_commit4<false>, grid, dim3(256), 0, c->d_wp, c->d_side, n, c->d_mask_old, c->d_canvas, c->d_snap_mask,

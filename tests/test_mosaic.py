@@ -193,12 +193,14 @@ def test_device_stream_path_matches_oracle(fixed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch,flags", [(1, 0), (3, 0), (4, 0), (6, 0), (7, 0), (4, 4), (6, 4)])
-def test_batched_stream_matches_oracle(batch, flags):
+@pytest.mark.parametrize("batch,flags,fused", [(1, 0, "0"), (3, 0, "1"), (4, 0, "0"), (6, 0, "1"), (7, 0, "0"), (4, 4, "1"),
+                                               (6, 4, "0"), (7, 0, "1")])
+def test_batched_stream_matches_oracle(batch, flags, fused, monkeypatch):
     """rtvm_process_batch: same canvas and homography as frame-by-frame processing, including a
     skipped frame in the middle of a batch (later frames come back as pending and are resubmitted)
     and at the end of a batch (the batch queued ahead of it comes back pending as a whole).
-    flags 4 = everything on one stream."""
+    flags 4 = everything on one stream; fused: the column pass of the blur inside the commit kernel, or not."""
+    monkeypatch.setenv("RTVM_FUSED_COMMIT", fused)
     import torch
     frames, _ = video(12, seed=6)
     order = [1, 2, 3, 4, 5, "flat", 6, 7, 8, 9, 10, 11]
@@ -288,11 +290,13 @@ def test_batches_queued_back_to_back():
 
 
 @pytest.mark.gpu
-def test_batch_with_pixels_that_blend_to_zero():
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_batch_with_pixels_that_blend_to_zero(fused, monkeypatch):
     """Two pixels of value 1 blend to 0 (the blurred weights add up to slightly less than 1), which
     clears the canvas mask there.  The batched path predicts the canvas masks of a batch ahead of
     time on the assumption that this does not happen; when it does, the later frames of the batch
     come back pending and are processed again: the result stays the frame-by-frame one."""
+    monkeypatch.setenv("RTVM_FUSED_COMMIT", fused)   # both ways of ending the canvas half rebuild the pixels of a bad piece
     import torch
     frames, _ = video(11, seed=9)
     frames = [f.copy() for f in frames]
@@ -322,10 +326,12 @@ def test_batch_with_pixels_that_blend_to_zero():
 
 
 @pytest.mark.gpu
-def test_batch_retry_queues_only_the_canvas_half_again():
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_batch_retry_queues_only_the_canvas_half_again(fused, monkeypatch):
     """rtvm_batch_retry: frames left pending because a blend cleared a canvas pixel keep their
     detection, matching and RANSAC results; their canvas half alone is queued again, for them and
     for the batch that was in flight behind them."""
+    monkeypatch.setenv("RTVM_FUSED_COMMIT", fused)
     import torch
     F = rtvm._ffi
     frames, _ = video(9, seed=9)

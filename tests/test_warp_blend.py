@@ -315,3 +315,30 @@ def test_hip_canvas_as_float64_is_the_u8_canvas_widened(ch, cw, fh, fw):
     assert f64.dtype == np.float64 and f64.shape == (ch, cw, 3)
     assert np.array_equal(f64, u8.astype(np.float64)) and np.array_equal(again, f64)
     assert u8[ch - fh:, (cw - fw) // 2:(cw - fw) // 2 + fw].tobytes() == first.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("cw,ch", [(160, 192), (163, 171), (257, 100)])
+def test_hip_blend_column_pass_inside_the_commit_or_as_a_kernel_of_its_own(fused, cw, ch, monkeypatch):
+    """The two ways the canvas half ends -- k_blur_cols + k_commit(4), or k_commit_cols with the column sums inside the
+    commit (the default from 4 megapixel frames on) -- against the oracle: a sequence of overlapping frames, canvas
+    sizes that are and are not multiples of the tiles (64 x 48) and of four, frames at the canvas' top and bottom rows
+    (reflected blur rows)."""
+    monkeypatch.setenv("RTVM_FUSED_COMMIT", fused)
+    frames, _ = frames_small(6)
+    ctx = rtvm.Context(FH, FW, ch, cw, nfeatures=300)
+    row_off, col_off = max(0, ch - FH), max(0, (cw - FW) // 2)
+    ctx.canvas_init(frames[0], row_off, col_off)
+    canvas = np.zeros((ch, cw, 3), np.uint8)
+    canvas[row_off:row_off + FH, col_off:col_off + FW] = frames[0][:ch - row_off, :cw - col_off]
+    Hs = [np.array([[1.0, 0.0, col_off + 3.5 * t], [0.0, 1.0, row_off - 9.25 * t], [0.0, 0.0, 1.0]]) for t in range(1, 6)]
+    Hs[3] = np.array([[0.98, 0.03, col_off - 6.0], [-0.03, 0.98, -5.0], [1e-5, -2e-5, 1.0]])     # up to the top rows
+    Hs[4] = np.array([[1.02, 0.0, col_off + 1.0], [0.0, 1.02, ch - FH * 0.6], [0.0, 0.0, 1.0]])   # over the bottom rows
+    for f, H in zip(frames[1:], Hs):
+        ctx.warp_blend(f, H)
+        canvas = orc.warp_blend(canvas, f, H, 0)
+    got = ctx.canvas_read()
+    ctx.close()
+    assert np.array_equal(got, canvas)
+    assert got[:8].any() and got[-8:].any()
