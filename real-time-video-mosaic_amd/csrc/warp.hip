@@ -708,32 +708,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 // rows per lane in the column pass of the blur (a workgroup of four waves covers 64 x 4*BC_ROWS pixels)
 constexpr int BC_ROWS = 12;
 
-// The column sums of BC_ROWS consecutive rows (ya ..) of column x from a window of 30 + BC_ROWS row-blurred pairs.
-template <bool EDGE>
+// The column sums of R consecutive rows (ya ..) of column x from a window of 30 + R row-blurred pairs.
+template <bool EDGE, int R>
 __device__ __forceinline__ void blur_cols_sums(const float* __restrict__ gk, const SideDev& side, int ch, int cw, int x,
-                                               int ya, f32x2 (&a)[BC_ROWS]) {
+                                               int ya, f32x2 (&a)[R]) {
     const auto rb = as_global<const f32x2>(side.rb);
-    f32x2 v[30 + BC_ROWS];
+    f32x2 v[30 + R];
 #pragma unroll
-    for (int j = 0; j < 30 + BC_ROWS; j++) {
+    for (int j = 0; j < 30 + R; j++) {
         const int y = EDGE ? reflect101(ya - 15 + j, ch) : ya - 15 + j;
         v[j] = rb[(size_t)y * cw + x];
     }
     {
         const float k0 = gk[15];
 #pragma unroll
-        for (int i = 0; i < BC_ROWS; i++) a[i] = f32x2{k0, k0} * v[15 + i];
+        for (int i = 0; i < R; i++) a[i] = f32x2{k0, k0} * v[15 + i];
     }
     // Groups of four sums as assembly, the four additions before the four multiply-adds, for the reason given
     // in the row pass: left to the scheduler every sum becomes one chain of add, wait state, multiply-add.
-    static_assert(BC_ROWS % 4 == 0, "the groups below take four sums");
+    static_assert(R % 4 == 0, "the groups below take four sums");
 #pragma unroll
-    for (int i = 0; i < BC_ROWS; i += 4) asm("s_nop 0" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
+    for (int i = 0; i < R; i += 4) asm("s_nop 0" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
 #pragma unroll
     for (int t = 1; t <= 15; t++) {
         const float kt = gk[15 + t];
 #pragma unroll
-        for (int i = 0; i < BC_ROWS; i += 4) {
+        for (int i = 0; i < R; i += 4) {
             f32x2 t0, t1, t2, t3;
             asm("v_pk_add_f32 %4, %8, %12\n\t"
                 "v_pk_add_f32 %5, %9, %13\n\t"
@@ -749,7 +749,7 @@ __device__ __forceinline__ void blur_cols_sums(const float* __restrict__ gk, con
         }
     }
 #pragma unroll
-    for (int i = 0; i < BC_ROWS; i += 4) asm("s_nop 0" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
+    for (int i = 0; i < R; i += 4) asm("s_nop 0" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
 }
 
 template <bool EDGE>
@@ -758,7 +758,7 @@ __device__ __forceinline__ void blur_cols_window(const WarpParams* __restrict__ 
                                                  const bool (&need)[BC_ROWS]) {
     const auto out_n = as_global(side.dist_new), out_o = as_global(side.dist_old);
     f32x2 a[BC_ROWS];
-    blur_cols_sums<EDGE>(gk, side, ch, cw, x, ya, a);
+    blur_cols_sums<EDGE, BC_ROWS>(gk, side, ch, cw, x, ya, a);
 #pragma unroll
     for (int i = 0; i < BC_ROWS; i++)
         if (need[i]) {
@@ -1035,13 +1035,17 @@ __global__ __launch_bounds__(256) void k_commit4(const WarpParams* __restrict__ 
 }
 
 // Column pass of the blur and commit in one kernel: the final blend weights never go to memory.  A wave is 64
-// columns x BC_ROWS rows of the canvas (lane = column, the rows' pixels in registers as B, G, R and the mask byte of
+// columns x CC_ROWS rows of the canvas (lane = column, the rows' pixels in registers as B, G, R and the mask byte of
 // one word each) and carries them through the frames of the batch in order, as k_commit does.  For a frame that
 // covers some of its pixels it fetches the frame's warped pixels; if any of them meets a non-zero canvas pixel it
 // fetches the window of row-blurred weight pairs and runs the column sums of blur_cols_sums (the same operations in
 // the same order as k_blur_cols: same weights), then blends.  Same results as k_blur_cols + k_commit.
 // What it saves: 8 bytes per pixel and frame written by the column pass and read back by the commit; and the
-// column sums where a frame lies on empty canvas.  blockIdx = tile of 64 x 4*BC_ROWS canvas pixels.
+// column sums where a frame lies on empty canvas.  blockIdx = tile of 64 x 4*CC_ROWS canvas pixels.
+// rows per lane of k_commit_cols: a window of 38 pairs for 8 sums (12 rows from 42 pairs as in k_blur_cols: 184
+// registers, two waves per SIMD and a third fewer waves: 51 against 37 us per 4K frame; 4 rows from 34: 51 us)
+constexpr int CC_ROWS = 8;
+
 template <bool REDO>
 __global__ __launch_bounds__(256) void k_commit_cols(const WarpParams* __restrict__ wps, const SideDev* __restrict__ sides,
                                                      const float* __restrict__ gk, int n, uint8_t* __restrict__ mask_old,
@@ -1054,24 +1058,24 @@ __global__ __launch_bounds__(256) void k_commit_cols(const WarpParams* __restric
         last = st->bad_frame;
         if (last >= n - 1) return;  // every frame was applied with the right weights
     }
-    const int bx = blockIdx.x * 64, by = blockIdx.y * (4 * BC_ROWS);
-    if (bx >= ubox[2] || bx + 64 <= ubox[0] || by >= ubox[3] || by + 4 * BC_ROWS <= ubox[1]) return;
+    const int bx = blockIdx.x * 64, by = blockIdx.y * (4 * CC_ROWS);
+    if (bx >= ubox[2] || bx + 64 <= ubox[0] || by >= ubox[3] || by + 4 * CC_ROWS <= ubox[1]) return;
     const int lane = threadIdx.x & 63;
-    const int x = bx + lane, ya = by + BC_ROWS * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = bx + lane, ya = by + CC_ROWS * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (ya >= ch) return;
     // the frames of the batch that touch this wave's pixels, one bit each (a batch has at most 32 frames)
     uint32_t frames = 0;
     for (int j = 0; j < n; j++) {
         const WarpParams* __restrict__ wp = wps + j;
-        if (ya < wp->ry1 && ya + BC_ROWS > wp->ry0 && bx < wp->rx1 && bx + 64 > wp->rx0) frames |= 1u << j;
+        if (ya < wp->ry1 && ya + CC_ROWS > wp->ry0 && bx < wp->rx1 && bx + 64 > wp->rx0) frames |= 1u << j;
     }
     if (!frames) return;
     const bool oncanvas = x < cw;
-    const int rows = min(BC_ROWS, ch - ya);   // the same for the whole wave
+    const int rows = min(CC_ROWS, ch - ya);   // the same for the whole wave
     const uint32_t p0 = (uint32_t)ya * (uint32_t)cw + (uint32_t)(oncanvas ? x : 0);
-    uint32_t cv[BC_ROWS];   // B | G << 8 | R << 16 | mask << 24
+    uint32_t cv[CC_ROWS];   // B | G << 8 | R << 16 | mask << 24
 #pragma unroll
-    for (int i = 0; i < BC_ROWS; i++) {
+    for (int i = 0; i < CC_ROWS; i++) {
         cv[i] = 0xFF000000u;
         if (oncanvas && i < rows) {
             const uint32_t p = p0 + (uint32_t)i * (uint32_t)cw;
@@ -1088,49 +1092,49 @@ __global__ __launch_bounds__(256) void k_commit_cols(const WarpParams* __restric
         }
     }
     uint32_t changed = REDO ? 0xFFFFFFFFu : 0u;   // bit i: row i was written to
-    const bool edge = !(ya - 15 >= 0 && ya + BC_ROWS + 15 <= ch);   // wave-uniform
+    const bool edge = !(ya - 15 >= 0 && ya + CC_ROWS + 15 <= ch);   // wave-uniform
     // The warped pixels of a frame are requested while the frame before it is being blended: a wave walks its
     // frames one after the other, and with few waves per SIMD nothing else hides the round trips.
-    auto fetch = [&](int j, uint32_t (&px)[BC_ROWS], bool& col_in) {
+    auto fetch = [&](int j, uint32_t (&px)[CC_ROWS], bool& col_in) {
         const WarpParams* __restrict__ wp = wps + j;
         const int rx0 = wp->rx0, rx1 = wp->rx1, ry0 = wp->ry0, ry1 = wp->ry1;
         col_in = oncanvas && x >= rx0 && x < rx1;
 #pragma unroll
-        for (int i = 0; i < BC_ROWS; i++) {
+        for (int i = 0; i < CC_ROWS; i++) {
             px[i] = 0;
             if (col_in && ya + i >= ry0 && ya + i < ry1)
                 px[i] = as_global<const uint32_t>(sides[j].warped)[p0 + (uint32_t)i * (uint32_t)cw];
         }
     };
     if (last < 31) frames &= (2u << last) - 1u;
-    uint32_t pxn[BC_ROWS];
+    uint32_t pxn[CC_ROWS];
     bool col_in_n = false;
     if (frames) fetch(__builtin_ctz(frames), pxn, col_in_n);
     while (frames) {
         const int j = __builtin_ctz(frames);
         frames &= frames - 1u;
-        uint32_t px[BC_ROWS];
+        uint32_t px[CC_ROWS];
         const bool col_in = col_in_n;
 #pragma unroll
-        for (int i = 0; i < BC_ROWS; i++) px[i] = pxn[i];
+        for (int i = 0; i < CC_ROWS; i++) px[i] = pxn[i];
         if (frames) fetch(__builtin_ctz(frames), pxn, col_in_n);
         bool blend = false;
 #pragma unroll
-        for (int i = 0; i < BC_ROWS; i++) blend |= (px[i] >> 24) && (cv[i] >> 24);
-        f32x2 a[BC_ROWS];
+        for (int i = 0; i < CC_ROWS; i++) blend |= (px[i] >> 24) && (cv[i] >> 24);
+        f32x2 a[CC_ROWS];
 #pragma unroll
-        for (int i = 0; i < BC_ROWS; i++) a[i] = f32x2{0.f, 0.f};
+        for (int i = 0; i < CC_ROWS; i++) a[i] = f32x2{0.f, 0.f};
         if (__any(blend)) {
             // the lanes outside the frame's columns hold no pixel of it: their sums are never looked at
             if (col_in) {
                 if (edge)
-                    blur_cols_sums<true>(gk, sides[j], ch, cw, x, ya, a);
+                    blur_cols_sums<true, CC_ROWS>(gk, sides[j], ch, cw, x, ya, a);
                 else
-                    blur_cols_sums<false>(gk, sides[j], ch, cw, x, ya, a);
+                    blur_cols_sums<false, CC_ROWS>(gk, sides[j], ch, cw, x, ya, a);
             }
         }
 #pragma unroll
-        for (int i = 0; i < BC_ROWS; i++) {
+        for (int i = 0; i < CC_ROWS; i++) {
             if (!(px[i] >> 24)) continue;  // outside the frame's mask (or its region)
             const int w0 = px[i] & 255, w1 = (px[i] >> 8) & 255, w2 = (px[i] >> 16) & 255;
             changed |= 1u << i;
@@ -1151,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_commit_cols(const WarpParams* __restric
         }
     }
 #pragma unroll
-    for (int i = 0; i < BC_ROWS; i++) {
+    for (int i = 0; i < CC_ROWS; i++) {
         if (i >= rows) continue;
         const uint32_t p = p0 + (uint32_t)i * (uint32_t)cw;
         if (oncanvas && ((changed >> i) & 1u)) {
@@ -1303,7 +1307,7 @@ int rtvm_launch_weights(rtvm_ctx* c, int n) {
 int rtvm_launch_commit(rtvm_ctx* c, int n) {
     const int wpitch = (c->cw + 31) / 32 + 2;
     if (c->fused_commit) {   // the column pass of the blur runs inside the commit
-        const dim3 grid((c->cw + 63) / 64, (c->ch + 4 * BC_ROWS - 1) / (4 * BC_ROWS));
+        const dim3 grid((c->cw + 63) / 64, (c->ch + 4 * CC_ROWS - 1) / (4 * CC_ROWS));
         RTVM_LAUNCH(c, k_commit_cols<false>, grid, dim3(256), 0, c->d_wp, c->d_side, c->d_gk, n, c->d_mask_old, c->d_canvas,
                     c->d_snap_mask, c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state, (const int*)(c->d_cbox + 4));
         if (n > 1)
