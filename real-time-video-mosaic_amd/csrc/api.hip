@@ -627,9 +627,9 @@ extern "C" int rtvm_create(rtvm_ctx** out, int device, int frame_h, int frame_w,
     }
     c->stream = c->stream_main;
     // The column pass of the blur inside the commit kernel saves 16 bytes of traffic per pixel and frame and costs
-    // parallelism (one wave walks the frames of a piece in order): measured +7 % at 2160 x 3840 (9700 tiles per frame
-    // region), +4 % at 1080p (2400 tiles), -1 % at 720p (540 tiles).  RTVM_FUSED_COMMIT=0/1 overrides (tests run both).
-    c->fused_commit = (long long)frame_h * frame_w >= 1500000;
+    // parallelism (one wave walks the frames of a piece in order): measured +8 % at 2160 x 3840, +5 % at 1080p, +1 %
+    // at 720p, -3 % at 360p (1100 waves per piece).  RTVM_FUSED_COMMIT=0/1 overrides (tests run both).
+    c->fused_commit = (long long)frame_h * frame_w >= 800000;
     if (const char* e = getenv("RTVM_FUSED_COMMIT")) c->fused_commit = atoi(e) != 0;
     int r = alloc_all(c);
     if (r != RTVM_OK) {

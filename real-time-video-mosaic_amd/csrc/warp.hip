@@ -1041,13 +1041,15 @@ __global__ __launch_bounds__(256) void k_commit4(const WarpParams* __restrict__ 
 // fetches the window of row-blurred weight pairs and runs the column sums of blur_cols_sums (the same operations in
 // the same order as k_blur_cols: same weights), then blends.  Same results as k_blur_cols + k_commit.
 // What it saves: 8 bytes per pixel and frame written by the column pass and read back by the commit; and the
-// column sums where a frame lies on empty canvas.  blockIdx = tile of 64 x 4*CC_ROWS canvas pixels.
+// column sums where a frame lies on empty canvas.  blockIdx = tile of 64 x CC_WAVES*CC_ROWS canvas pixels.
 // rows per lane of k_commit_cols: a window of 38 pairs for 8 sums (12 rows from 42 pairs as in k_blur_cols: 184
 // registers, two waves per SIMD and a third fewer waves: 51 against 37 us per 4K frame; 4 rows from 34: 51 us)
 constexpr int CC_ROWS = 8;
+// waves per workgroup (no wave needs another: one-wave workgroups spread most evenly over the compute units)
+constexpr int CC_WAVES = 1;
 
 template <bool REDO>
-__global__ __launch_bounds__(256) void k_commit_cols(const WarpParams* __restrict__ wps, const SideDev* __restrict__ sides,
+__global__ __launch_bounds__(64 * CC_WAVES) void k_commit_cols(const WarpParams* __restrict__ wps, const SideDev* __restrict__ sides,
                                                      const float* __restrict__ gk, int n, uint8_t* __restrict__ mask_old,
                                                      uint8_t* __restrict__ canvas, uint8_t* __restrict__ snap_mask,
                                                      uint8_t* __restrict__ snap_canvas, uint32_t* __restrict__ bold,
@@ -1058,8 +1060,8 @@ __global__ __launch_bounds__(256) void k_commit_cols(const WarpParams* __restric
         last = st->bad_frame;
         if (last >= n - 1) return;  // every frame was applied with the right weights
     }
-    const int bx = blockIdx.x * 64, by = blockIdx.y * (4 * CC_ROWS);
-    if (bx >= ubox[2] || bx + 64 <= ubox[0] || by >= ubox[3] || by + 4 * CC_ROWS <= ubox[1]) return;
+    const int bx = blockIdx.x * 64, by = blockIdx.y * (CC_WAVES * CC_ROWS);
+    if (bx >= ubox[2] || bx + 64 <= ubox[0] || by >= ubox[3] || by + CC_WAVES * CC_ROWS <= ubox[1]) return;
     const int lane = threadIdx.x & 63;
     const int x = bx + lane, ya = by + CC_ROWS * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (ya >= ch) return;
@@ -1307,11 +1309,11 @@ int rtvm_launch_weights(rtvm_ctx* c, int n) {
 int rtvm_launch_commit(rtvm_ctx* c, int n) {
     const int wpitch = (c->cw + 31) / 32 + 2;
     if (c->fused_commit) {   // the column pass of the blur runs inside the commit
-        const dim3 grid((c->cw + 63) / 64, (c->ch + 4 * CC_ROWS - 1) / (4 * CC_ROWS));
-        RTVM_LAUNCH(c, k_commit_cols<false>, grid, dim3(256), 0, c->d_wp, c->d_side, c->d_gk, n, c->d_mask_old, c->d_canvas,
+        const dim3 grid((c->cw + 63) / 64, (c->ch + CC_WAVES * CC_ROWS - 1) / (CC_WAVES * CC_ROWS));
+        RTVM_LAUNCH(c, k_commit_cols<false>, grid, dim3(64 * CC_WAVES), 0, c->d_wp, c->d_side, c->d_gk, n, c->d_mask_old, c->d_canvas,
                     c->d_snap_mask, c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state, (const int*)(c->d_cbox + 4));
         if (n > 1)
-            RTVM_LAUNCH(c, k_commit_cols<true>, grid, dim3(256), 0, c->d_wp, c->d_side, c->d_gk, n, c->d_mask_old, c->d_canvas,
+            RTVM_LAUNCH(c, k_commit_cols<true>, grid, dim3(64 * CC_WAVES), 0, c->d_wp, c->d_side, c->d_gk, n, c->d_mask_old, c->d_canvas,
                         c->d_snap_mask, c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state,
                         (const int*)(c->d_cbox + 4));
         HIP_TRY(c, hipGetLastError());

@@ -322,8 +322,8 @@ def test_hip_canvas_as_float64_is_the_u8_canvas_widened(ch, cw, fh, fw):
 @pytest.mark.parametrize("cw,ch", [(160, 192), (163, 171), (257, 100)])
 def test_hip_blend_column_pass_inside_the_commit_or_as_a_kernel_of_its_own(fused, cw, ch, monkeypatch):
     """The two ways the canvas half ends -- k_blur_cols + k_commit(4), or k_commit_cols with the column sums inside the
-    commit (the default for frames of 1.5 megapixels and more) -- against the oracle: a sequence of overlapping frames, canvas
-    sizes that are and are not multiples of the tiles (64 x 48 and 64 x 32) and of four, frames at the canvas' top and bottom rows
+    commit (the default for frames of 0.8 megapixels and more) -- against the oracle: a sequence of overlapping frames, canvas
+    sizes that are and are not multiples of the tiles (64 x 48 and 64 x 8) and of four, frames at the canvas' top and bottom rows
     (reflected blur rows)."""
     monkeypatch.setenv("RTVM_FUSED_COMMIT", fused)
     frames, _ = frames_small(6)
