@@ -1049,19 +1049,11 @@ constexpr int CC_ROWS = 8;
 constexpr int CC_WAVES = 1;
 
 template <bool REDO>
-__global__ __launch_bounds__(64 * CC_WAVES) void k_commit_cols(const WarpParams* __restrict__ wps, const SideDev* __restrict__ sides,
-                                                     const float* __restrict__ gk, int n, uint8_t* __restrict__ mask_old,
-                                                     uint8_t* __restrict__ canvas, uint8_t* __restrict__ snap_mask,
-                                                     uint8_t* __restrict__ snap_canvas, uint32_t* __restrict__ bold,
-                                                     int wpitch, int ch, int cw, StreamState* __restrict__ st,
-                                                     const int* __restrict__ ubox) {
-    int last = n - 1;
-    if (REDO) {
-        last = st->bad_frame;
-        if (last >= n - 1) return;  // every frame was applied with the right weights
-    }
-    const int bx = blockIdx.x * 64, by = blockIdx.y * (CC_WAVES * CC_ROWS);
-    if (bx >= ubox[2] || bx + 64 <= ubox[0] || by >= ubox[3] || by + CC_WAVES * CC_ROWS <= ubox[1]) return;
+__device__ __forceinline__ void commit_cols_tile(const WarpParams* __restrict__ wps, const SideDev* __restrict__ sides,
+                                                 const float* __restrict__ gk, int n, int last, uint8_t* __restrict__ mask_old,
+                                                 uint8_t* __restrict__ canvas, uint8_t* __restrict__ snap_mask,
+                                                 uint8_t* __restrict__ snap_canvas, uint32_t* __restrict__ bold,
+                                                 int wpitch, int ch, int cw, StreamState* __restrict__ st, int bx, int by) {
     const int lane = threadIdx.x & 63;
     const int x = bx + lane, ya = by + CC_ROWS * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (ya >= ch) return;
@@ -1173,6 +1165,32 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k_commit_cols(const WarpParams*
             B[1] = (uint32_t)(bal >> 32);
         }
     }
+}
+
+// blockIdx = tile of the canvas.  REDO runs after the optimistic pass, as a small grid that walks the tiles of the
+// batch's box only if a frame went bad (its workgroups leave at once otherwise, which is the usual case).
+template <bool REDO>
+__global__ __launch_bounds__(64 * CC_WAVES) void k_commit_cols(const WarpParams* __restrict__ wps, const SideDev* __restrict__ sides,
+                                                     const float* __restrict__ gk, int n, uint8_t* __restrict__ mask_old,
+                                                     uint8_t* __restrict__ canvas, uint8_t* __restrict__ snap_mask,
+                                                     uint8_t* __restrict__ snap_canvas, uint32_t* __restrict__ bold,
+                                                     int wpitch, int ch, int cw, StreamState* __restrict__ st,
+                                                     const int* __restrict__ ubox) {
+    constexpr int TH = CC_WAVES * CC_ROWS;
+    if (!REDO) {
+        const int bx = blockIdx.x * 64, by = blockIdx.y * TH;
+        if (bx >= ubox[2] || bx + 64 <= ubox[0] || by >= ubox[3] || by + TH <= ubox[1]) return;
+        commit_cols_tile<false>(wps, sides, gk, n, n - 1, mask_old, canvas, snap_mask, snap_canvas, bold, wpitch, ch, cw, st, bx, by);
+        return;
+    }
+    const int last = st->bad_frame;
+    if (last >= n - 1) return;  // every frame was applied with the right weights
+    const int tx0 = max(ubox[0], 0) / 64, tx1 = (min(ubox[2], cw) + 63) / 64;
+    const int ty0 = max(ubox[1], 0) / TH, ty1 = (min(ubox[3], ch) + TH - 1) / TH;
+    const int ntx = tx1 - tx0, T = ntx * (ty1 - ty0);
+    for (int t = blockIdx.x; t < T; t += gridDim.x)
+        commit_cols_tile<true>(wps, sides, gk, n, last, mask_old, canvas, snap_mask, snap_canvas, bold, wpitch, ch, cw, st,
+                               (tx0 + t % ntx) * 64, (ty0 + t / ntx) * TH);
 }
 
 __global__ __launch_bounds__(256) void k_canvas_paste(const uint8_t* __restrict__ src, uint8_t* __restrict__ canvas,
@@ -1313,7 +1331,7 @@ int rtvm_launch_commit(rtvm_ctx* c, int n) {
         RTVM_LAUNCH(c, k_commit_cols<false>, grid, dim3(64 * CC_WAVES), 0, c->d_wp, c->d_side, c->d_gk, n, c->d_mask_old, c->d_canvas,
                     c->d_snap_mask, c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state, (const int*)(c->d_cbox + 4));
         if (n > 1)
-            RTVM_LAUNCH(c, k_commit_cols<true>, grid, dim3(64 * CC_WAVES), 0, c->d_wp, c->d_side, c->d_gk, n, c->d_mask_old, c->d_canvas,
+            RTVM_LAUNCH(c, k_commit_cols<true>, dim3(1024), dim3(64 * CC_WAVES), 0, c->d_wp, c->d_side, c->d_gk, n, c->d_mask_old, c->d_canvas,
                         c->d_snap_mask, c->d_snap_canvas, c->d_bold, wpitch, c->ch, c->cw, c->d_state,
                         (const int*)(c->d_cbox + 4));
         HIP_TRY(c, hipGetLastError());
