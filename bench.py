@@ -38,6 +38,7 @@ CONFIGS = {
     "1080p_orb1000": (1080, 1920, 2160, 2304, 1000),
     "4k_orb4000_canvas16k": (2160, 3840, 4096, 16384, 4000),
     "360p_orb700": (360, 640, 720, 768, 700),
+    "540p_orb1000": (540, 960, 1080, 1152, 1000),
     "1080p_sift2000_l2": (1080, 1920, 2160, 2304, 2000),
     # the reference's default detector (main.py:1603) through the same device-resident pipeline
     "720p_sift700": (720, 1280, 1440, 1536, 700),
