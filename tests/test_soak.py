@@ -9,10 +9,10 @@ from rtvm import synth
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("detector,nf,n", [("orb", 500, 1300), ("sift", 300, 400)])
-def test_long_video_pipe_process_video_and_frame_by_frame_agree(detector, nf, n, capsys):
+@pytest.mark.parametrize("detector,nf,n,fh,fw", [("orb", 500, 1300, 240, 320), ("sift", 300, 400, 240, 320),
+                                                 ("orb", 1000, 1024, 720, 1280)])
+def test_long_video_pipe_process_video_and_frame_by_frame_agree(detector, nf, n, fh, fw, capsys):
     import torch
-    fh, fw = 240, 320
     ch, cw = 2 * fh, int(1.2 * fw)
     Gs, wh, ww = synth.bounded_path(n + 1, fh, fw, seed=11, margin=100)
     world = synth.make_world(wh, ww, seed=4)
